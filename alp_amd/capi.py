@@ -1,0 +1,164 @@
+"""ctypes binding of the C ABI in include/alpgpu.h (libalpgpu.so) — Python-side plumbing only.
+
+The codec runs entirely in hand-written HIP kernels behind the C ABI; this module passes raw device
+pointers (from torch tensors, which are used purely as an HBM allocator + stream provider) and sizes.
+There is no CPU fallback: importing works anywhere (the .so links only the HIP runtime), but creating a
+Context without a gfx950 device raises, and a missing libalpgpu.so raises at import.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libalpgpu.so")
+
+VECTOR_SIZE = 1024
+ROWGROUP_VECTORS = 100
+SCHEME_ALP_RD = 1
+SCHEME_ALP = 2
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  alp_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+# numpy mirrors of the two HBM record types (include/alpgpu.h)
+ROWGROUP_DTYPE = np.dtype([
+    ("scheme", np.uint8), ("k", np.uint8), ("combos", np.uint8, (10,)), ("rd_rbw", np.uint8), ("rd_lbw", np.uint8),
+    ("rd_dict_size", np.uint8), ("pad", np.uint8), ("rd_dict", np.uint16, (8,)),
+], align=False)
+VECTOR_DTYPE = np.dtype([
+    ("packed_off", np.uint64), ("exc_off", np.uint64), ("base", np.int64), ("bw", np.uint8), ("e", np.uint8),
+    ("f", np.uint8), ("lbw", np.uint8), ("exc_cnt", np.uint16), ("scheme", np.uint16),
+], align=False)
+assert ROWGROUP_DTYPE.itemsize == 32 and VECTOR_DTYPE.itemsize == 32
+
+
+class CColumn(C.Structure):
+    _fields_ = [
+        ("n_vectors", C.c_uint64), ("n_rowgroups", C.c_uint64), ("d_rowgroups", C.c_void_p), ("d_vectors", C.c_void_p),
+        ("d_packed", C.c_void_p), ("packed_capacity", C.c_uint64), ("d_exc", C.c_void_p), ("exc_capacity", C.c_uint64),
+        ("d_totals", C.c_void_p),
+    ]
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_vp, _u64, _sz, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
+_sig("alpgpu_abi_version", _int)
+_sig("alpgpu_last_error", C.c_char_p)
+_sig("alpgpu_ctx_create", _int, _int, C.POINTER(_vp))
+_sig("alpgpu_ctx_destroy", None, _vp)
+_sig("alpgpu_set_stream", _int, _vp, _vp)
+_sig("alpgpu_synchronize", _int, _vp)
+_sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
+_sig("alpgpu_packed_capacity", _u64, _u64)
+_sig("alpgpu_exc_capacity", _u64, _u64)
+_sig("alpgpu_decode_f64", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_column_totals", _int, _vp, C.POINTER(CColumn), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_int))
+
+
+class AlpGpuError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise AlpGpuError(f"{what} failed ({rc}): {lib.alpgpu_last_error().decode()}")
+
+
+class Context:
+    """One per device / process.  Uses torch's current stream unless told otherwise."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        h = _vp()
+        _check(lib.alpgpu_ctx_create(device, C.byref(h)), "alpgpu_ctx_create")
+        self.h = h
+        self.device = device
+        if use_torch_stream:
+            import torch
+            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.alpgpu_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle: int):
+        _check(lib.alpgpu_set_stream(self.h, _vp(stream_handle)), "alpgpu_set_stream")
+
+    def synchronize(self):
+        _check(lib.alpgpu_synchronize(self.h), "alpgpu_synchronize")
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(128)
+        cus, hbm = _int(), _u64()
+        _check(lib.alpgpu_device_info(self.h, name, 128, C.byref(cus), C.byref(hbm)), "alpgpu_device_info")
+        return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": hbm.value}
+
+    # ---- whole-column path ------------------------------------------------------------------------
+    def decode(self, col: "DeviceColumn", out=None):
+        import torch
+        if out is None:
+            out = torch.empty(col.n_vectors * VECTOR_SIZE, dtype=torch.float64, device=f"cuda:{self.device}")
+        assert out.is_contiguous() and out.numel() >= col.n_vectors * VECTOR_SIZE and out.dtype == torch.float64
+        _check(lib.alpgpu_decode_f64(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_decode_f64")
+        return out
+
+
+class DeviceColumn:
+    """A compressed column in HBM (struct alpgpu_column) whose buffers are torch uint8 tensors."""
+
+    def __init__(self, n_vectors: int, device: int = 0, packed_capacity: int | None = None,
+                 exc_capacity: int | None = None):
+        import torch
+        dev = f"cuda:{device}"
+        self.n_vectors = int(n_vectors)
+        self.n_rowgroups = (self.n_vectors + ROWGROUP_VECTORS - 1) // ROWGROUP_VECTORS
+        pc = int(lib.alpgpu_packed_capacity(self.n_vectors)) if packed_capacity is None else int(packed_capacity)
+        ec = int(lib.alpgpu_exc_capacity(self.n_vectors)) if exc_capacity is None else int(exc_capacity)
+        self.rowgroups = torch.zeros(max(1, self.n_rowgroups) * 32, dtype=torch.uint8, device=dev)
+        self.vectors = torch.zeros(max(1, self.n_vectors) * 32, dtype=torch.uint8, device=dev)
+        self.packed = torch.zeros(pc, dtype=torch.uint8, device=dev)
+        self.exc = torch.zeros(ec, dtype=torch.uint8, device=dev)
+        self.totals = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.c = CColumn(self.n_vectors, self.n_rowgroups, self.rowgroups.data_ptr(), self.vectors.data_ptr(),
+                         self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr())
+
+    @classmethod
+    def from_host(cls, rowgroups: np.ndarray, vectors: np.ndarray, packed: np.ndarray, exc: np.ndarray, device: int = 0):
+        """Upload host-side records/streams (numpy; see ROWGROUP_DTYPE / VECTOR_DTYPE)."""
+        import torch
+        n = vectors.size
+        col = cls(n, device, packed_capacity=packed.size + 1024, exc_capacity=exc.size + 64)
+        col.rowgroups[: rowgroups.size * 32] = torch.from_numpy(rowgroups.view(np.uint8).reshape(-1)).to(col.rowgroups.device)
+        col.vectors[: n * 32] = torch.from_numpy(vectors.view(np.uint8).reshape(-1)).to(col.vectors.device)
+        col.packed[: packed.size] = torch.from_numpy(packed).to(col.packed.device)
+        col.exc[: exc.size] = torch.from_numpy(exc).to(col.exc.device)
+        col.totals[0] = packed.size
+        col.totals[1] = exc.size
+        return col
+
+    def to_host(self):
+        rg = self.rowgroups.cpu().numpy().view(ROWGROUP_DTYPE)[: self.n_rowgroups]
+        vec = self.vectors.cpu().numpy().view(VECTOR_DTYPE)[: self.n_vectors]
+        tot = self.totals.cpu().numpy()
+        packed = self.packed[: int(tot[0])].cpu().numpy()
+        exc = self.exc[: int(tot[1])].cpu().numpy()
+        return rg, vec, packed, exc

@@ -1,0 +1,183 @@
+// alp_device.hpp — shared device-side building blocks for the gfx950 ALP kernels.
+//
+// Execution model used by every kernel in this directory: ONE 64-lane wavefront owns ONE 1024-value
+// vector.  Value i of the vector is handled by lane (i >> 1) & 63 in step m = i >> 7, i.e. a lane owns
+// the value PAIR (128*m + 2*lane, +1) for m = 0..7, so that every global access to the doubles is a
+// 16-byte-per-lane, 1-KiB-per-instruction contiguous transaction.
+//
+// FastLanes u64 layout (reference src/fastlanes_generated_ffor.cpp:7379-29749, closed form SURVEY.md §8 A9):
+//   value i -> lane16 = i & 15, row = i >> 4; the lane's stream is the LSB-first concatenation of its 64
+//   bw-bit fields; stream word k lives at packed[16*k + lane16].
+// With the pair mapping a lane's two values share the row (8*m + (lane >> 3)) and sit in adjacent
+// lane16 columns (2*(lane & 7), +1), so their packed words are one aligned 16-byte unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/alpgpu.h"
+
+namespace alpgpu {
+
+constexpr int kVec        = 1024;
+constexpr int kRowgroup   = 100;
+constexpr int kWavesPerWg = 4;
+
+// ---- constants (reference include/alp/constants.hpp:66-154): bit-identical tables --------------------
+__device__ __constant__ const double kFracArr[21] = {
+    1.0,
+    0.1,
+    0.01,
+    0.001,
+    0.0001,
+    0.00001,
+    0.000001,
+    0.0000001,
+    0.00000001,
+    0.000000001,
+    0.0000000001,
+    0.00000000001,
+    0.000000000001,
+    0.0000000000001,
+    0.00000000000001,
+    0.000000000000001,
+    0.0000000000000001,
+    0.00000000000000001,
+    0.000000000000000001,
+    0.0000000000000000001,
+    0.00000000000000000001,
+};
+__device__ __constant__ const double kExpArr[24] = {
+    1.0,
+    10.0,
+    100.0,
+    1000.0,
+    10000.0,
+    100000.0,
+    1000000.0,
+    10000000.0,
+    100000000.0,
+    1000000000.0,
+    10000000000.0,
+    100000000000.0,
+    1000000000000.0,
+    10000000000000.0,
+    100000000000000.0,
+    1000000000000000.0,
+    10000000000000000.0,
+    100000000000000000.0,
+    1000000000000000000.0,
+    10000000000000000000.0,
+    100000000000000000000.0,
+    1000000000000000000000.0,
+    10000000000000000000000.0,
+    100000000000000000000000.0,
+};
+__device__ __constant__ const int64_t kFactArr[19] = {1LL,
+                                                      10LL,
+                                                      100LL,
+                                                      1000LL,
+                                                      10000LL,
+                                                      100000LL,
+                                                      1000000LL,
+                                                      10000000LL,
+                                                      100000000LL,
+                                                      1000000000LL,
+                                                      10000000000LL,
+                                                      100000000000LL,
+                                                      1000000000000LL,
+                                                      10000000000000LL,
+                                                      100000000000000LL,
+                                                      1000000000000000LL,
+                                                      10000000000000000LL,
+                                                      100000000000000000LL,
+                                                      1000000000000000000LL};
+
+constexpr double kMagic      = 6755399441055744.0;     // 2^52 + 2^51, constants.hpp:70
+constexpr double kUpperLimit = 9223372036854774784.0;  // constants.hpp:17
+constexpr double kLowerLimit = -9223372036854774784.0; // constants.hpp:18
+
+// ---- wave helpers -----------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
+__device__ __forceinline__ int wave_in_wg() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
+
+// Orders this wave's LDS traffic (and the compiler) around an intra-wave exchange.  The LDS unit executes
+// one wave's DS operations in issue order, so no hardware barrier is needed between lanes of one wave.
+__device__ __forceinline__ void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint64_t bw_mask(int bw) { return bw >= 64 ? ~0ULL : ((1ULL << bw) - 1ULL); }
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x) {
+	const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x));
+	const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x >> 32));
+	return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// ---- scalar codec arithmetic --------------------------------------------------
+
+// static_cast<int64_t>(double) with x86-64 semantics (cvttsd2si): NaN / |x| >= 2^63 -> INT64_MIN.
+// The reference relies on this at include/alp/encoder.hpp:88.
+__device__ __forceinline__ int64_t cast64_x86(double x) {
+	const bool in_range = (x > -9223372036854775808.0) && (x < 9223372036854775808.0);
+	return in_range ? static_cast<int64_t>(x) : INT64_MIN;
+}
+
+// include/alp/decoder.hpp:128-131 — wrap-around integer multiply, exact int64->double, one FP multiply
+__device__ __forceinline__ double decode_value(int64_t enc, int64_t fact, double frac) {
+	const int64_t m = static_cast<int64_t>(static_cast<uint64_t>(enc) * static_cast<uint64_t>(fact));
+	return static_cast<double>(m) * frac;
+}
+
+// include/alp/encoder.hpp:81-89 with SAFE = false.  Compiled with -ffp-contract=off: two multiplies, one
+// add, one subtract, each rounded.
+__device__ __forceinline__ int64_t encode_value_unsafe(double v, double exp10, double frac10) {
+	double t = v * exp10;
+	t        = t * frac10;
+	t        = t + kMagic;
+	t        = t - kMagic;
+	return cast64_x86(t);
+}
+
+// include/alp/encoder.hpp:75-89 with SAFE = true
+__device__ __forceinline__ int64_t encode_value_safe(double v, double exp10, double frac10) {
+	double t = v * exp10;
+	t        = t * frac10;
+	const bool impossible = !(__builtin_fabs(t) <= 1.7976931348623157e308) /* inf or nan */ || t > kUpperLimit ||
+	                        t < kLowerLimit || (t == 0.0 && __builtin_signbit(t));
+	if (impossible) { return static_cast<int64_t>(kUpperLimit); }
+	t = t + kMagic;
+	t = t - kMagic;
+	return cast64_x86(t);
+}
+
+// include/alp/encoder.hpp:91-106
+__device__ __forceinline__ int count_bits(int64_t mx, int64_t mn) {
+	const uint64_t d = static_cast<uint64_t>(mx) - static_cast<uint64_t>(mn);
+	return d == 0 ? 0 : 64 - __builtin_clzll(d);
+}
+
+// ---- FastLanes u64 unpack of one value pair from a staged copy of the vector's packed words -----------
+// words16: the vector's packed stream viewed as 16-byte units (unit index = 8*k + a holds stream word k of
+// lane16 columns 2a and 2a+1).  One extra unit row past the end must be readable (content irrelevant).
+struct U64Pair {
+	uint64_t x, y;
+};
+
+template <typename Units>
+__device__ __forceinline__ U64Pair unpack_pair_u64(const Units& units, int bw, uint64_t mask, int row, int a) {
+	const int p = row * bw;
+	const int k = p >> 6;
+	const int s = p & 63;
+	const ulonglong2 w0 = units(8 * k + a);
+	const ulonglong2 w1 = units(8 * k + 8 + a);
+	U64Pair          r;
+	// (w1 << (64 - s)) without the undefined shift by 64 when s == 0
+	r.x = ((w0.x >> s) | ((w1.x << 1) << (63 - s))) & mask;
+	r.y = ((w0.y >> s) | ((w1.y << 1) << (63 - s))) & mask;
+	return r;
+}
+
+} // namespace alpgpu

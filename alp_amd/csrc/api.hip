@@ -1,0 +1,175 @@
+// api.hip — the extern "C" surface declared in include/alpgpu.h.  Thin: argument checks, stream selection,
+// kernel launches.  No codec arithmetic lives here and there is no CPU path: without a gfx950 device
+// alpgpu_ctx_create fails and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/alpgpu.h"
+#include "launch.hpp"
+
+struct alpgpu_ctx {
+	int         device;
+	hipStream_t own_stream;
+	hipStream_t stream;
+	int         n_cus;
+	int         decode_variant;
+	char        name[128];
+	uint64_t    hbm_bytes;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+	if (e != hipSuccess) {
+		std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+	} else {
+		std::snprintf(g_err, sizeof(g_err), "%s", what);
+	}
+	return code;
+}
+
+#define ALPGPU_HIP(call)                                                                                                \
+	do {                                                                                                                \
+		hipError_t e_ = (call);                                                                                         \
+		if (e_ != hipSuccess) { return fail(ALPGPU_ERR_HIP, #call, e_); }                                               \
+	} while (0)
+
+#define ALPGPU_CHECK_CTX(ctx)                                                                                           \
+	do {                                                                                                                \
+		if (!(ctx)) { return fail(ALPGPU_ERR_INVALID, "null context"); }                                                \
+		ALPGPU_HIP(hipSetDevice((ctx)->device));                                                                        \
+	} while (0)
+
+} // namespace
+
+extern "C" {
+
+int alpgpu_abi_version(void) { return 1; }
+
+const char* alpgpu_last_error(void) { return g_err; }
+
+int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
+	if (!out_ctx) { return fail(ALPGPU_ERR_INVALID, "out_ctx is null"); }
+	*out_ctx  = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		return fail(ALPGPU_ERR_NO_DEVICE, "no HIP device visible: libalpgpu has no CPU fallback");
+	}
+	if (device < 0 || device >= count) { return fail(ALPGPU_ERR_INVALID, "device index out of range"); }
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { return fail(ALPGPU_ERR_NO_DEVICE, "hipGetDeviceProperties failed"); }
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("ALPGPU_ALLOW_ANY_ARCH")) {
+		std::snprintf(g_err, sizeof(g_err), "device %d is %s; libalpgpu is built for gfx950 only", device, prop.gcnArchName);
+		return ALPGPU_ERR_NO_DEVICE;
+	}
+	ALPGPU_HIP(hipSetDevice(device));
+	alpgpu_ctx* ctx = new (std::nothrow) alpgpu_ctx();
+	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "out of host memory"); }
+	ctx->device = device;
+	if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+		delete ctx;
+		return fail(ALPGPU_ERR_HIP, "hipStreamCreate failed");
+	}
+	ctx->stream         = ctx->own_stream;
+	ctx->n_cus          = prop.multiProcessorCount;
+	ctx->hbm_bytes      = prop.totalGlobalMem;
+	ctx->decode_variant = 0;
+	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { ctx->decode_variant = std::atoi(v); }
+	std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+	*out_ctx = ctx;
+	return ALPGPU_OK;
+}
+
+void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
+	if (!ctx) { return; }
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamDestroy(ctx->own_stream);
+	delete ctx;
+}
+
+int alpgpu_set_stream(alpgpu_ctx* ctx, void* hip_stream) {
+	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+	ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+	return ALPGPU_OK;
+}
+
+int alpgpu_synchronize(alpgpu_ctx* ctx) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	return ALPGPU_OK;
+}
+
+int alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes) {
+	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+	if (name_out && name_cap) { std::snprintf(name_out, name_cap, "%s", ctx->name); }
+	if (cu_count) { *cu_count = ctx->n_cus; }
+	if (hbm_bytes) { *hbm_bytes = ctx->hbm_bytes; }
+	return ALPGPU_OK;
+}
+
+int alpgpu_malloc(alpgpu_ctx* ctx, void** d_ptr, size_t bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_ptr) { return fail(ALPGPU_ERR_INVALID, "d_ptr is null"); }
+	ALPGPU_HIP(hipMalloc(d_ptr, bytes ? bytes : 8));
+	return ALPGPU_OK;
+}
+
+int alpgpu_free(alpgpu_ctx* ctx, void* d_ptr) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipFree(d_ptr));
+	return ALPGPU_OK;
+}
+
+int alpgpu_memcpy_h2d(alpgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	return ALPGPU_OK;
+}
+
+int alpgpu_memcpy_d2h(alpgpu_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	return ALPGPU_OK;
+}
+
+int alpgpu_memset(alpgpu_ctx* ctx, void* d_dst, int value, size_t bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+	return ALPGPU_OK;
+}
+
+// worst case per vector: ALP bw=64 -> 8192 B; ALP_RD rbw=63,lbw=3 -> 8448 B.  +1 KiB slack at the end.
+uint64_t alpgpu_packed_capacity(uint64_t n_vectors) { return n_vectors * 8448ull + 1024ull; }
+// worst case per vector: 1024 exceptions x (8 B value + 2 B position)
+uint64_t alpgpu_exc_capacity(uint64_t n_vectors) { return n_vectors * 10240ull + 64ull; }
+
+int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || !d_out) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, ctx->decode_variant, ctx->n_cus);
+	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+
+int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || !col->d_totals) { return fail(ALPGPU_ERR_INVALID, "null column"); }
+	uint64_t t[4] = {0, 0, 0, 0};
+	ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	if (packed_bytes) { *packed_bytes = t[0]; }
+	if (exc_bytes) { *exc_bytes = t[1]; }
+	if (overflow) { *overflow = static_cast<int>(t[2]); }
+	return t[2] ? fail(ALPGPU_ERR_CAPACITY, "an output stream overflowed its capacity") : ALPGPU_OK;
+}
+
+} // extern "C"

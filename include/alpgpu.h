@@ -1,0 +1,213 @@
+/*
+ * alpgpu.h — C ABI of libalpgpu.so: the MI355X (gfx950) ALP / ALP_RD vector codec.
+ *
+ * This is the drop-in boundary of the repository.  Everything behind it is hand-written HIP for CDNA4;
+ * there is NO CPU fallback: every entry point fails with ALPGPU_ERR_NO_DEVICE when no gfx950 device is
+ * usable.  The C++ header include/alp.hpp (source-compatible with the reference's include/alp.hpp:4-13)
+ * and the Python harness (alp_amd/capi.py) are both thin callers of these functions.
+ *
+ * The reference (cwida/ALP) has no FFI layer; its boundary is the C++ vector API.  Each batch entry
+ * point below names the reference function(s) it replaces, file:line relative to /root/reference:
+ *
+ *   alpgpu_rowgroup_init_f64   alp::encoder<double>::init            include/alp/encoder.hpp:420-427
+ *                              (sampler::first_level_sample           include/alp/sampler.hpp:14-52,
+ *                               find_top_k_combinations               include/alp/encoder.hpp:139-235)
+ *                              alp::rd_encoder<double>::init          include/alp/rd.hpp:180-185 (:33-104)
+ *   alpgpu_encode_f64          alp::encoder<double>::encode           include/alp/encoder.hpp:402-418
+ *                              (find_best_exponent_factor_from_combinations :241-305, encode_simdized :307-400)
+ *                              alp::encoder<double>::analyze_ffor     include/alp/encoder.hpp:109-120
+ *                              ffor::ffor(int64/uint64/uint16)        include/fastlanes/ffor.hpp:7-15
+ *                                                                     (src/fastlanes_generated_ffor.cpp:29781,29939)
+ *                              alp::rd_encoder<double>::encode        include/alp/rd.hpp:109-147
+ *   alpgpu_decode_f64          generated::falp::fallback::scalar::falp include/alp/falp.hpp:10-26 (src/falp.cpp:42440)
+ *                              alp::decoder<double>::patch_exceptions include/alp/decoder.hpp:141-149
+ *                              unffor::unffor(uint64/uint16)          include/fastlanes/unffor.hpp:7-15
+ *                              alp::rd_encoder<double>::decode        include/alp/rd.hpp:152-178
+ *   alpgpu_ffor_i64 / alpgpu_unffor_i64 / alpgpu_ffor_u16 / alpgpu_unffor_u16
+ *                              ffor::ffor / unffor::unffor            include/fastlanes/{ffor,unffor}.hpp:7-15
+ *   alpgpu_falp_f64            falp (no exception patching)           include/alp/falp.hpp:10-26
+ *   alpgpu_decode_values_f64   alp::decoder<double>::decode           include/alp/decoder.hpp:134-138
+ *   alpgpu_patch_f64           alp::decoder<double>::patch_exceptions include/alp/decoder.hpp:141-149
+ *   alpgpu_encode_simdized_f64 alp::encoder<double>::encode_simdized  include/alp/encoder.hpp:307-400
+ *   alpgpu_analyze_ffor_i64    alp::encoder<double>::analyze_ffor     include/alp/encoder.hpp:109-120
+ *   alpgpu_rd_encode_vectors_f64 / alpgpu_rd_decode_vectors_f64
+ *                              alp::rd_encoder<double>::encode/decode include/alp/rd.hpp:109-147 / :152-178
+ *
+ * Conventions
+ *   - plain C types; every pointer named d_* is a DEVICE pointer (HBM) unless stated otherwise;
+ *   - a "vector" is 1024 values, a "rowgroup" is 100 vectors (reference include/alp/config.hpp:11-15);
+ *     rowgroup r owns vectors 100r .. 100r+99 and one state (scheme, (e,f) candidates / RD dictionary);
+ *   - all work is enqueued on the context's stream (alpgpu_set_stream) and is asynchronous; call
+ *     alpgpu_synchronize (or synchronise the stream yourself) before reading results on the host;
+ *   - return value: ALPGPU_OK or a negative ALPGPU_ERR_*; alpgpu_last_error() gives the text (thread-local);
+ *   - no C++ exceptions cross this boundary; one context per device, used by one host thread at a time.
+ */
+#ifndef ALPGPU_H
+#define ALPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALPGPU_VECTOR_SIZE 1024u
+#define ALPGPU_ROWGROUP_VECTORS 100u
+#define ALPGPU_MAX_COMBINATIONS 5u
+#define ALPGPU_RD_DICT_SIZE 8u
+
+/* same numeric values as the reference's alp::Scheme (include/alp/constants.hpp:10-14) */
+#define ALPGPU_SCHEME_INVALID 0u
+#define ALPGPU_SCHEME_ALP_RD 1u
+#define ALPGPU_SCHEME_ALP 2u
+
+#define ALPGPU_OK 0
+#define ALPGPU_ERR_NO_DEVICE (-1)   /* no usable gfx950 device / HIP runtime failure at start-up */
+#define ALPGPU_ERR_INVALID (-2)     /* bad argument */
+#define ALPGPU_ERR_HIP (-3)         /* a HIP call failed; see alpgpu_last_error() */
+#define ALPGPU_ERR_CAPACITY (-4)    /* an output stream was too small (reported by alpgpu_column_totals) */
+
+typedef struct alpgpu_ctx alpgpu_ctx;
+
+/* Per-rowgroup codec state in HBM (32 bytes).  Mirror of the fields of alp::state<double>
+ * (reference include/alp/encoder.hpp:35-62) that outlive init(). */
+typedef struct alpgpu_rowgroup_state {
+	uint8_t  scheme;      /* ALPGPU_SCHEME_ALP | ALPGPU_SCHEME_ALP_RD */
+	uint8_t  k;           /* ALP: number of (e,f) candidates, 1..5 (state.k_combinations) */
+	uint8_t  combos[10];  /* ALP: combos[2i] = exponent e, combos[2i+1] = factor f (best_k_combinations) */
+	uint8_t  rd_rbw;      /* ALP_RD: right_bit_width (48..63) */
+	uint8_t  rd_lbw;      /* ALP_RD: left_bit_width (1..3) */
+	uint8_t  rd_dict_size;/* ALP_RD: actual_dictionary_size (1..8) */
+	uint8_t  pad;
+	uint16_t rd_dict[8];  /* ALP_RD: left_parts_dict */
+} alpgpu_rowgroup_state;
+
+/* Per-vector descriptor in HBM (32 bytes, 32-byte aligned; one scalar load per wavefront).
+ * Modelled on the reference's per-vector metadata (state.exp/fac/bit_width/for_base + exceptions_count;
+ * the 48-byte alp_m record of publication/source_code/bench_end_to_end/include/encoding/helper.hpp:36-67). */
+typedef struct alpgpu_vector_desc {
+	uint64_t packed_off;  /* byte offset of this vector's bit-packed words in the packed stream (multiple of 128).
+	                         ALP: 128*bw bytes.  ALP_RD: 128*rbw bytes (right, u64 lanes) then 128*lbw (left, u16 lanes) */
+	uint64_t exc_off;     /* byte offset of this vector's exception record in the exception stream (multiple of 8).
+	                         ALP: cnt*8 B values (f64 bits) then cnt*2 B positions.  ALP_RD: cnt*2 B left parts then cnt*2 B positions.
+	                         record size is rounded up to 8 bytes */
+	int64_t  base;        /* ALP: frame-of-reference base (for_base).  ALP_RD: 0 */
+	uint8_t  bw;          /* ALP: bit width 0..64.  ALP_RD: right bit width */
+	uint8_t  e;           /* ALP: exponent index (state.exp) */
+	uint8_t  f;           /* ALP: factor index (state.fac) */
+	uint8_t  lbw;         /* ALP_RD: left bit width; ALP: 0 */
+	uint16_t exc_cnt;     /* number of exceptions 0..1024 */
+	uint16_t scheme;      /* copy of the rowgroup's scheme */
+} alpgpu_vector_desc;
+
+/* A compressed column resident in HBM.  All buffers are caller-allocated (alpgpu_malloc or any HIP
+ * allocator, e.g. a torch tensor) and caller-owned, like every buffer of the reference API. */
+typedef struct alpgpu_column {
+	uint64_t               n_vectors;
+	uint64_t               n_rowgroups;     /* ceil(n_vectors / 100) */
+	alpgpu_rowgroup_state* d_rowgroups;     /* [n_rowgroups] */
+	alpgpu_vector_desc*    d_vectors;       /* [n_vectors] */
+	uint8_t*               d_packed;        /* packed stream, 128-byte aligned */
+	uint64_t               packed_capacity; /* bytes; worst case n_vectors * 8448 */
+	uint8_t*               d_exc;           /* exception stream, 8-byte aligned */
+	uint64_t               exc_capacity;    /* bytes; worst case n_vectors * 10240 */
+	uint64_t*              d_totals;        /* [4]: packed bytes used, exception bytes used, overflow flag, reserved */
+} alpgpu_column;
+
+/* ---- context / plumbing ------------------------------------------------------------------------- */
+int         alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx);
+void        alpgpu_ctx_destroy(alpgpu_ctx* ctx);
+const char* alpgpu_last_error(void);
+int         alpgpu_abi_version(void);
+/* run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = context's own */
+int         alpgpu_set_stream(alpgpu_ctx* ctx, void* hip_stream);
+int         alpgpu_synchronize(alpgpu_ctx* ctx);
+/* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
+int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
+
+/* device memory helpers for hosts that do not link a HIP runtime themselves (include/alp.hpp) */
+int alpgpu_malloc(alpgpu_ctx* ctx, void** d_ptr, size_t bytes);
+int alpgpu_free(alpgpu_ctx* ctx, void* d_ptr);
+int alpgpu_memcpy_h2d(alpgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int alpgpu_memcpy_d2h(alpgpu_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int alpgpu_memset(alpgpu_ctx* ctx, void* d_dst, int value, size_t bytes);
+
+/* worst-case stream capacities for n_vectors (bytes) */
+uint64_t alpgpu_packed_capacity(uint64_t n_vectors);
+uint64_t alpgpu_exc_capacity(uint64_t n_vectors);
+
+/* ---- whole-column hot path ----------------------------------------------------------------------- */
+
+/* Rowgroup init for every rowgroup of the column: first-level sampling, (e,f) top-k search, scheme
+ * decision, and for ALP_RD rowgroups the cut/dictionary search.  Writes col->d_rowgroups[0..n_rowgroups). */
+int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
+
+/* Vector encode of the whole column given col->d_rowgroups (from alpgpu_rowgroup_init_f64 or supplied by
+ * the caller): second-level sampling, encode + exception compaction, analyze_ffor, FFOR pack (ALP);
+ * split + dictionary encode + FFOR pack of right/left (ALP_RD).  Single pass over the input; output
+ * offsets are assigned in vector order.  Writes d_vectors, d_packed, d_exc, d_totals. */
+int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
+
+/* alpgpu_rowgroup_init_f64 followed by alpgpu_encode_vectors_f64 */
+int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
+
+/* Fused decode of the whole column: ALP vectors = falp (unFFOR + int->double) + patch_exceptions;
+ * ALP_RD vectors = unFFOR(right,left) + dictionary glue + patch.  d_out receives n_vectors*1024 doubles. */
+int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
+
+/* host copy of d_totals after the stream has drained: packed bytes, exception bytes, overflow flag */
+int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes,
+                         int* overflow);
+
+/* ---- vector primitives on batches (fixed strides; the reference's per-vector API, n at a time) ------
+ * Each processes n_vectors independent vectors.  "stride" arguments are in ELEMENTS of the pointed type
+ * between consecutive vectors (the reference's callers use 1024-element buffers for everything). */
+
+/* ffor::ffor / unffor::unffor, 64-bit lanes: in/out [n][1024] int64, packed [n][packed_stride] (>= 16*bw words
+ * used per vector), bw/base per vector */
+int alpgpu_ffor_i64(alpgpu_ctx* ctx, const int64_t* d_in, int64_t* d_packed, size_t packed_stride,
+                    const uint8_t* d_bw, const int64_t* d_base, uint64_t n_vectors);
+int alpgpu_unffor_i64(alpgpu_ctx* ctx, const int64_t* d_packed, size_t packed_stride, int64_t* d_out,
+                      const uint8_t* d_bw, const int64_t* d_base, uint64_t n_vectors);
+/* 16-bit lanes (ALP_RD left parts) */
+int alpgpu_ffor_u16(alpgpu_ctx* ctx, const uint16_t* d_in, uint16_t* d_packed, size_t packed_stride,
+                    const uint8_t* d_bw, const uint16_t* d_base, uint64_t n_vectors);
+int alpgpu_unffor_u16(alpgpu_ctx* ctx, const uint16_t* d_packed, size_t packed_stride, uint16_t* d_out,
+                      const uint8_t* d_bw, const uint16_t* d_base, uint64_t n_vectors);
+
+/* falp without exception patching: packed -> doubles */
+int alpgpu_falp_f64(alpgpu_ctx* ctx, const int64_t* d_packed, size_t packed_stride, double* d_out,
+                    const uint8_t* d_bw, const int64_t* d_base, const uint8_t* d_fac, const uint8_t* d_exp,
+                    uint64_t n_vectors);
+/* decoder::decode: encoded integers -> doubles */
+int alpgpu_decode_values_f64(alpgpu_ctx* ctx, const int64_t* d_enc, double* d_out, const uint8_t* d_fac,
+                             const uint8_t* d_exp, uint64_t n_vectors);
+/* decoder::patch_exceptions: out[pos[j]] = exc[j]; exc/pos [n][exc_stride] */
+int alpgpu_patch_f64(alpgpu_ctx* ctx, double* d_out, const double* d_exc, const uint16_t* d_pos, size_t exc_stride,
+                     const uint16_t* d_cnt, uint64_t n_vectors);
+/* encoder::encode_simdized with a given (fac, exp) per vector: -> enc [n][1024], exc/pos [n][exc_stride], cnt [n] */
+int alpgpu_encode_simdized_f64(alpgpu_ctx* ctx, const double* d_in, double* d_exc, uint16_t* d_pos, size_t exc_stride,
+                               uint16_t* d_cnt, int64_t* d_enc, const uint8_t* d_fac, const uint8_t* d_exp,
+                               uint64_t n_vectors);
+/* encoder::encode (second-level sampling when state.k > 1, then encode_simdized); one state per vector
+ * (d_state_idx[v] indexes d_states; NULL = vector v uses state v/100); chosen (fac, exp) are returned */
+int alpgpu_encode_values_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states,
+                             const uint32_t* d_state_idx, double* d_exc, uint16_t* d_pos, size_t exc_stride,
+                             uint16_t* d_cnt, int64_t* d_enc, uint8_t* d_fac, uint8_t* d_exp, uint64_t n_vectors);
+/* encoder::analyze_ffor */
+int alpgpu_analyze_ffor_i64(alpgpu_ctx* ctx, const int64_t* d_enc, uint8_t* d_bw, int64_t* d_base, uint64_t n_vectors);
+
+/* rd_encoder::encode / decode with per-vector state index as above */
+int alpgpu_rd_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states,
+                                 const uint32_t* d_state_idx, uint16_t* d_exc, uint16_t* d_pos, size_t exc_stride,
+                                 uint16_t* d_cnt, uint64_t* d_right, uint16_t* d_left, uint64_t n_vectors);
+int alpgpu_rd_decode_vectors_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t* d_right, const uint16_t* d_left,
+                                 const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
+                                 const uint16_t* d_exc, const uint16_t* d_pos, size_t exc_stride,
+                                 const uint16_t* d_cnt, uint64_t n_vectors);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALPGPU_H */

@@ -1,0 +1,64 @@
+"""Seeded synthetic double columns shared by tests and bench.py.  numpy only."""
+import numpy as np
+
+VEC = 1024
+
+
+def decimal_column(n_vectors, decimals=2, lo=-1e5, hi=1e5, seed=42):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(lo, hi, n_vectors * VEC)
+    return np.round(x, decimals)
+
+
+def mixed_column(n_vectors, seed=42, exc_rate=0.01, special_rate=0.001, decimals_per_rowgroup=(1, 2, 4)):
+    """round(x, d) with d cycling per rowgroup, a fraction of full-precision values (exceptions) and specials."""
+    rng = np.random.default_rng(seed)
+    n = n_vectors * VEC
+    x = rng.uniform(-1e5, 1e5, n)
+    out = np.empty(n, np.float64)
+    for r in range((n_vectors + 99) // 100):
+        s = slice(r * 100 * VEC, min(n, (r + 1) * 100 * VEC))
+        out[s] = np.round(x[s], decimals_per_rowgroup[r % len(decimals_per_rowgroup)])
+    m = rng.random(n) < exc_rate
+    out[m] = x[m] * np.pi
+    sp = rng.random(n) < special_rate
+    specials = np.array([np.nan, np.inf, -np.inf, -0.0])
+    out[sp] = specials[rng.integers(0, 4, int(sp.sum()))]
+    return out
+
+
+def rd_column(n_vectors, seed=42, kind="unit"):
+    rng = np.random.default_rng(seed)
+    n = n_vectors * VEC
+    if kind == "unit":
+        return rng.random(n)
+    return rng.uniform(-90.0, 90.0, n)  # lat/lon-like, full precision
+
+
+def drifting_column(n_vectors, seed=7):
+    """precision changes inside a rowgroup -> several (e,f) candidates (k > 1): exercises second-level sampling"""
+    rng = np.random.default_rng(seed)
+    n = n_vectors * VEC
+    x = rng.uniform(0, 1000, n)
+    out = np.empty(n, np.float64)
+    for v in range(n_vectors):
+        d = (1, 3, 5, 2)[(v // 7) % 4]
+        out[v * VEC:(v + 1) * VEC] = np.round(x[v * VEC:(v + 1) * VEC], d)
+    return out
+
+
+def adversarial_vectors():
+    """hand-made single vectors for the corner cases of encode (all exceptions, exceptions 0..1022, ...)"""
+    base = np.round(np.random.default_rng(3).uniform(0, 100, VEC), 2)
+    cases = {}
+    cases["plain"] = base.copy()
+    a = base.copy(); a[:] = np.pi * (np.arange(VEC) + 1); cases["all_exceptions"] = a
+    a = base.copy(); a[:1023] = np.e * (np.arange(1023) + 1); cases["exceptions_0_to_1022"] = a
+    a = base.copy(); a[:5] = np.nan; cases["prefix_nan"] = a
+    a = base.copy(); a[1023] = np.inf; a[0] = -np.inf; cases["inf_ends"] = a
+    a = base.copy(); a[::2] = -0.0; cases["half_negzero"] = a
+    a = np.zeros(VEC); cases["all_zero"] = a
+    a = np.full(VEC, 10.23); cases["constant"] = a
+    a = base.copy(); a[7] = 2.0**63; a[8] = -2.0**63; a[9] = 1e300; a[10] = 5e-324; cases["huge_tiny"] = a
+    a = base.copy(); a[100:200] = np.random.default_rng(4).random(100); cases["exception_block"] = a
+    return cases
