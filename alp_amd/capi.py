@@ -11,6 +11,10 @@ import ctypes as C
 import os
 
 import numpy as np
+# torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  It MUST be loaded first so that
+# libalpgpu.so binds to the same HIP runtime instance as the tensors/streams it is handed; two runtimes in
+# one process do not see each other's streams (and the second one may not see the device at all).
+import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libalpgpu.so")

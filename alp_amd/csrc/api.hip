@@ -95,7 +95,13 @@ void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 
 int alpgpu_set_stream(alpgpu_ctx* ctx, void* hip_stream) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
-	ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+	ctx->stream = static_cast<hipStream_t>(hip_stream); // NULL is the device's legacy default stream
+	return ALPGPU_OK;
+}
+
+int alpgpu_use_own_stream(alpgpu_ctx* ctx) {
+	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+	ctx->stream = ctx->own_stream;
 	return ALPGPU_OK;
 }
 

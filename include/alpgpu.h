@@ -120,8 +120,10 @@ int         alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx);
 void        alpgpu_ctx_destroy(alpgpu_ctx* ctx);
 const char* alpgpu_last_error(void);
 int         alpgpu_abi_version(void);
-/* run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = context's own */
+/* run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the device's
+ * default (null) stream.  A new context runs on its own non-blocking stream until this is called. */
 int         alpgpu_set_stream(alpgpu_ctx* ctx, void* hip_stream);
+int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
