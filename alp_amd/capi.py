@@ -68,7 +68,11 @@ _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
+_sig("alpgpu_use_own_stream", _int, _vp)
 _sig("alpgpu_decode_f64", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_rowgroup_init_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
+_sig("alpgpu_encode_vectors_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
+_sig("alpgpu_encode_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_column_totals", _int, _vp, C.POINTER(CColumn), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_int))
 
 
@@ -117,6 +121,32 @@ class Context:
         return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": hbm.value}
 
     # ---- whole-column path ------------------------------------------------------------------------
+    def _check_input(self, x, col):
+        import torch
+        assert x.dtype == torch.float64 and x.is_contiguous() and x.is_cuda
+        assert x.numel() == col.n_vectors * VECTOR_SIZE, "input must hold exactly n_vectors * 1024 doubles"
+
+    def rowgroup_init(self, x, col: "DeviceColumn"):
+        self._check_input(x, col)
+        _check(lib.alpgpu_rowgroup_init_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_rowgroup_init_f64")
+
+    def encode_vectors(self, x, col: "DeviceColumn"):
+        self._check_input(x, col)
+        _check(lib.alpgpu_encode_vectors_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_encode_vectors_f64")
+
+    def encode(self, x, col: "DeviceColumn" = None):
+        """rowgroup init + vector encode of a device tensor of n_vectors*1024 doubles"""
+        if col is None:
+            col = DeviceColumn(x.numel() // VECTOR_SIZE, self.device)
+        self._check_input(x, col)
+        _check(lib.alpgpu_encode_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_encode_f64")
+        return col
+
+    def column_totals(self, col: "DeviceColumn"):
+        pb, eb, ov = _u64(), _u64(), _int()
+        _check(lib.alpgpu_column_totals(self.h, C.byref(col.c), C.byref(pb), C.byref(eb), C.byref(ov)), "alpgpu_column_totals")
+        return pb.value, eb.value, ov.value
+
     def decode(self, col: "DeviceColumn", out=None):
         import torch
         if out is None:

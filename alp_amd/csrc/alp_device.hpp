@@ -166,6 +166,12 @@ struct U64Pair {
 	uint64_t x, y;
 };
 
+// packed words addressed as 16-byte units through a plain pointer (LDS or global)
+struct UnitsPtr {
+	const ulonglong2* p;
+	__device__ __forceinline__ ulonglong2 operator()(int i) const { return p[i]; }
+};
+
 template <typename Units>
 __device__ __forceinline__ U64Pair unpack_pair_u64(const Units& units, int bw, uint64_t mask, int row, int a) {
 	const int p = row * bw;

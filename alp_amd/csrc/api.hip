@@ -19,6 +19,8 @@ struct alpgpu_ctx {
 	int         decode_variant;
 	char        name[128];
 	uint64_t    hbm_bytes;
+	void*       workspace;       // scan workspace (tile sums), grown on demand
+	uint64_t    workspace_bytes;
 };
 
 namespace {
@@ -79,7 +81,9 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->stream         = ctx->own_stream;
 	ctx->n_cus          = prop.multiProcessorCount;
 	ctx->hbm_bytes      = prop.totalGlobalMem;
-	ctx->decode_variant = 0;
+	ctx->decode_variant  = 0;
+	ctx->workspace       = nullptr;
+	ctx->workspace_bytes = 0;
 	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { ctx->decode_variant = std::atoi(v); }
 	std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
 	*out_ctx = ctx;
@@ -90,6 +94,7 @@ void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 	if (!ctx) { return; }
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamDestroy(ctx->own_stream);
+	if (ctx->workspace) { (void)hipFree(ctx->workspace); }
 	delete ctx;
 }
 
@@ -157,6 +162,55 @@ uint64_t alpgpu_packed_capacity(uint64_t n_vectors) { return n_vectors * 8448ull
 // worst case per vector: 1024 exceptions x (8 B value + 2 B position)
 uint64_t alpgpu_exc_capacity(uint64_t n_vectors) { return n_vectors * 10240ull + 64ull; }
 
+static int ensure_workspace(alpgpu_ctx* ctx, uint64_t bytes) {
+	if (ctx->workspace_bytes >= bytes) { return ALPGPU_OK; }
+	// grows only between launches of different sizes; the old buffer may still be in use by queued work
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	if (ctx->workspace) { ALPGPU_HIP(hipFree(ctx->workspace)); }
+	ctx->workspace       = nullptr;
+	ctx->workspace_bytes = 0;
+	const uint64_t want  = bytes < (1ull << 20) ? (1ull << 20) : bytes * 2;
+	ALPGPU_HIP(hipMalloc(&ctx->workspace, want));
+	ctx->workspace_bytes = want;
+	return ALPGPU_OK;
+}
+
+static int check_column(const alpgpu_column* col, uint64_t n_vectors) {
+	if (!col) { return fail(ALPGPU_ERR_INVALID, "null column"); }
+	if (col->n_vectors != n_vectors) { return fail(ALPGPU_ERR_INVALID, "column.n_vectors does not match n_vectors"); }
+	if (col->n_rowgroups != (n_vectors + 99) / 100) { return fail(ALPGPU_ERR_INVALID, "column.n_rowgroups must be ceil(n_vectors/100)"); }
+	if (n_vectors && (!col->d_rowgroups || !col->d_vectors || !col->d_packed || !col->d_exc || !col->d_totals)) {
+		return fail(ALPGPU_ERR_INVALID, "column buffers must be allocated by the caller");
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (alpgpu::launch_rowgroup_init(ctx->stream, d_in, n_vectors, col->d_rowgroups) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (int rc = ensure_workspace(ctx, alpgpu::encode_workspace_bytes(n_vectors))) { return rc; }
+	if (alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace), ctx->n_cus) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	if (int rc = alpgpu_rowgroup_init_f64(ctx, d_in, n_vectors, col)) { return rc; }
+	return alpgpu_encode_vectors_f64(ctx, d_in, n_vectors, col);
+}
+
 int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || !d_out) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
@@ -164,6 +218,78 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, ctx->decode_variant, ctx->n_cus);
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
+}
+
+// ---- vector primitives on batches ---------------------------------------------------------------------------
+#define ALPGPU_PRIM(cond_ok, call)                                                                                      \
+	do {                                                                                                                \
+		ALPGPU_CHECK_CTX(ctx);                                                                                          \
+		if (n_vectors && !(cond_ok)) { return fail(ALPGPU_ERR_INVALID, "null pointer argument"); }                      \
+		if ((call) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "kernel launch failed", hipGetLastError()); }            \
+		return ALPGPU_OK;                                                                                               \
+	} while (0)
+
+int alpgpu_ffor_i64(alpgpu_ctx* ctx, const int64_t* d_in, int64_t* d_packed, size_t packed_stride, const uint8_t* d_bw,
+                    const int64_t* d_base, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_packed && d_bw && d_base,
+	            alpgpu::launch_ffor_i64(ctx->stream, ctx->n_cus, d_in, d_packed, packed_stride, d_bw, d_base, n_vectors));
+}
+int alpgpu_unffor_i64(alpgpu_ctx* ctx, const int64_t* d_packed, size_t packed_stride, int64_t* d_out, const uint8_t* d_bw,
+                      const int64_t* d_base, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_packed && d_out && d_bw && d_base,
+	            alpgpu::launch_unffor_i64(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, n_vectors));
+}
+int alpgpu_ffor_u16(alpgpu_ctx* ctx, const uint16_t* d_in, uint16_t* d_packed, size_t packed_stride, const uint8_t* d_bw,
+                    const uint16_t* d_base, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_packed && d_bw,
+	            alpgpu::launch_ffor_u16(ctx->stream, ctx->n_cus, d_in, d_packed, packed_stride, d_bw, d_base, n_vectors));
+}
+int alpgpu_unffor_u16(alpgpu_ctx* ctx, const uint16_t* d_packed, size_t packed_stride, uint16_t* d_out, const uint8_t* d_bw,
+                      const uint16_t* d_base, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_packed && d_out && d_bw,
+	            alpgpu::launch_unffor_u16(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, n_vectors));
+}
+int alpgpu_falp_f64(alpgpu_ctx* ctx, const int64_t* d_packed, size_t packed_stride, double* d_out, const uint8_t* d_bw,
+                    const int64_t* d_base, const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_packed && d_out && d_bw && d_base && d_fac && d_exp,
+	            alpgpu::launch_falp(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, d_fac, d_exp, n_vectors));
+}
+int alpgpu_decode_values_f64(alpgpu_ctx* ctx, const int64_t* d_enc, double* d_out, const uint8_t* d_fac, const uint8_t* d_exp,
+                             uint64_t n_vectors) {
+	ALPGPU_PRIM(d_enc && d_out && d_fac && d_exp, alpgpu::launch_decode_values(ctx->stream, ctx->n_cus, d_enc, d_out, d_fac, d_exp, n_vectors));
+}
+int alpgpu_patch_f64(alpgpu_ctx* ctx, double* d_out, const double* d_exc, const uint16_t* d_pos, size_t exc_stride,
+                     const uint16_t* d_cnt, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_out && d_exc && d_pos && d_cnt, alpgpu::launch_patch(ctx->stream, ctx->n_cus, d_out, d_exc, d_pos, exc_stride, d_cnt, n_vectors));
+}
+int alpgpu_encode_simdized_f64(alpgpu_ctx* ctx, const double* d_in, double* d_exc, uint16_t* d_pos, size_t exc_stride,
+                               uint16_t* d_cnt, int64_t* d_enc, const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_exc && d_pos && d_cnt && d_enc && d_fac && d_exp,
+	            alpgpu::launch_encode_simdized(ctx->stream, ctx->n_cus, d_in, d_exc, d_pos, exc_stride, d_cnt, d_enc, d_fac, d_exp, n_vectors));
+}
+int alpgpu_encode_values_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
+                             double* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, int64_t* d_enc, uint8_t* d_fac,
+                             uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_states && d_exc && d_pos && d_cnt && d_enc && d_fac && d_exp,
+	            alpgpu::launch_encode_values(ctx->stream, ctx->n_cus, d_in, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, d_enc,
+	                                         d_fac, d_exp, n_vectors));
+}
+int alpgpu_analyze_ffor_i64(alpgpu_ctx* ctx, const int64_t* d_enc, uint8_t* d_bw, int64_t* d_base, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_enc && d_bw && d_base, alpgpu::launch_analyze_ffor(ctx->stream, ctx->n_cus, d_enc, d_bw, d_base, n_vectors));
+}
+int alpgpu_rd_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states,
+                                 const uint32_t* d_state_idx, uint16_t* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt,
+                                 uint64_t* d_right, uint16_t* d_left, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_states && d_exc && d_pos && d_cnt && d_right && d_left,
+	            alpgpu::launch_rd_encode(ctx->stream, ctx->n_cus, d_in, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, d_right,
+	                                     d_left, n_vectors));
+}
+int alpgpu_rd_decode_vectors_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t* d_right, const uint16_t* d_left,
+                                 const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx, const uint16_t* d_exc,
+                                 const uint16_t* d_pos, size_t exc_stride, const uint16_t* d_cnt, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_out && d_right && d_left && d_states && d_exc && d_pos && d_cnt,
+	            alpgpu::launch_rd_decode(ctx->stream, ctx->n_cus, d_out, d_right, d_left, d_states, d_state_idx, d_exc, d_pos, exc_stride,
+	                                     d_cnt, n_vectors));
 }
 
 int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {

@@ -30,14 +30,8 @@ struct __attribute__((aligned(16))) DecodeLds {
 	uint64_t excv[kExcStage];
 };
 
-struct UnitsLds {
-	const ulonglong2* p;
-	__device__ __forceinline__ ulonglong2 operator()(int i) const { return p[i]; }
-};
-struct UnitsGlobal {
-	const ulonglong2* p;
-	__device__ __forceinline__ ulonglong2 operator()(int i) const { return p[i]; }
-};
+using UnitsLds    = UnitsPtr;
+using UnitsGlobal = UnitsPtr;
 
 // Builds mask/pref (and stages values) for one vector's exception record.  VAL_BYTES = 8 (ALP) or 2 (RD).
 template <int VAL_BYTES>

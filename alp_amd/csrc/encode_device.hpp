@@ -1,0 +1,336 @@
+// encode_device.hpp — wavefront-level building blocks of the ALP / ALP_RD vector ENCODE path (gfx950).
+//
+// Same ownership as the decode side: one 64-lane wavefront per 1024-value vector, lane L holds the value
+// pairs i = 128*m + 2*L + j (m = 0..7, j = 0..1) in registers, so the 8 KiB input is read with eight
+// 1-KiB-contiguous 16-B-per-lane loads and never re-read inside the kernel.
+//
+// Reference functions restated here (file:line relative to /root/reference):
+//   second-level sampling  alp::encoder<double>::find_best_exponent_factor_from_combinations  include/alp/encoder.hpp:241-305
+//   value encode + verify  alp::encoder<double>::encode_simdized                              include/alp/encoder.hpp:307-400
+//   FOR analysis           alp::encoder<double>::analyze_ffor                                 include/alp/encoder.hpp:109-120
+//   FFOR bit-packing       ffor::ffor (u64: src/fastlanes_generated_ffor.cpp:7379-29749; u16: :357-1775)
+//   ALP_RD split           alp::rd_encoder<double>::encode                                    include/alp/rd.hpp:109-147
+#pragma once
+#include "alp_device.hpp"
+
+namespace alpgpu {
+
+struct __attribute__((aligned(16))) EncodeLds {
+	uint64_t vals[kVec]; // (enc - base) or RD right parts, natural index order: 8 KiB
+	double   smp[32];    // second-level samples
+};
+
+struct VecIn {
+	double2 x[8];
+};
+
+struct AlpVectorResult {
+	int      e, f, bw, cnt;
+	int64_t  base;
+};
+
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		const int64_t o = __shfl_xor(v, d);
+		v               = o < v ? o : v;
+	}
+	return v;
+}
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		const int64_t o = __shfl_xor(v, d);
+		v               = o > v ? o : v;
+	}
+	return v;
+}
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int src_lane) {
+	const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), src_lane);
+	const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32), src_lane);
+	return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+__device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint64_t v, int lane) {
+	const double2* p = reinterpret_cast<const double2*>(in + v * kVec);
+	VecIn          r;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) { r.x[m] = p[64 * m + lane]; }
+	return r;
+}
+
+// ---- second-level sampling (encoder.hpp:241-305) --------------------------------------------------------
+// 32 samples = input[32*s]; both half-waves evaluate one candidate each per round (lane & 31 = sample).
+// All candidates are evaluated; the reference's early exit (two consecutive non-improvements) only stops
+// evaluating, so replaying its sequential decision over the computed sizes gives the same (e,f).
+__device__ __forceinline__ void second_level_select(const VecIn& in, const alpgpu_rowgroup_state* __restrict__ rgp, EncodeLds& L, int lane,
+                                                    int& e_out, int& f_out) {
+	const int k = rgp->k;
+	// sample s lives at index 32*s = 128*(s>>2) + 2*(16*(s&3)): element .x of step s>>2 in lane 16*(s&3)
+	if ((lane & 15) == 0) {
+#pragma unroll
+		for (int m = 0; m < 8; ++m) { L.smp[4 * m + (lane >> 4)] = in.x[m].x; }
+	}
+	wave_lds_sync();
+	const double sv   = L.smp[lane & 31];
+	const int    half = lane >> 5;
+
+	uint32_t sizes[5];
+#pragma unroll
+	for (int i = 0; i < 5; ++i) { sizes[i] = 0xFFFFFFFFu; }
+
+#pragma unroll
+	for (int kk = 0; kk < 6; kk += 2) {
+		if (kk < k) { // wave-uniform
+			const int  c     = kk + half;
+			const bool valid = c < k;
+			const int  cc    = valid ? c : 0;
+			const int  e     = rgp->combos[2 * cc];
+			const int  f     = rgp->combos[2 * cc + 1];
+			const int64_t enc = encode_value_safe(sv, kExpArr[e], kFracArr[f]);
+			const double  dec = decode_value(enc, kFactArr[f], kFracArr[e]);
+			const bool    ok  = dec == sv;
+			const uint64_t bal  = __ballot(!ok);
+			const uint32_t excs = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
+			int64_t mx = ok ? enc : INT64_MIN;
+			int64_t mn = ok ? enc : INT64_MAX;
+#pragma unroll
+			for (int d = 16; d >= 1; d >>= 1) { // stays inside the 32-lane half
+				const int64_t omx = __shfl_xor(mx, d);
+				const int64_t omn = __shfl_xor(mn, d);
+				mx                = omx > mx ? omx : mx;
+				mn                = omn < mn ? omn : mn;
+			}
+			const uint32_t size = 32u * static_cast<uint32_t>(count_bits(mx, mn)) + excs * 80u;
+			const uint32_t s0   = __builtin_amdgcn_readlane(size, 0);
+			const uint32_t s1   = __builtin_amdgcn_readlane(size, 32);
+			sizes[kk] = s0;
+			if (kk + 1 < 5) { sizes[kk + 1] = s1; }
+		}
+	}
+	// the reference's sequential decision (encoder.hpp:283-301)
+	int      best       = 0;
+	uint32_t best_size  = sizes[0];
+	int      worse      = 0;
+	bool     stopped    = false;
+#pragma unroll
+	for (int i = 1; i < 5; ++i) {
+		if (i < k && !stopped) {
+			if (sizes[i] >= best_size) {
+				worse++;
+				if (worse == 2) { stopped = true; }
+			} else {
+				best_size = sizes[i];
+				best      = i;
+				worse     = 0;
+			}
+		}
+	}
+	e_out = rgp->combos[2 * best];
+	f_out = rgp->combos[2 * best + 1];
+	wave_lds_sync();
+}
+
+// ---- encode_simdized + analyze_ffor for one vector held in registers -------------------------------------
+// Outputs: enc[m][j] with exception slots overwritten by the filler; exception flags as a 16-bit per-lane
+// mask (bit 2m+j); ballots per (m,j); count; FOR base and bit width.
+struct AlpEncoded {
+	int64_t  enc[8][2];
+	uint64_t ballot[8][2];
+	uint32_t flags;
+	int      cnt;
+	int64_t  base;
+	int      bw;
+};
+
+__device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int f, int lane, AlpEncoded& R) {
+	const double  exp10 = kExpArr[e];
+	const double  frac_f = kFracArr[f];
+	const int64_t fact  = kFactArr[f];
+	const double  frac_e = kFracArr[e];
+	R.flags = 0;
+	R.cnt   = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const double   v    = j == 0 ? in.x[m].x : in.x[m].y;
+			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(v));
+			// pass 1 (encoder.hpp:326-338): for doubles only -0.0 matches (the mask literal evaluates to
+			// 0xFFE0000000000000); NaN/Inf go through the arithmetic and fail the compare
+			const double  vv  = bits == 0x8000000000000000ull ? kUpperLimit : v;
+			const int64_t enc = encode_value_unsafe(vv, exp10, frac_f);
+			const double  dec = decode_value(enc, fact, frac_e);
+			const bool    exc = dec != vv; // IEEE compare: NaN is always an exception
+			R.enc[m][j]       = enc;
+			R.ballot[m][j]    = __ballot(exc);
+			R.flags |= exc ? (1u << (2 * m + j)) : 0u;
+			R.cnt += __builtin_popcountll(R.ballot[m][j]);
+		}
+	}
+	// filler = encoded value at the first non-exception position p (encoder.hpp:382-388); 0 when there is
+	// none or when p == 1023 (the reference's index scan cannot see that case)
+	int64_t filler = 0;
+	bool    found  = false;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		const uint64_t n0 = ~R.ballot[m][0];
+		const uint64_t n1 = ~R.ballot[m][1];
+		if (!found && (n0 | n1) != 0) { // wave-uniform
+			const int l0   = n0 ? __builtin_ctzll(n0) : 64;
+			const int l1   = n1 ? __builtin_ctzll(n1) : 64;
+			const int pos0 = 2 * l0, pos1 = 2 * l1 + 1;
+			int       p;
+			if (pos0 < pos1) {
+				filler = readlane_i64(R.enc[m][0], l0);
+				p      = 128 * m + pos0;
+			} else {
+				filler = readlane_i64(R.enc[m][1], l1);
+				p      = 128 * m + pos1;
+			}
+			if (p == 1023) { filler = 0; }
+			found = true;
+		}
+	}
+	int64_t mn = INT64_MAX, mx = INT64_MIN;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			if (R.flags & (1u << (2 * m + j))) { R.enc[m][j] = filler; }
+			mn = R.enc[m][j] < mn ? R.enc[m][j] : mn;
+			mx = R.enc[m][j] > mx ? R.enc[m][j] : mx;
+		}
+	}
+	mn     = wave_min_i64(mn);
+	mx     = wave_max_i64(mx);
+	R.base = mn;
+	R.bw   = count_bits(mx, mn);
+}
+
+// rank of this lane's (m, j) exception among the vector's exceptions in ascending position order
+__device__ __forceinline__ int exception_rank(const uint64_t (&ballot)[8][2], uint32_t flags, int m, int j, int lane, int step_offset) {
+	const uint64_t lt = lanemask_lt(lane);
+	int            r  = step_offset + __builtin_popcountll(ballot[m][0] & lt) + __builtin_popcountll(ballot[m][1] & lt);
+	if (j == 1 && (flags & (1u << (2 * m)))) { r += 1; }
+	return r;
+}
+
+// ---- FFOR u64 pack from LDS (closed form of src/fastlanes_generated_ffor.cpp:7379-29749) -------------------
+// vals[i] hold (value - base) & mask in natural index order.  Output unit u = 8*k + a is the 16-byte pair of
+// stream word k for lane16 columns 2a, 2a+1; lane handles units lane, lane+64, ... -> 1-KiB contiguous stores.
+__device__ __forceinline__ void pack_u64_from_lds(const EncodeLds& L, int bw, ulonglong2* __restrict__ out, int lane) {
+	const ulonglong2* vals2   = reinterpret_cast<const ulonglong2*>(L.vals);
+	const int         n_units = 8 * bw;
+	for (int u = lane; u < n_units; u += 64) {
+		const int  k    = u >> 3;
+		const int  a    = u & 7;
+		const int  bit0 = 64 * k;
+		int        r    = bit0 / bw;
+		int        p    = r * bw;
+		ulonglong2 acc  = make_ulonglong2(0, 0);
+		while (p < bit0 + 64 && r < 64) {
+			const ulonglong2 v  = vals2[8 * r + a];
+			const int        sh = p - bit0;
+			if (sh >= 0) {
+				acc.x |= v.x << sh;
+				acc.y |= v.y << sh;
+			} else {
+				acc.x |= v.x >> (-sh);
+				acc.y |= v.y >> (-sh);
+			}
+			p += bw;
+			++r;
+		}
+		out[u] = acc;
+	}
+}
+
+// ---- ALP_RD split of one vector held in registers (rd.hpp:109-147) ------------------------------------------
+struct RdEncoded {
+	uint64_t right[8][2];
+	uint16_t left[8][2];  // original left parts
+	uint8_t  idx[8][2];   // dictionary index; dict_size at exception slots
+	uint64_t ballot[8][2];
+	uint32_t flags;
+	int      cnt;
+};
+
+__device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgpu_rowgroup_state& rg, int lane, RdEncoded& R) {
+	const int      rbw  = rg.rd_rbw;
+	const uint64_t mask = bw_mask(rbw);
+	const int      ds   = rg.rd_dict_size;
+	R.flags = 0;
+	R.cnt   = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const double   v    = j == 0 ? in.x[m].x : in.x[m].y;
+			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(v));
+			R.right[m][j]       = bits & mask;
+			const uint16_t left = static_cast<uint16_t>(bits >> rbw);
+			int            idx  = ds;
+#pragma unroll
+			for (int d = 7; d >= 0; --d) {
+				if (d < ds && rg.rd_dict[d] == left) { idx = d; }
+			}
+			const bool exc = idx == ds;
+			R.left[m][j]   = left;
+			R.idx[m][j]    = static_cast<uint8_t>(idx);
+			R.ballot[m][j] = __ballot(exc);
+			R.flags |= exc ? (1u << (2 * m + j)) : 0u;
+			R.cnt += __builtin_popcountll(R.ballot[m][j]);
+		}
+	}
+}
+
+// FFOR u16 pack of the dictionary indices (64 lane-streams x 16 rows, words at out[64*k + lane64]);
+// value i -> lane64 = i & 63, row = i >> 6.  A lane holds rows 2m + (lane>>5) of streams 2*(lane&31), +1;
+// partner lane^32 holds the other 8 rows.  lbw <= 16 in general; the codec uses 1..3.
+__device__ __forceinline__ void pack_left_u16(const uint16_t (&idx)[8][2], int lbw, uint32_t* __restrict__ out32, int lane) {
+	if (lbw <= 4) {
+		// whole stream (16 rows x lbw bits <= 64 bits) fits one u64 accumulator per stream
+		const uint64_t lmask = (1ull << lbw) - 1ull;
+		uint64_t       acc0 = 0, acc1 = 0;
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			const int row = 2 * m + (lane >> 5);
+			acc0 |= (static_cast<uint64_t>(idx[m][0]) & lmask) << (row * lbw);
+			acc1 |= (static_cast<uint64_t>(idx[m][1]) & lmask) << (row * lbw);
+		}
+		acc0 |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(acc0), 32));
+		acc1 |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(acc1), 32));
+		if (lane < 32) {
+			for (int k = 0; k < lbw; ++k) {
+				const uint32_t w0 = static_cast<uint32_t>(acc0 >> (16 * k)) & 0xFFFFu;
+				const uint32_t w1 = static_cast<uint32_t>(acc1 >> (16 * k)) & 0xFFFFu;
+				out32[32 * k + lane] = w0 | (w1 << 16);
+			}
+		}
+	} else {
+		// generic width: word by word
+		const uint32_t lmask = lbw >= 16 ? 0xFFFFu : ((1u << lbw) - 1u);
+		for (int k = 0; k < lbw; ++k) {
+			uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+			for (int m = 0; m < 8; ++m) {
+				const int row = 2 * m + (lane >> 5);
+				const int sh  = row * lbw - 16 * k; // position of this row's field relative to word k
+				if (sh > -16 && sh < 16) {
+					const uint32_t a = idx[m][0] & lmask, b = idx[m][1] & lmask;
+					w0 |= sh >= 0 ? (a << sh) : (a >> (-sh));
+					w1 |= sh >= 0 ? (b << sh) : (b >> (-sh));
+				}
+			}
+			w0 = (w0 | __shfl_xor(w0, 32)) & 0xFFFFu;
+			w1 = (w1 | __shfl_xor(w1, 32)) & 0xFFFFu;
+			if (lane < 32) { out32[32 * k + lane] = w0 | (w1 << 16); }
+		}
+	}
+}
+
+} // namespace alpgpu

@@ -1,0 +1,245 @@
+// init_kernels.hip — per-rowgroup codec state for gfx950: sampling, (e,f) search, scheme decision, RD dictionary.
+//
+// Replaces, per rowgroup of <= 100 vectors (file:line relative to /root/reference):
+//   alp::sampler::first_level_sample                 include/alp/sampler.hpp:14-52
+//   alp::encoder<double>::find_top_k_combinations    include/alp/encoder.hpp:139-235
+//   alp::encoder<double>::init                       include/alp/encoder.hpp:420-427
+//   alp::rd_encoder<double>::init / find_best_dictionary / build_left_parts_dictionary
+//                                                    include/alp/rd.hpp:180-185 / :89-104 / :33-87
+//
+// One workgroup of 9 wavefronts per rowgroup; wavefront w owns sampled vector w (rowgroup vectors 0,12,..,96),
+// 32 samples each at stride 32 — the reference's sample set for whole-vector columns.  The (e,f) search maps
+// the 190 candidates to lanes (3 per lane) and walks the 32 samples as LDS broadcasts, so there is no
+// cross-lane traffic until the final arg-min.  The candidate order (e = 18..0, f = e..0) and the reference's
+// update rule make the winner "the first candidate in that order with the minimum estimated size", i.e. the
+// minimum of (size, candidate index).
+#include "alp_device.hpp"
+#include "launch.hpp"
+
+namespace alpgpu {
+
+constexpr int kMaxSampledVectors = 9; // ceil(100 / 12)
+constexpr int kNumCombos         = 190;
+constexpr int kInitThreads       = 64 * kMaxSampledVectors;
+
+struct ComboTable {
+	uint8_t e[192];
+	uint8_t f[192];
+};
+constexpr ComboTable make_combo_table() {
+	ComboTable t {};
+	int        c = 0;
+	for (int e = 18; e >= 0; --e) {
+		for (int f = e; f >= 0; --f) {
+			t.e[c] = static_cast<uint8_t>(e);
+			t.f[c] = static_cast<uint8_t>(f);
+			++c;
+		}
+	}
+	return t;
+}
+__device__ __constant__ const ComboTable kCombos = make_combo_table();
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		const uint32_t o = __shfl_xor(v, d);
+		v                = o < v ? o : v;
+	}
+	return v;
+}
+
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* scratch /*[kMaxSampledVectors]*/, int lane, int wave) {
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d); }
+	__syncthreads();
+	if (lane == 0) { scratch[wave] = v; }
+	__syncthreads();
+	uint32_t s = 0;
+#pragma unroll
+	for (int w = 0; w < kMaxSampledVectors; ++w) { s += scratch[w]; }
+	return s;
+}
+
+__global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __restrict__ in, uint64_t n_vectors,
+                                                                alpgpu_rowgroup_state* __restrict__ rgs) {
+	__shared__ double   smp[kMaxSampledVectors * 32];
+	__shared__ uint32_t best_key[kMaxSampledVectors];
+	__shared__ uint32_t red[kMaxSampledVectors];
+	__shared__ uint16_t s_cnt[kMaxSampledVectors * 32];
+	__shared__ uint8_t  s_first[kMaxSampledVectors * 32];
+	__shared__ uint16_t s_best_dict[8];
+	__shared__ int      s_scheme;
+
+	const int      lane    = lane_id();
+	const int      wave    = wave_in_wg();
+	const int      tid     = static_cast<int>(threadIdx.x);
+	const uint64_t rg      = blockIdx.x;
+	const uint64_t v_first = rg * kRowgroup;
+	const int      nv      = static_cast<int>((n_vectors - v_first) < kRowgroup ? (n_vectors - v_first) : kRowgroup);
+	const int      n_sv    = (nv + 11) / 12; // vectors with (index % 12) == 0, sampler.hpp:29-33
+	const int      n_smp   = 32 * n_sv;
+
+	// first-level sample: values 32*s of each sampled vector (sampler.hpp:35-49 with full vectors)
+	if (wave < n_sv && lane < 32) { smp[wave * 32 + lane] = in[(v_first + 12ull * wave) * kVec + 32ull * lane]; }
+	__syncthreads();
+
+	// ---- find_top_k_combinations: per sampled vector, arg-min over the 190 (e,f) candidates ----
+	if (wave < n_sv) {
+		uint32_t my_key = 0xFFFFFFFFu;
+#pragma unroll 1
+		for (int r = 0; r < 3; ++r) {
+			const int c = lane + 64 * r;
+			if (c < kNumCombos) {
+				const int     e      = kCombos.e[c];
+				const int     f      = kCombos.f[c];
+				const double  exp10  = kExpArr[e];
+				const double  frac_f = kFracArr[f];
+				const int64_t fact   = kFactArr[f];
+				const double  frac_e = kFracArr[e];
+				int           non_exc = 0;
+				int64_t       mx = INT64_MIN, mn = INT64_MAX;
+#pragma unroll 4
+				for (int s = 0; s < 32; ++s) {
+					const double  v   = smp[wave * 32 + s];
+					const int64_t enc = encode_value_safe(v, exp10, frac_f);
+					const double  dec = decode_value(enc, fact, frac_e);
+					if (dec == v) {
+						++non_exc;
+						mx = enc > mx ? enc : mx;
+						mn = enc < mn ? enc : mn;
+					}
+				}
+				if (non_exc >= 2) { // encoder.hpp:182
+					const uint32_t size = 32u * static_cast<uint32_t>(count_bits(mx, mn)) + static_cast<uint32_t>(32 - non_exc) * 80u;
+					const uint32_t key  = (size << 8) | static_cast<uint32_t>(c);
+					my_key              = key < my_key ? key : my_key;
+				}
+			}
+		}
+		my_key = wave_min_u32(my_key);
+		if (lane == 0) { best_key[wave] = my_key; }
+	}
+	__syncthreads();
+
+	// ---- vote, scheme decision, top-k (encoder.hpp:207-234) ----
+	if (tid == 0) {
+		uint32_t best_size = 32u * (64u + 16u) + 32u * 64u; // worst case, encoder.hpp:147-149
+		int      ce[kMaxSampledVectors], cf[kMaxSampledVectors], cn[kMaxSampledVectors];
+		int      n_c = 0;
+		for (int w = 0; w < n_sv; ++w) {
+			int e = 0, f = 0;
+			if (best_key[w] != 0xFFFFFFFFu) {
+				const int      c    = static_cast<int>(best_key[w] & 0xFFu);
+				const uint32_t size = best_key[w] >> 8;
+				e                   = kCombos.e[c];
+				f                   = kCombos.f[c];
+				best_size           = size < best_size ? size : best_size;
+			}
+			int hit = -1;
+			for (int i = 0; i < n_c; ++i) {
+				if (ce[i] == e && cf[i] == f) { hit = i; }
+			}
+			if (hit < 0) {
+				ce[n_c] = e, cf[n_c] = f, cn[n_c] = 1;
+				++n_c;
+			} else {
+				++cn[hit];
+			}
+		}
+		alpgpu_rowgroup_state st;
+		st.k = 0;
+		for (int i = 0; i < 10; ++i) { st.combos[i] = 0; }
+		st.rd_rbw = st.rd_lbw = st.rd_dict_size = st.pad = 0;
+		for (int i = 0; i < 8; ++i) { st.rd_dict[i] = 0; }
+		if (best_size >= 48u * 32u) { // RD_SIZE_THRESHOLD_LIMIT, encoder.hpp:213-216
+			st.scheme = ALPGPU_SCHEME_ALP_RD;
+		} else {
+			st.scheme = ALPGPU_SCHEME_ALP;
+			// insertion sort by (count desc, e desc, f desc): a strict total order (encoder.hpp:128-132)
+			for (int i = 1; i < n_c; ++i) {
+				const int e = ce[i], f = cf[i], n = cn[i];
+				int       j = i - 1;
+				while (j >= 0 && (n > cn[j] || (n == cn[j] && e > ce[j]) || (n == cn[j] && e == ce[j] && f > cf[j]))) {
+					ce[j + 1] = ce[j], cf[j + 1] = cf[j], cn[j + 1] = cn[j];
+					--j;
+				}
+				ce[j + 1] = e, cf[j + 1] = f, cn[j + 1] = n;
+			}
+			const int k = n_c < 5 ? n_c : 5;
+			st.k        = static_cast<uint8_t>(k);
+			for (int i = 0; i < k; ++i) {
+				st.combos[2 * i]     = static_cast<uint8_t>(ce[i]);
+				st.combos[2 * i + 1] = static_cast<uint8_t>(cf[i]);
+			}
+		}
+		rgs[rg]  = st;
+		s_scheme = st.scheme;
+	}
+	__syncthreads();
+	if (s_scheme != ALPGPU_SCHEME_ALP_RD) { return; }
+
+	// ---- ALP_RD: find the cut and the dictionary (rd.hpp:89-104, :33-87) ----
+	// For each cut, sample t counts the samples sharing its left part and whether it is that part's first
+	// occurrence; distinct parts are ranked by (count desc, first occurrence asc) — the reference sorts by
+	// count only and leaves ties to libstdc++ internals; the size estimate does not depend on
+	// the tie order, the dictionary order does.
+	const uint64_t my_bits = tid < n_smp ? static_cast<uint64_t>(__double_as_longlong(smp[tid])) : 0ull;
+	double         best_est = 1.7976931348623157e308;
+	int            best_rbw = 0, best_lbw = 0, best_ds = 0;
+#pragma unroll 1
+	for (int cut = 1; cut <= 16; ++cut) {
+		const int      rbw  = 64 - cut;
+		const uint64_t left = my_bits >> rbw;
+		uint32_t       cnt = 0;
+		bool           first = true;
+		if (tid < n_smp) {
+			for (int j = 0; j < n_smp; ++j) {
+				const uint64_t lj = static_cast<uint64_t>(__double_as_longlong(smp[j])) >> rbw;
+				const bool     eq = lj == left;
+				cnt += eq ? 1u : 0u;
+				first = first && !(eq && j < tid);
+			}
+			s_cnt[tid]   = static_cast<uint16_t>(cnt);
+			s_first[tid] = first ? 1 : 0;
+		}
+		__syncthreads();
+		uint32_t rank = 0;
+		if (tid < n_smp && first) {
+			for (int j = 0; j < n_smp; ++j) {
+				const uint32_t cj = s_cnt[j];
+				if (s_first[j] && (cj > cnt || (cj == cnt && j < tid))) { ++rank; }
+			}
+		}
+		const bool     in_dict  = tid < n_smp && first && rank < 8;
+		const uint32_t covered  = block_sum_u32(in_dict ? cnt : 0u, red, lane, wave);
+		const uint32_t distinct = block_sum_u32((tid < n_smp && first) ? 1u : 0u, red, lane, wave);
+		const uint32_t excs     = static_cast<uint32_t>(n_smp) - covered;
+		const int      ds       = distinct < 8 ? static_cast<int>(distinct) : 8;
+		const int      lbw      = ds <= 2 ? 1 : (ds <= 4 ? 2 : 3); // max(1, ceil(log2(ds)))
+		const double   est      = static_cast<double>(rbw + lbw) + static_cast<double>(excs * 32u) / static_cast<double>(n_smp);
+		if (est < best_est) { // block-uniform
+			best_est = est;
+			best_rbw = rbw;
+			best_lbw = lbw;
+			best_ds  = ds;
+			if (in_dict) { s_best_dict[rank] = static_cast<uint16_t>(left); }
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		rgs[rg].rd_rbw       = static_cast<uint8_t>(best_rbw);
+		rgs[rg].rd_lbw       = static_cast<uint8_t>(best_lbw);
+		rgs[rg].rd_dict_size = static_cast<uint8_t>(best_ds);
+		for (int i = 0; i < 8; ++i) { rgs[rg].rd_dict[i] = i < best_ds ? s_best_dict[i] : 0; }
+	}
+}
+
+int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs) {
+	if (n_vectors == 0) { return ALPGPU_OK; }
+	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
+	hipLaunchKernelGGL(k_rowgroup_init, dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+} // namespace alpgpu

@@ -10,4 +10,38 @@ namespace alpgpu {
 // decode_kernels.hip
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus);
 
+// init_kernels.hip
+int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs);
+
+// encode_kernels.hip
+uint64_t encode_workspace_bytes(uint64_t n_vectors);
+int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
+                          int n_cus);
+
+// primitive_kernels.hip
+int launch_ffor_i64(hipStream_t stream, int n_cus, const int64_t* in, int64_t* packed, size_t stride, const uint8_t* bw,
+                    const int64_t* base, uint64_t n);
+int launch_unffor_i64(hipStream_t stream, int n_cus, const int64_t* packed, size_t stride, int64_t* out, const uint8_t* bw,
+                      const int64_t* base, uint64_t n);
+int launch_falp(hipStream_t stream, int n_cus, const int64_t* packed, size_t stride, double* out, const uint8_t* bw,
+                const int64_t* base, const uint8_t* fac, const uint8_t* exp, uint64_t n);
+int launch_ffor_u16(hipStream_t stream, int n_cus, const uint16_t* in, uint16_t* packed, size_t stride, const uint8_t* bw,
+                    const uint16_t* base, uint64_t n);
+int launch_unffor_u16(hipStream_t stream, int n_cus, const uint16_t* packed, size_t stride, uint16_t* out, const uint8_t* bw,
+                      const uint16_t* base, uint64_t n);
+int launch_decode_values(hipStream_t stream, int n_cus, const int64_t* enc, double* out, const uint8_t* fac, const uint8_t* exp,
+                         uint64_t n);
+int launch_patch(hipStream_t stream, int n_cus, double* out, const double* exc, const uint16_t* pos, size_t stride,
+                 const uint16_t* cnt, uint64_t n);
+int launch_analyze_ffor(hipStream_t stream, int n_cus, const int64_t* enc, uint8_t* bw, int64_t* base, uint64_t n);
+int launch_encode_simdized(hipStream_t stream, int n_cus, const double* in, double* exc, uint16_t* pos, size_t stride, uint16_t* cnt,
+                           int64_t* enc, const uint8_t* fac, const uint8_t* exp, uint64_t n);
+int launch_encode_values(hipStream_t stream, int n_cus, const double* in, const alpgpu_rowgroup_state* states, const uint32_t* idx,
+                         double* exc, uint16_t* pos, size_t stride, uint16_t* cnt, int64_t* enc, uint8_t* fac, uint8_t* exp, uint64_t n);
+int launch_rd_encode(hipStream_t stream, int n_cus, const double* in, const alpgpu_rowgroup_state* states, const uint32_t* idx,
+                     uint16_t* exc, uint16_t* pos, size_t stride, uint16_t* cnt, uint64_t* right, uint16_t* left, uint64_t n);
+int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t* right, const uint16_t* left,
+                     const alpgpu_rowgroup_state* states, const uint32_t* idx, const uint16_t* exc, const uint16_t* pos, size_t stride,
+                     const uint16_t* cnt, uint64_t n);
+
 } // namespace alpgpu

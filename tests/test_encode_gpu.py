@@ -1,0 +1,155 @@
+"""GPU parity: rowgroup init + vector encode (HIP, through the C ABI) against the oracle, bit for bit:
+rowgroup state (scheme, k, (e,f) candidates), per-vector (e, f, bit width, base, exception count), packed
+bytes, exception values and positions, stream offsets; then encode->decode round trips on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import datagen
+import golden_io
+import layout
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_encode(ctx, col_np, states=None):
+    from alp_amd import capi
+    x = torch.from_numpy(np.ascontiguousarray(col_np)).cuda()
+    col = capi.DeviceColumn(col_np.size // 1024)
+    if states is None:
+        ctx.encode(x, col)
+    else:
+        col.rowgroups[: states.size * 32] = torch.from_numpy(states.view(np.uint8).reshape(-1)).cuda()
+        ctx.encode_vectors(x, col)
+    ctx.synchronize()
+    pb, eb, ov = ctx.column_totals(col)
+    assert ov == 0
+    return col, x
+
+
+def assert_parts_equal(got, want, name):
+    """got/want: fixed-stride dicts (layout.expand / oracle).  Per-vector metadata, packed u64 words (ALP words /
+    ALP_RD right parts), exception values and positions must match in every bit."""
+    n = want["scheme"].size
+    for k in ("scheme", "e", "f", "bw", "lbw", "base", "exc_cnt"):
+        assert np.array_equal(got[k], want[k]), f"{name}: {k} differs at {np.nonzero(got[k] != want[k])[0][:5]}"
+    assert np.array_equal(got["packed"], want["packed"]), f"{name}: packed words differ"
+    for v in range(n):
+        c = int(want["exc_cnt"][v])
+        assert np.array_equal(got["pos"][v, :c], want["pos"][v, :c]), f"{name}: exception positions differ in vector {v}"
+        if want["scheme"][v] == 2:
+            assert np.array_equal(got["exc"][v].view(np.uint64)[:c], want["exc"][v].view(np.uint64)[:c]), f"{name}: exc values v{v}"
+        else:
+            assert np.array_equal(got["exc"][v].view(np.uint16)[:c], want["exc"][v].view(np.uint16)[:c]), f"{name}: rd exc values v{v}"
+
+
+COLUMNS = {
+    "decimal2": lambda: datagen.decimal_column(230, 2, seed=1),
+    "decimal5_small": lambda: datagen.decimal_column(101, 5, 0, 10, seed=2),
+    "mixed_1pct": lambda: datagen.mixed_column(250, seed=3, exc_rate=0.01),
+    "mixed_10pct": lambda: datagen.mixed_column(120, seed=4, exc_rate=0.10),
+    "drifting_k": lambda: datagen.drifting_column(200, seed=7),
+    "integers": lambda: np.floor(datagen.decimal_column(64, 0, 0, 1e6, seed=8)),
+    "tiny": lambda: datagen.decimal_column(3, 3, seed=9),
+    "adversarial": lambda: np.concatenate(list(datagen.adversarial_vectors().values())),
+}
+
+
+@pytest.mark.parametrize("name", list(COLUMNS.keys()))
+def test_alp_columns_encode_bit_exact(ctx, oracle, name):
+    col_np = COLUMNS[name]()
+    want = oracle.encode_column(col_np)
+    dcol, x = gpu_encode(ctx, col_np)
+    rg, vec, packed, exc = dcol.to_host()
+    got = layout.expand(rg, vec, packed, exc)
+    assert np.array_equal(got["k"], want["k"]), name
+    assert np.array_equal(got["combos"], want["combos"]), name
+    assert_parts_equal(got, want, name)
+    # offsets are the exclusive scan of the record sizes, in vector order
+    w_rg, w_vec, w_packed, w_exc = layout.compact(want)
+    assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
+    if (want["scheme"] == 2).all():
+        assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc), "whole streams must be byte-identical"
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+
+
+@pytest.mark.parametrize("case", golden_io.rowgroup_samples(), ids=lambda c: c[0])
+def test_golden_rowgroup_samples_encode_bit_exact(ctx, case):
+    name, col_np, gold = case
+    dcol, x = gpu_encode(ctx, col_np)
+    got = layout.expand(*dcol.to_host())
+    assert np.array_equal(got["k"], gold["k"]) and np.array_equal(got["combos"], gold["combos"])
+    assert_parts_equal(got, gold, name)
+
+
+def test_golden_first_vectors_encode(ctx):
+    for name, col_np, gold, known in golden_io.first_vectors():
+        dcol, x = gpu_encode(ctx, col_np)
+        got = layout.expand(*dcol.to_host())
+        assert got["scheme"][0] == gold["scheme"][0], name
+        if gold["scheme"][0] == 2:
+            assert np.array_equal(got["k"], gold["k"]) and np.array_equal(got["combos"], gold["combos"]), name
+            assert_parts_equal(got, gold, name)
+            if known[0] >= 0:  # the pairs test/test_alp_sample.cpp:178-179 asserts
+                assert int(got["bw"][0]) == int(known[0]) and int(got["exc_cnt"][0]) == int(known[1]), name
+        else:
+            assert got["bw"][0] == gold["bw"][0] and got["lbw"][0] == gold["lbw"][0], name
+            assert got["dict_size"][0] == gold["dict_size"][0], name
+        out = ctx.decode(dcol)
+        ctx.synchronize()
+        assert torch.equal(out.view(torch.int64), x.view(torch.int64)), name
+
+
+RD_COLUMNS = {
+    "rd_unit": lambda: datagen.rd_column(130, seed=5, kind="unit"),
+    "rd_latlon": lambda: datagen.rd_column(110, seed=6, kind="latlon"),
+    "rd_few_left_parts": lambda: (np.random.default_rng(10).integers(0, 5, 150 * 1024).astype(np.float64) * 1e-3
+                                  + np.random.default_rng(11).random(150 * 1024) * 1e-9),
+    "mixed_alp_and_rd": lambda: np.concatenate([datagen.decimal_column(100, 2, seed=21), datagen.rd_column(100, seed=22),
+                                                datagen.mixed_column(100, seed=23), datagen.rd_column(57, seed=24, kind="latlon")]),
+}
+
+
+@pytest.mark.parametrize("name", list(RD_COLUMNS.keys()))
+def test_rd_vectors_with_reference_state_bit_exact(ctx, oracle, name):
+    """ALP_RD vector encode given the rowgroup state the oracle (== reference) computed: right parts, exception
+    lists and counts are bit-exact; left indices are compared at non-exception slots."""
+    col_np = RD_COLUMNS[name]()
+    want = oracle.encode_column(col_np)
+    states, _, _, _ = layout.compact(want)
+    dcol, x = gpu_encode(ctx, col_np, states=states)
+    got = layout.expand(*dcol.to_host())
+    assert_parts_equal(got, want, name)
+    for v in np.nonzero(want["scheme"] == 1)[0]:
+        a = oracle.unffor_u16(got["packed_left"][v], int(want["lbw"][v]))
+        b = oracle.unffor_u16(want["packed_left"][v], int(want["lbw"][v]))
+        keep = np.ones(1024, bool)
+        keep[want["pos"][v, : int(want["exc_cnt"][v])]] = False
+        assert np.array_equal(a[keep], b[keep]), f"{name}: left dictionary indices differ in vector {v}"
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+
+
+@pytest.mark.parametrize("name", list(RD_COLUMNS.keys()))
+def test_rd_rowgroup_init_matches_reference_decisions(ctx, oracle, name):
+    """Own rowgroup init: scheme, cut (right/left bit width) and dictionary size equal the oracle's; round trip exact."""
+    col_np = RD_COLUMNS[name]()
+    want = oracle.encode_column(col_np)
+    dcol, x = gpu_encode(ctx, col_np)
+    rg, vec, packed, exc = dcol.to_host()
+    w_rg, _, _, _ = layout.compact(want)
+    assert np.array_equal(rg["scheme"], w_rg["scheme"])
+    rd = rg["scheme"] == 1
+    assert np.array_equal(rg["rd_rbw"][rd], w_rg["rd_rbw"][rd]) and np.array_equal(rg["rd_lbw"][rd], w_rg["rd_lbw"][rd])
+    assert np.array_equal(rg["rd_dict_size"][rd], w_rg["rd_dict_size"][rd])
+    for r in np.nonzero(rd)[0]:
+        ds = int(rg["rd_dict_size"][r])
+        if ds < 8:  # every distinct sampled left part is in the dictionary: same set regardless of tie order
+            assert sorted(rg["rd_dict"][r, :ds].tolist()) == sorted(w_rg["rd_dict"][r, :ds].tolist())
+    assert np.array_equal(rg["k"][~rd], w_rg["k"][~rd]) and np.array_equal(rg["combos"][~rd], w_rg["combos"][~rd])
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
