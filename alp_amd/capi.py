@@ -74,6 +74,18 @@ _sig("alpgpu_rowgroup_init_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_vectors_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_column_totals", _int, _vp, C.POINTER(CColumn), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_int))
+_sig("alpgpu_ffor_i64", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
+_sig("alpgpu_unffor_i64", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
+_sig("alpgpu_ffor_u16", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
+_sig("alpgpu_unffor_u16", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
+_sig("alpgpu_falp_f64", _int, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_decode_values_f64", _int, _vp, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_patch_f64", _int, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
+_sig("alpgpu_encode_simdized_f64", _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_encode_values_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_analyze_ffor_i64", _int, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_rd_encode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
+_sig("alpgpu_rd_decode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
 
 
 class AlpGpuError(RuntimeError):
@@ -146,6 +158,52 @@ class Context:
         pb, eb, ov = _u64(), _u64(), _int()
         _check(lib.alpgpu_column_totals(self.h, C.byref(col.c), C.byref(pb), C.byref(eb), C.byref(ov)), "alpgpu_column_totals")
         return pb.value, eb.value, ov.value
+
+    # ---- batch primitives (torch tensors on this device; shapes [n, 1024] unless noted) ---------------
+    @staticmethod
+    def _p(t):
+        return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+    def ffor_i64(self, vals, packed, bw, base):
+        _check(lib.alpgpu_ffor_i64(self.h, self._p(vals), self._p(packed), packed.shape[1], self._p(bw), self._p(base), vals.shape[0]), "alpgpu_ffor_i64")
+
+    def unffor_i64(self, packed, out, bw, base):
+        _check(lib.alpgpu_unffor_i64(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), out.shape[0]), "alpgpu_unffor_i64")
+
+    def ffor_u16(self, vals, packed, bw, base=None):
+        _check(lib.alpgpu_ffor_u16(self.h, self._p(vals), self._p(packed), packed.shape[1], self._p(bw), self._p(base), vals.shape[0]), "alpgpu_ffor_u16")
+
+    def unffor_u16(self, packed, out, bw, base=None):
+        _check(lib.alpgpu_unffor_u16(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), out.shape[0]), "alpgpu_unffor_u16")
+
+    def falp(self, packed, out, bw, base, fac, exp):
+        _check(lib.alpgpu_falp_f64(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), self._p(fac), self._p(exp),
+                                   out.shape[0]), "alpgpu_falp_f64")
+
+    def decode_values(self, enc, out, fac, exp):
+        _check(lib.alpgpu_decode_values_f64(self.h, self._p(enc), self._p(out), self._p(fac), self._p(exp), out.shape[0]), "alpgpu_decode_values_f64")
+
+    def patch(self, out, exc, pos, cnt):
+        _check(lib.alpgpu_patch_f64(self.h, self._p(out), self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_patch_f64")
+
+    def encode_simdized(self, x, exc, pos, cnt, enc, fac, exp):
+        _check(lib.alpgpu_encode_simdized_f64(self.h, self._p(x), self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), self._p(enc),
+                                              self._p(fac), self._p(exp), x.shape[0]), "alpgpu_encode_simdized_f64")
+
+    def encode_values(self, x, states, state_idx, exc, pos, cnt, enc, fac, exp):
+        _check(lib.alpgpu_encode_values_f64(self.h, self._p(x), self._p(states), self._p(state_idx), self._p(exc), self._p(pos), exc.shape[1],
+                                            self._p(cnt), self._p(enc), self._p(fac), self._p(exp), x.shape[0]), "alpgpu_encode_values_f64")
+
+    def analyze_ffor(self, enc, bw, base):
+        _check(lib.alpgpu_analyze_ffor_i64(self.h, self._p(enc), self._p(bw), self._p(base), enc.shape[0]), "alpgpu_analyze_ffor_i64")
+
+    def rd_encode_vectors(self, x, states, state_idx, exc, pos, cnt, right, left):
+        _check(lib.alpgpu_rd_encode_vectors_f64(self.h, self._p(x), self._p(states), self._p(state_idx), self._p(exc), self._p(pos), exc.shape[1],
+                                                self._p(cnt), self._p(right), self._p(left), x.shape[0]), "alpgpu_rd_encode_vectors_f64")
+
+    def rd_decode_vectors(self, out, right, left, states, state_idx, exc, pos, cnt):
+        _check(lib.alpgpu_rd_decode_vectors_f64(self.h, self._p(out), self._p(right), self._p(left), self._p(states), self._p(state_idx),
+                                                self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_rd_decode_vectors_f64")
 
     def decode(self, col: "DeviceColumn", out=None):
         import torch

@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X ALP path (BASELINE.json): fused ALP decode (falp + patch) GB/s of
+decoded doubles per GPU and fraction of the HBM roofline, with encode GB/s and the reference's CPU path next to it.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1 Mi vectors (1024 doubles each, 8 GiB decoded) per GPU of synthetic decimal
+doubles, ALP-encoded, bit widths sweeping 1..53 across rowgroups (rowgroup r has bw = 1 + r mod 53), per-vector
+base = splitmix64(42, v) mod 2^bw, (f, e) = (min(12, floor((62-bw) log10 2)), f+2), no exceptions; packed words
+are uniform random bits (every bit pattern is a valid FFOR stream of uniform digits).  All inputs are resident in
+HBM before the timed region.  A "step" = one alpgpu_decode_f64 over the whole column.  N > 1: every rank owns its
+own column of the same size (weak scaling; vectors are independent, there is no collective on the data path).
+
+One JSON line is printed by rank 0 (see the driver contract in the task description / DESIGN.md).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from alp_amd import capi  # noqa: E402  (raises if libalpgpu.so is missing: there is no CPU fallback)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VEC = 1024
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=None, exc_per_vec: int = 0, first_vector: int = 0):
+    """Synthetic ALP-encoded column in HBM (descriptors on host -> device; packed words generated on device)."""
+    v = np.arange(n_vectors, dtype=np.uint64) + np.uint64(first_vector)  # global vector index of this shard's vectors
+    rg = (v // np.uint64(100)).astype(np.int64)
+    bw = (1 + rg % 53) if bw_of_rowgroup is None else np.broadcast_to(np.asarray(bw_of_rowgroup), rg.shape)
+    bw = bw.astype(np.int64)
+    f = np.minimum(12, np.floor((62 - bw) * np.log10(2.0))).astype(np.int64)
+    f = np.maximum(f, 0)
+    e = f + 2
+    with np.errstate(over="ignore"):
+        base = (splitmix64(v + np.uint64(seed) * np.uint64(0x632BE59BD9B4E019)) % (np.uint64(1) << bw.astype(np.uint64))).astype(np.int64)
+    rec = (10 * exc_per_vec + 7) // 8 * 8
+    vec = np.zeros(n_vectors, capi.VECTOR_DTYPE)
+    vec["bw"], vec["e"], vec["f"], vec["base"] = bw, e, f, base
+    vec["scheme"] = capi.SCHEME_ALP
+    vec["exc_cnt"] = exc_per_vec
+    psz = 128 * bw
+    vec["packed_off"] = np.concatenate([[0], np.cumsum(psz)[:-1]]).astype(np.uint64)
+    vec["exc_off"] = (np.arange(n_vectors, dtype=np.uint64) * np.uint64(rec))
+    packed_bytes = int(psz.sum())
+    rgs = np.zeros((n_vectors + 99) // 100, capi.ROWGROUP_DTYPE)
+    rgs["scheme"] = capi.SCHEME_ALP
+    rgs["k"] = 1
+    col = capi.DeviceColumn(n_vectors, device, packed_capacity=packed_bytes + 1024, exc_capacity=n_vectors * rec + 64)
+    dev = col.vectors.device
+    col.vectors.copy_(torch.from_numpy(vec.view(np.uint8).reshape(-1)).to(dev))
+    col.rowgroups[: rgs.size * 32] = torch.from_numpy(rgs.view(np.uint8).reshape(-1)).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + seed)
+    chunk = 1 << 28
+    for o in range(0, packed_bytes, chunk):
+        m = min(chunk, packed_bytes - o)
+        col.packed[o:o + m] = torch.randint(0, 256, (m,), dtype=torch.uint8, device=dev, generator=g)
+    if exc_per_vec:
+        rng = np.random.default_rng(seed)
+        one = np.zeros(rec, np.uint8)
+        one[: 8 * exc_per_vec] = rng.integers(0, 255, 8 * exc_per_vec)
+        one[8 * exc_per_vec: 10 * exc_per_vec] = np.sort(rng.choice(1024, exc_per_vec, replace=False)).astype(np.uint16).view(np.uint8)
+        col.exc[: n_vectors * rec] = torch.from_numpy(np.tile(one, n_vectors)).to(dev)
+    col.totals[0] = packed_bytes
+    col.totals[1] = n_vectors * rec
+    # algorithmic bytes per launch: read 128*bw + 10*exc + 13, write 8192, per vector
+    alg_bytes = int((128 * bw + 10 * exc_per_vec + 13 + 8192).sum())
+    return col, vec, alg_bytes
+
+
+def time_launches(fn, iters: int, warmup: int):
+    """median / mean ms per launch with HIP events on the launch stream (torch's current stream == ctx stream)"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = np.array([a.elapsed_time(b) for a, b in evs])
+    return float(np.median(ts)), float(ts.mean())
+
+
+def synthetic_input(kind: str, n_vectors: int, device, seed: int):
+    """device-side synthetic double columns for the encode legs"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = n_vectors * VEC
+    if kind == "rd":
+        return torch.rand(n, dtype=torch.float64, device=device, generator=g)
+    x = (torch.rand(n, dtype=torch.float64, device=device, generator=g) - 0.5) * 2e5
+    out = torch.empty_like(x)
+    nrg = (n_vectors + 99) // 100
+    for d in (1, 2, 4):  # decimals cycle per rowgroup
+        sc = 10.0 ** d
+        idx = torch.arange(nrg, device=device)
+        sel = (idx % 3 == (1, 2, 4).index(d)).repeat_interleave(100 * VEC)[:n]
+        out[sel] = torch.round(x[sel] * sc) / sc
+    m = torch.rand(n, device=device, generator=g) < 0.01  # 1 % full-precision values -> exceptions
+    out[m] = x[m] * 3.141592653589793
+    sp = torch.rand(n, device=device, generator=g) < 0.001  # 0.1 % specials
+    specials = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0], dtype=torch.float64, device=device)
+    out[sp] = specials[torch.randint(0, 4, (int(sp.sum()),), device=device, generator=g)]
+    return out
+
+
+def cpu_baseline_leg(col, vec, gpu_out, sample_vectors: int):
+    """Times the REFERENCE's CPU decode (falp + patch_exceptions; oracle/_ref, built from /root/reference in the build
+    container) on this box's host cores over a bounded sample of the same column, and uses its output to check the
+    GPU result bit for bit.  The only place bench.py touches oracle/."""
+    from oracle import pyoracle
+    kind, runner = None, None
+    flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    if pyoracle.Reference.available():
+        path = pyoracle.REF_AVX512_SO if ("avx512dq" in flags and os.path.exists(pyoracle.REF_AVX512_SO)) else pyoracle.REF_SO
+        runner, kind = pyoracle.Reference(path), "reference"
+    else:
+        runner, kind = pyoracle.Oracle(), "port"
+    n = min(sample_vectors, vec.size)
+    end = int(vec["packed_off"][n - 1]) + 128 * int(vec["bw"][n - 1])
+    packed_host = col.packed[:end].cpu().numpy()
+    packed = np.zeros((n, 1024), np.int64)
+    p8 = packed.view(np.uint8).reshape(n, 8192)
+    for v in range(n):
+        b, o = int(vec["bw"][v]), int(vec["packed_off"][v])
+        p8[v, :128 * b] = packed_host[o:o + 128 * b]
+    bw, e, f, base = (np.ascontiguousarray(vec[k][:n]) for k in ("bw", "e", "f", "base"))
+    cnt = np.zeros(n, np.uint16)
+    exc = np.zeros((n, 8), np.float64)
+    pos = np.zeros((n, 8), np.uint16)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    per = n  # every thread decodes the whole (shared, read-only) sample into its own output buffer
+    outs = [np.empty(per * 1024, np.float64) for _ in range(threads)]
+
+    def work(t, reps, res):
+        res[t] = runner.time_falp_column(packed, 1024, bw, e, f, base, cnt, exc, pos, 8, per, outs[t], reps)
+
+    def run(nthreads, reps):
+        res = [0.0] * nthreads
+        ths = [threading.Thread(target=work, args=(t, reps, res)) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return time.perf_counter() - t0, res
+
+    run(threads, 1)  # warm (page-faults the outputs)
+    wall1, _ = run(threads, 1)
+    reps = int(max(1, min(500, 8.0 / max(wall1, 1e-3))))
+    wall, _ = run(threads, reps)
+    all_cores = threads * per * 8192 * reps / wall / 1e9
+    r1 = max(1, reps // 2)
+    t1 = runner.time_falp_column(packed, 1024, bw, e, f, base, cnt, exc, pos, 8, per, outs[0], r1)
+    single = per * 8192 * r1 / t1 / 1e9
+    got = gpu_out[: per * 1024].cpu().numpy()
+    exact = bool(np.array_equal(got.view(np.uint64), outs[0].view(np.uint64)))
+    model = ""
+    for line in flags.splitlines():
+        if line.startswith("model name"):
+            model = line.split(":", 1)[1].strip()
+            break
+    return {
+        "value": round(all_cores, 3), "unit": "GB/s decoded doubles", "cores": threads, "kind": kind,
+        "sample": f"falp+patch_exceptions on the first {per} vectors of the same column ({per * 8 // 1024} MiB decoded per pass per "
+                  f"thread, private output buffers), {reps} passes, {threads} host threads ({os.path.basename(runner.path)}; "
+                  f"single thread {single:.2f} GB/s; cpu: {model})",
+        "single_thread_value": round(single, 3), "gpu_matches_cpu_bit_exact": exact,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--vectors", type=int, default=1 << 20, help="vectors per GPU (default 1 Mi = 8 GiB decoded)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-bit-width sweep, the encode legs and the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; alp_amd has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    ctx = capi.Context(local_rank)  # launches on torch's current stream of this device
+
+    # the global column has world * vectors vectors; this rank decodes its contiguous whole-rowgroup shard of it
+    from alp_amd.sharding import rowgroup_shard
+    first_vector, n = rowgroup_shard(world * args.vectors, rank, world)
+    col, vec, alg_bytes = build_decode_column(n, local_rank, seed=42, first_vector=first_vector)
+    out = torch.empty(n * VEC, dtype=torch.float64, device=dev)
+
+    def step():
+        ctx.decode(col, out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # average launch duration (HIP events, launch stream)
+    if dist is not None:
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+
+    decoded_bytes = n * 8192
+    if dist is not None:  # shards differ by at most one rowgroup; sum the actual sizes
+        tb = torch.tensor([decoded_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb)
+        total_decoded = int(tb[0])
+    else:
+        total_decoded = decoded_bytes
+    value = total_decoded * args.steps / elapsed / 1e9
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "ALP fused decode (falp + patch) throughput, decoded doubles",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "falp fused decode, synthetic decimal doubles, 1024-value vectors, bit-width sweep 1-53 across rowgroups, "
+                               "no exceptions (BASELINE.json configs[1])",
+                   "vectors_per_gpu": n, "decoded_bytes_per_gpu": decoded_bytes, "parallelism": f"{world} independent shards (no collective)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "k_decode_column", "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        "per_gpu_value": round(decoded_bytes * args.steps / elapsed / 1e9, 2),
+    }
+    pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            t = json.load(open(pmc))
+            if t.get("vectors") == n and t.get("kernel") == "k_decode_column":
+                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = t.get("source")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        # per-bit-width sweep (each point: 128 Ki vectors = 1 GiB decoded, median of 5 launches)
+        ns = min(n, 1 << 17)
+        sweep = {}
+        for bw in (1, 2, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 53):
+            c, _, ab = build_decode_column(ns, local_rank, seed=7, bw_of_rowgroup=bw)
+            med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+            sweep[str(bw)] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
+            del c
+        extras["decode_sweep_by_bit_width"] = sweep
+        c, _, ab = build_decode_column(ns, local_rank, seed=8, bw_of_rowgroup=16, exc_per_vec=20)
+        med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+        extras["decode_bw16_2pct_exceptions"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
+        del c
+        # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
+        for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
+            ne = min(n, 1 << 18)
+            x = synthetic_input(kind, ne, dev, seed=42)
+            ecol = capi.DeviceColumn(ne, local_rank)
+            med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
+            pb, eb, ov = ctx.column_totals(ecol)
+            dmed, _ = time_launches(lambda: ctx.decode(ecol, out), 5, 2)
+            rt = bool(torch.equal(out[: ne * VEC].view(torch.int64), x.view(torch.int64)))
+            extras[label] = {"input_GBps": round(ne * 8192 / med / 1e6, 1), "ms": round(med, 3), "vectors": ne,
+                             "compressed_bits_per_value": round((pb + eb + 32 * ne) * 8 / (ne * VEC), 2),
+                             "roofline_frac_algorithmic": round((ne * 8192 + pb + eb + 13 * ne) / med / 1e6 / HBM_PEAK_GBPS, 4),
+                             "decode_GBps": round(ne * 8192 / dmed / 1e6, 1), "gpu_roundtrip_bit_exact": rt}
+            del x, ecol
+        result["extras"] = extras
+        ctx.decode(col, out)
+        torch.cuda.synchronize()
+        result["cpu_baseline"] = cpu_baseline_leg(col, vec, out, sample_vectors=1024)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
