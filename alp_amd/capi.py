@@ -17,7 +17,7 @@ import numpy as np
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libalpgpu.so")
+LIB_PATH = os.environ.get("ALPGPU_LIB", os.path.join(HERE, "libalpgpu.so"))  # ALPGPU_LIB: A/B builds of the same ABI
 
 VECTOR_SIZE = 1024
 ROWGROUP_VECTORS = 100

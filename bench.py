@@ -280,8 +280,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
-        # per-bit-width sweep (each point: 128 Ki vectors = 1 GiB decoded, median of 5 launches)
-        ns = min(n, 1 << 17)
+        # per-bit-width sweep at the FULL column size (1 Mi vectors): smaller columns leave the packed stream resident in
+        # the 256 MiB Infinity Cache across launches and overstate narrow widths by up to 1.8x (profiles/r01_time_one.txt)
+        ns = n
         sweep = {}
         for bw in (1, 2, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 53):
             c, _, ab = build_decode_column(ns, local_rank, seed=7, bw_of_rowgroup=bw)
