@@ -195,6 +195,24 @@ int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vec
 	return ALPGPU_OK;
 }
 
+static int state_from_samples(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_samples || !d_state) { return fail(ALPGPU_ERR_INVALID, "null samples or state"); }
+	if (n_samples == 0 || n_samples > 288) { return fail(ALPGPU_ERR_INVALID, "n_samples must be 1..288 (9 sampled vectors x 32)"); }
+	if (alpgpu::launch_state_from_samples(ctx->stream, d_samples, n_samples, d_state, force_rd) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "state-from-samples launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state) {
+	return state_from_samples(ctx, d_samples, n_samples, d_state, 0);
+}
+
+int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state) {
+	return state_from_samples(ctx, d_samples, n_samples, d_state, 1);
+}
+
 int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }

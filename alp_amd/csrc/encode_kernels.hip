@@ -269,7 +269,7 @@ uint64_t encode_workspace_bytes(uint64_t n_vectors) { return ((n_vectors + kScan
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus) {
 	if (n_vectors == 0) {
-		hipMemsetAsync(col->d_totals, 0, 32, stream);
+		(void)hipMemsetAsync(col->d_totals, 0, 32, stream);
 		return ALPGPU_OK;
 	}
 	const uint64_t n_tiles = (n_vectors + kScanTile - 1) / kScanTile;

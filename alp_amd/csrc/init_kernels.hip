@@ -61,8 +61,14 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* scratch 
 	return s;
 }
 
+// FROM_SAMPLES = false: `in` is the column, the kernel gathers the rowgroup's first-level sample itself.
+// FROM_SAMPLES = true : `in` holds first-level samples gathered by the caller (what the reference's
+// find_top_k_combinations / find_best_dictionary receive): workgroup b reads n_vectors (= its sample count, <= 288)
+// doubles at in + 288*b.  Used by the per-rowgroup entry point behind include/alp.hpp, where the column may end in
+// a partial vector and the sampler's index rules (sampler.hpp:29-44) are applied on the host.
+template <bool FROM_SAMPLES>
 __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __restrict__ in, uint64_t n_vectors,
-                                                                alpgpu_rowgroup_state* __restrict__ rgs) {
+                                                                alpgpu_rowgroup_state* __restrict__ rgs, int force_rd) {
 	__shared__ double   smp[kMaxSampledVectors * 32];
 	__shared__ uint32_t best_key[kMaxSampledVectors];
 	__shared__ uint32_t red[kMaxSampledVectors];
@@ -75,17 +81,29 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 	const int      wave    = wave_in_wg();
 	const int      tid     = static_cast<int>(threadIdx.x);
 	const uint64_t rg      = blockIdx.x;
-	const uint64_t v_first = rg * kRowgroup;
-	const int      nv      = static_cast<int>((n_vectors - v_first) < kRowgroup ? (n_vectors - v_first) : kRowgroup);
-	const int      n_sv    = (nv + 11) / 12; // vectors with (index % 12) == 0, sampler.hpp:29-33
-	const int      n_smp   = 32 * n_sv;
-
-	// first-level sample: values 32*s of each sampled vector (sampler.hpp:35-49 with full vectors)
-	if (wave < n_sv && lane < 32) { smp[wave * 32 + lane] = in[(v_first + 12ull * wave) * kVec + 32ull * lane]; }
+	int n_sv, n_smp, samples_size;
+	if constexpr (FROM_SAMPLES) {
+		// encoder.hpp:140-143: ceil(n / 32) sampled "vectors" of min(n, 32) samples each
+		n_smp        = static_cast<int>(n_vectors);
+		n_sv         = (n_smp + 31) / 32;
+		samples_size = n_smp < 32 ? n_smp : 32;
+		if (wave < n_sv && lane < 32) { smp[wave * 32 + lane] = in[288ull * rg + wave * samples_size + (lane < samples_size ? lane : 0)]; }
+	} else {
+		const uint64_t v_first = rg * kRowgroup;
+		const int      nv      = static_cast<int>((n_vectors - v_first) < kRowgroup ? (n_vectors - v_first) : kRowgroup);
+		n_sv                   = (nv + 11) / 12; // vectors with (index % 12) == 0, sampler.hpp:29-33
+		n_smp                  = 32 * n_sv;
+		samples_size           = 32;
+		// first-level sample: values 32*s of each sampled vector (sampler.hpp:35-49 with full vectors)
+		if (wave < n_sv && lane < 32) { smp[wave * 32 + lane] = in[(v_first + 12ull * wave) * kVec + 32ull * lane]; }
+	}
 	__syncthreads();
 
 	// ---- find_top_k_combinations: per sampled vector, arg-min over the 190 (e,f) candidates ----
-	if (wave < n_sv) {
+	// (force_rd: rd_encoder::init called directly on these samples — the reference's rd.hpp:180-185 does not re-check
+	//  the ALP threshold — so the search is skipped and every key stays "no valid candidate")
+	if (lane == 0 && wave < kMaxSampledVectors) { best_key[wave] = 0xFFFFFFFFu; }
+	if (wave < n_sv && !force_rd) {
 		uint32_t my_key = 0xFFFFFFFFu;
 #pragma unroll 1
 		for (int r = 0; r < 3; ++r) {
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 				int           non_exc = 0;
 				int64_t       mx = INT64_MIN, mn = INT64_MAX;
 #pragma unroll 4
-				for (int s = 0; s < 32; ++s) {
+				for (int s = 0; s < samples_size; ++s) {
 					const double  v   = smp[wave * 32 + s];
 					const int64_t enc = encode_value_safe(v, exp10, frac_f);
 					const double  dec = decode_value(enc, fact, frac_e);
@@ -111,7 +129,8 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 					}
 				}
 				if (non_exc >= 2) { // encoder.hpp:182
-					const uint32_t size = 32u * static_cast<uint32_t>(count_bits(mx, mn)) + static_cast<uint32_t>(32 - non_exc) * 80u;
+					const uint32_t size = static_cast<uint32_t>(samples_size) * static_cast<uint32_t>(count_bits(mx, mn)) +
+					                      static_cast<uint32_t>(samples_size - non_exc) * 80u;
 					const uint32_t key  = (size << 8) | static_cast<uint32_t>(c);
 					my_key              = key < my_key ? key : my_key;
 				}
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 
 	// ---- vote, scheme decision, top-k (encoder.hpp:207-234) ----
 	if (tid == 0) {
-		uint32_t best_size = 32u * (64u + 16u) + 32u * 64u; // worst case, encoder.hpp:147-149
+		uint32_t best_size = static_cast<uint32_t>(samples_size) * (64u + 16u) + static_cast<uint32_t>(samples_size) * 64u; // encoder.hpp:147-149
 		int      ce[kMaxSampledVectors], cf[kMaxSampledVectors], cn[kMaxSampledVectors];
 		int      n_c = 0;
 		for (int w = 0; w < n_sv; ++w) {
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 		for (int i = 0; i < 10; ++i) { st.combos[i] = 0; }
 		st.rd_rbw = st.rd_lbw = st.rd_dict_size = st.pad = 0;
 		for (int i = 0; i < 8; ++i) { st.rd_dict[i] = 0; }
-		if (best_size >= 48u * 32u) { // RD_SIZE_THRESHOLD_LIMIT, encoder.hpp:213-216
+		if (force_rd || best_size >= 48u * 32u) { // RD_SIZE_THRESHOLD_LIMIT, encoder.hpp:213-216
 			st.scheme = ALPGPU_SCHEME_ALP_RD;
 		} else {
 			st.scheme = ALPGPU_SCHEME_ALP;
@@ -184,7 +203,9 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 	// occurrence; distinct parts are ranked by (count desc, first occurrence asc) — the reference sorts by
 	// count only and leaves ties to libstdc++ internals; the size estimate does not depend on
 	// the tie order, the dictionary order does.
-	const uint64_t my_bits = tid < n_smp ? static_cast<uint64_t>(__double_as_longlong(smp[tid])) : 0ull;
+	// (sample t sits at smp[32 * (t / samples_size) + t % samples_size]; with 32-sample blocks that is smp[t])
+	auto smp_at = [&](int t) { return smp[32 * (t / samples_size) + (t % samples_size)]; };
+	const uint64_t my_bits = tid < n_smp ? static_cast<uint64_t>(__double_as_longlong(smp_at(tid))) : 0ull;
 	double         best_est = 1.7976931348623157e308;
 	int            best_rbw = 0, best_lbw = 0, best_ds = 0;
 #pragma unroll 1
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 		bool           first = true;
 		if (tid < n_smp) {
 			for (int j = 0; j < n_smp; ++j) {
-				const uint64_t lj = static_cast<uint64_t>(__double_as_longlong(smp[j])) >> rbw;
+				const uint64_t lj = static_cast<uint64_t>(__double_as_longlong(smp_at(j))) >> rbw;
 				const bool     eq = lj == left;
 				cnt += eq ? 1u : 0u;
 				first = first && !(eq && j < tid);
@@ -238,7 +259,13 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs) {
 	if (n_vectors == 0) { return ALPGPU_OK; }
 	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
-	hipLaunchKernelGGL(k_rowgroup_init, dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs);
+	hipLaunchKernelGGL(k_rowgroup_init<false>, dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+	hipLaunchKernelGGL(k_rowgroup_init<true>, dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
+	                   force_rd);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

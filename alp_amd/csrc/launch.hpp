@@ -13,6 +13,8 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 // init_kernels.hip
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs);
 
+int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
+
 // encode_kernels.hip
 uint64_t encode_workspace_bytes(uint64_t n_vectors);
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,

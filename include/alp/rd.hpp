@@ -1,0 +1,111 @@
+// alp/rd.hpp — alp::rd_encoder<PT> with the reference's signatures (include/alp/rd.hpp:109-185), computed on the GPU.
+//
+// Dictionary order.  The reference builds the left-part histogram in a std::unordered_map and std::sort()s it by count
+// only, so the order of equally frequent left parts is whatever libstdc++ produces.  The GPU builder
+// ranks by (count desc, first occurrence in the sample asc): same cut position, bit widths, dictionary size and — when
+// counts are untied — same dictionary.  Left parts outside the dictionary are packed as index = dictionary size (the
+// reference packs a map position there, which no decoder reads).  A state produced by the reference itself can be
+// passed to encode()/decode() unchanged.
+#ifndef ALP_RD_HPP
+#define ALP_RD_HPP
+#include "alp/common.hpp"
+#include "alp/constants.hpp"
+#include "alp/encoder.hpp"
+#include "alp/gpu_bridge.hpp"
+#include "alp/sampler.hpp"
+
+namespace alp {
+
+template <class PT>
+struct rd_encoder {
+	using UT                                     = typename inner_t<PT>::ut;
+	static constexpr uint8_t EXACT_TYPE_BIT_SIZE = sizeof(UT) * 8;
+
+	//! rd.hpp:180-185: sample the rowgroup, choose the cut and the dictionary
+	static inline void init(const PT* data_column, size_t column_offset, size_t tuples_count, PT* sample_arr, state<PT>& stt) {
+		stt.scheme           = Scheme::ALP_RD;
+		stt.sampled_values_n = sampler::first_level_sample<PT>(data_column, column_offset, tuples_count, sample_arr);
+		find_best_dictionary(sample_arr, stt);
+	}
+
+	//! rd.hpp:89-104
+	static inline void find_best_dictionary(const PT* smp_arr, state<PT>& stt) {
+		// the device decision covers ALP and ALP_RD in one pass; ask it to judge these samples as an RD rowgroup
+		auto&        s       = gpu::tls();
+		const size_t n       = stt.sampled_values_n;
+		const size_t n_block = (n + config::SAMPLES_PER_VECTOR - 1) / config::SAMPLES_PER_VECTOR;
+		const size_t n_up    = n < config::SAMPLES_PER_VECTOR ? n : n_block * config::SAMPLES_PER_VECTOR;
+		gpu::h2d(s.at<PT>(s.SAMPLES), smp_arr, n_up * sizeof(PT));
+		gpu::check(alpgpu_rd_state_from_samples_f64(gpu::context(), s.at<PT>(s.SAMPLES), static_cast<uint32_t>(n),
+		                                            s.at<alpgpu_rowgroup_state>(s.STATE)),
+		           "alpgpu_rd_state_from_samples_f64");
+		alpgpu_rowgroup_state d {};
+		gpu::d2h(&d, s.at<alpgpu_rowgroup_state>(s.STATE), sizeof(d));
+		stt.right_bit_width              = d.rd_rbw;
+		stt.left_bit_width               = d.rd_lbw;
+		stt.actual_dictionary_size       = d.rd_dict_size;
+		stt.actual_dictionary_size_bytes = d.rd_dict_size * DICTIONARY_ELEMENT_SIZE_BYTES;
+		stt.left_parts_dict_map.clear();
+		for (size_t i = 0; i < config::MAX_RD_DICTIONARY_SIZE; ++i) {
+			stt.left_parts_dict[i] = d.rd_dict[i];
+			if (i < d.rd_dict_size) { stt.left_parts_dict_map.insert({d.rd_dict[i], static_cast<uint16_t>(i)}); }
+		}
+	}
+
+	//! rd.hpp:109-147
+	static inline void encode(const PT*  dbl_arr,
+	                          uint16_t*  exceptions,
+	                          uint16_t*  exception_positions,
+	                          uint16_t*  exceptions_count_p,
+	                          UT*        right_parts,
+	                          uint16_t*  left_parts,
+	                          state<PT>& stt) {
+		auto&                       s = gpu::tls();
+		const alpgpu_rowgroup_state d = gpu::to_device_state(stt);
+		gpu::h2d(s.at<PT>(s.IN), dbl_arr, 8192);
+		gpu::h2d(s.at<alpgpu_rowgroup_state>(s.STATE), &d, sizeof(d));
+		gpu::check(alpgpu_rd_encode_vectors_f64(gpu::context(), s.at<PT>(s.IN), s.at<alpgpu_rowgroup_state>(s.STATE), nullptr,
+		                                        s.at<uint16_t>(s.EXC), s.at<uint16_t>(s.POS), 1024, s.cnt(), s.at<UT>(s.ENC),
+		                                        s.at<uint16_t>(s.LEFT), 1),
+		           "alpgpu_rd_encode_vectors_f64");
+		uint16_t n = 0;
+		gpu::d2h(&n, s.cnt(), 2);
+		gpu::d2h(right_parts, s.at<UT>(s.ENC), 8192);
+		gpu::d2h(left_parts, s.at<uint16_t>(s.LEFT), 2048);
+		if (n) {
+			gpu::d2h(exceptions, s.at<uint16_t>(s.EXC), static_cast<size_t>(n) * 2);
+			gpu::d2h(exception_positions, s.at<uint16_t>(s.POS), static_cast<size_t>(n) * 2);
+		}
+		stt.exceptions_count  = n;
+		exceptions_count_p[0] = n;
+	}
+
+	//! rd.hpp:152-178
+	static inline void decode(PT*        a_out,
+	                          UT*        unffor_right_arr,
+	                          uint16_t*  unffor_left_arr,
+	                          uint16_t*  exceptions,
+	                          uint16_t*  exceptions_positions,
+	                          uint16_t*  exceptions_count,
+	                          state<PT>& stt) {
+		auto&                       s = gpu::tls();
+		const alpgpu_rowgroup_state d = gpu::to_device_state(stt);
+		const uint16_t              n = exceptions_count[0];
+		gpu::h2d(s.at<UT>(s.ENC), unffor_right_arr, 8192);
+		gpu::h2d(s.at<uint16_t>(s.LEFT), unffor_left_arr, 2048);
+		gpu::h2d(s.at<alpgpu_rowgroup_state>(s.STATE), &d, sizeof(d));
+		gpu::h2d(s.cnt(), &n, 2);
+		if (n) {
+			gpu::h2d(s.at<uint16_t>(s.EXC), exceptions, static_cast<size_t>(n) * 2);
+			gpu::h2d(s.at<uint16_t>(s.POS), exceptions_positions, static_cast<size_t>(n) * 2);
+		}
+		gpu::check(alpgpu_rd_decode_vectors_f64(gpu::context(), s.at<PT>(s.OUT), s.at<UT>(s.ENC), s.at<uint16_t>(s.LEFT),
+		                                        s.at<alpgpu_rowgroup_state>(s.STATE), nullptr, s.at<uint16_t>(s.EXC), s.at<uint16_t>(s.POS), 1024,
+		                                        s.cnt(), 1),
+		           "alpgpu_rd_decode_vectors_f64");
+		gpu::d2h(a_out, s.at<PT>(s.OUT), 8192);
+	}
+};
+
+} // namespace alp
+#endif

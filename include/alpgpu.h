@@ -13,6 +13,7 @@
  *                              (sampler::first_level_sample           include/alp/sampler.hpp:14-52,
  *                               find_top_k_combinations               include/alp/encoder.hpp:139-235)
  *                              alp::rd_encoder<double>::init          include/alp/rd.hpp:180-185 (:33-104)
+ *   alpgpu_state_from_samples_f64  find_top_k_combinations (:139-235) + find_best_dictionary (rd.hpp:89-104) on given samples
  *   alpgpu_encode_f64          alp::encoder<double>::encode           include/alp/encoder.hpp:402-418
  *                              (find_best_exponent_factor_from_combinations :241-305, encode_simdized :307-400)
  *                              alp::encoder<double>::analyze_ffor     include/alp/encoder.hpp:109-120
@@ -144,6 +145,13 @@ uint64_t alpgpu_exc_capacity(uint64_t n_vectors);
 /* Rowgroup init for every rowgroup of the column: first-level sampling, (e,f) top-k search, scheme
  * decision, and for ALP_RD rowgroups the cut/dictionary search.  Writes col->d_rowgroups[0..n_rowgroups). */
 int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
+
+/* The same decision for ONE rowgroup from first-level samples the caller gathered (what the reference's
+ * find_top_k_combinations, include/alp/encoder.hpp:139-235, and find_best_dictionary, include/alp/rd.hpp:89-104,
+ * receive): d_samples holds n_samples (1..288) doubles, blocks of min(n_samples, 32) per sampled vector. */
+int alpgpu_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
+/* rd_encoder::init's half alone (include/alp/rd.hpp:180-185): cut + dictionary for these samples, no ALP/ALP_RD re-decision */
+int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
 
 /* Vector encode of the whole column given col->d_rowgroups (from alpgpu_rowgroup_init_f64 or supplied by
  * the caller): second-level sampling, encode + exception compaction, analyze_ffor, FFOR pack (ALP);

@@ -1,0 +1,42 @@
+// fastlanes/ffor.hpp — ffor::ffor with the reference's signatures (include/fastlanes/ffor.hpp:7-15) for the word sizes
+// the ALP path uses: 64-bit (ALP integers, ALP_RD right parts) and 16-bit (ALP_RD left parts).  GPU-backed.
+// 8- and 32-bit lanes are not part of the double-precision path and are not declared.
+#ifndef FASTLANES_FFOR_HPP
+#define FASTLANES_FFOR_HPP
+#include "alp/gpu_bridge.hpp"
+#include <cstdint>
+
+namespace fastlanes::generated::ffor::fallback::scalar {
+
+inline void ffor(const uint64_t* __restrict in, uint64_t* __restrict out, uint8_t bw, const uint64_t* __restrict a_base_p) {
+	if (bw == 0 || bw > 64) { return; } // the reference writes nothing for bw 0 and ignores unknown widths
+	auto& s = alp::gpu::tls();
+	alp::gpu::h2d(s.at<uint64_t>(s.ENC), in, 8192);
+	alp::gpu::h2d(s.bw(), &bw, 1);
+	alp::gpu::h2d(s.ffor_base(), a_base_p, 8);
+	alp::gpu::check(alpgpu_ffor_i64(alp::gpu::context(), s.at<int64_t>(s.ENC), s.at<int64_t>(s.PACKED), 1024, s.bw(), s.ffor_base(), 1),
+	                "alpgpu_ffor_i64");
+	alp::gpu::d2h(out, s.at<uint64_t>(s.PACKED), static_cast<size_t>(bw) * 128);
+}
+inline void ffor(const int64_t* __restrict in, int64_t* __restrict out, uint8_t bw, const int64_t* __restrict a_base_p) {
+	ffor(reinterpret_cast<const uint64_t*>(in), reinterpret_cast<uint64_t*>(out), bw, reinterpret_cast<const uint64_t*>(a_base_p));
+}
+
+inline void ffor(const uint16_t* __restrict in, uint16_t* __restrict out, uint8_t bw, const uint16_t* __restrict a_base_p) {
+	if (bw == 0 || bw > 16) { return; }
+	auto& s = alp::gpu::tls();
+	alp::gpu::h2d(s.at<uint16_t>(s.LEFT), in, 2048);
+	alp::gpu::h2d(s.bw(), &bw, 1);
+	alp::gpu::h2d(s.base16(), a_base_p, 2);
+	alp::gpu::check(alpgpu_ffor_u16(alp::gpu::context(), s.at<uint16_t>(s.LEFT), s.at<uint16_t>(s.PACKED_LEFT), 1024, s.bw(), s.base16(), 1),
+	                "alpgpu_ffor_u16");
+	alp::gpu::d2h(out, s.at<uint16_t>(s.PACKED_LEFT), static_cast<size_t>(bw) * 128);
+}
+inline void ffor(const int16_t* __restrict in, int16_t* __restrict out, uint8_t bw, const int16_t* __restrict a_base_p) {
+	ffor(reinterpret_cast<const uint16_t*>(in), reinterpret_cast<uint16_t*>(out), bw, reinterpret_cast<const uint16_t*>(a_base_p));
+}
+
+} // namespace fastlanes::generated::ffor::fallback::scalar
+
+namespace ffor = fastlanes::generated::ffor::fallback::scalar;
+#endif

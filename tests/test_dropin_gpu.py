@@ -1,0 +1,40 @@
+"""GPU: the source-compatible C++ header include/alp.hpp.  A C++ harness written in the style of the reference's own
+unit test (test/test_alp_sample.cpp `test_column`) is compiled with g++ against include/ and libalpgpu.so and run over
+the reference's test columns (tests/golden): every column must round-trip bit-exactly through
+init -> encode -> analyze_ffor -> ffor -> falp -> patch_exceptions (or the ALP_RD chain), the fused and unfused decode
+paths must agree, and the first vector must give the (bit width, exception count) the reference's test asserts."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_dropin_header_against_reference_columns(tmp_path):
+    exe = tmp_path / "dropin_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", f"-I{ROOT}/include", "-o", str(exe), f"{ROOT}/tests/cpp/dropin_test.cpp",
+                           f"-L{ROOT}/alp_amd", "-lalpgpu", f"-Wl,-rpath,{ROOT}/alp_amd"])
+    lines = []
+    for name, col, gold, known in golden_io.first_vectors():
+        key = name.replace("/", "_").replace(".csv", "")
+        col.tofile(tmp_path / f"{key}.f64")
+        is_rd = int(gold["scheme"][0] == 1)
+        bw, exc = (int(known[0]), int(known[1])) if (known[0] >= 0 and not is_rd) else (-1, -1)
+        lines.append(f"{key} 1024 {bw} {exc} {is_rd}")
+    for name, col, gold in golden_io.rowgroup_samples():  # 128 vectors: two rowgroups, k > 1 (second-level sampling)
+        col.tofile(tmp_path / f"{name}.f64")
+        lines.append(f"{name} {col.size} {int(gold['bw'][0])} {int(gold['exc_cnt'][0])} {int(gold['scheme'][0] == 1)}")
+    # a column that ends in a partial vector: the host-side sampler rules + whole vectors only
+    tail = np.round(np.random.default_rng(1).uniform(0, 100, 3 * 1024 + 500), 2)
+    tail.tofile(tmp_path / "partial_tail.f64")
+    lines.append(f"partial_tail {tail.size} -1 -1 0")
+    (tmp_path / "columns.txt").write_text("\n".join(lines) + "\n")
+    p = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    tail_out = "\n".join(p.stdout.splitlines()[-15:])
+    assert p.returncode == 0, f"drop-in harness failed:\n{tail_out}\n{p.stderr[-2000:]}"
+    assert f"{len(lines)} columns, 0 failures" in p.stdout
