@@ -49,16 +49,47 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 	return v;
 }
 
-__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* scratch /*[kMaxSampledVectors]*/, int lane, int wave) {
+constexpr int kMaxSamples = kMaxSampledVectors * 32; // 288
+
+// per-wavefront scratch of the ALP_RD cut search
+struct RdWaveScratch {
+	uint32_t len[kMaxSamples];      // run length, stored at the run's first sorted position (0 elsewhere)
+	uint32_t first[kMaxSamples];    // smallest original sample index inside the run (its first occurrence)
+	uint32_t hist[kMaxSamples + 8]; // hist[L] = number of runs of length L
+};
+
+// Runs of equal left parts (bits >> rbw) in the sorted samples: fills W.len / W.first, zeroes W.hist.  One wavefront.
+__device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, const uint64_t* s_key, const uint16_t* s_idx, int n_smp, int rbw, int lane) {
+	for (int b = 0; b < kMaxSamples + 8; b += 64) {
+		const int j = b + lane;
+		if (j < kMaxSamples) {
+			W.len[j]   = 0u;
+			W.first[j] = 0xFFFFFFFFu;
+		}
+		if (j < kMaxSamples + 8) { W.hist[j] = 0u; }
+	}
+	wave_lds_sync();
+	int carry = 0; // start of the run that continues from the previous chunk
+	for (int b = 0; b < n_smp; b += 64) {
+		const int      j     = b + lane;
+		const bool     valid = j < n_smp;
+		const uint64_t left  = valid ? (s_key[j] >> rbw) : 0ull;
+		const uint64_t prev  = (valid && j > 0) ? (s_key[j - 1] >> rbw) : ~left;
+		const bool     head  = valid && (j == 0 || left != prev);
+		int            st    = head ? j : -1;
 #pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d); }
-	__syncthreads();
-	if (lane == 0) { scratch[wave] = v; }
-	__syncthreads();
-	uint32_t s = 0;
-#pragma unroll
-	for (int w = 0; w < kMaxSampledVectors; ++w) { s += scratch[w]; }
-	return s;
+		for (int d = 1; d < 64; d <<= 1) {
+			const int t = __shfl_up(st, d);
+			if (lane >= d) { st = t > st ? t : st; }
+		}
+		st = st < 0 ? carry : st;
+		if (valid) {
+			atomicAdd(&W.len[st], 1u);
+			atomicMin(&W.first[st], static_cast<uint32_t>(s_idx[j]));
+		}
+		carry = __shfl(st, 63);
+	}
+	wave_lds_sync();
 }
 
 // FROM_SAMPLES = false: `in` is the column, the kernel gathers the rowgroup's first-level sample itself.
@@ -71,11 +102,14 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
                                                                 alpgpu_rowgroup_state* __restrict__ rgs, int force_rd) {
 	__shared__ double   smp[kMaxSampledVectors * 32];
 	__shared__ uint32_t best_key[kMaxSampledVectors];
-	__shared__ uint32_t red[kMaxSampledVectors];
-	__shared__ uint16_t s_cnt[kMaxSampledVectors * 32];
-	__shared__ uint8_t  s_first[kMaxSampledVectors * 32];
-	__shared__ uint16_t s_best_dict[8];
-	__shared__ int      s_scheme;
+	__shared__ uint64_t      s_key[kMaxSamples]; // samples sorted by bit pattern (ALP_RD)
+	__shared__ uint16_t      s_idx[kMaxSamples]; // original sample index of each sorted entry
+	__shared__ RdWaveScratch s_rd[kMaxSampledVectors];
+	__shared__ double        s_cut_est[17];
+	__shared__ uint8_t       s_cut_ds[17];
+	__shared__ int           s_best_cut;
+	__shared__ uint16_t      s_best_dict[8];
+	__shared__ int           s_scheme;
 
 	const int      lane    = lane_id();
 	const int      wave    = wave_in_wg();
@@ -199,60 +233,106 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 	if (s_scheme != ALPGPU_SCHEME_ALP_RD) { return; }
 
 	// ---- ALP_RD: find the cut and the dictionary (rd.hpp:89-104, :33-87) ----
-	// For each cut, sample t counts the samples sharing its left part and whether it is that part's first
-	// occurrence; distinct parts are ranked by (count desc, first occurrence asc) — the reference sorts by
-	// count only and leaves ties to libstdc++ internals; the size estimate does not depend on
-	// the tie order, the dictionary order does.
+	// The samples are sorted ONCE by their 64-bit pattern; for every cut position the equal left parts are then
+	// contiguous runs of the sorted order.  One wavefront evaluates one cut at a time with wave-level primitives
+	// only: run starts (max-scan), run lengths and first occurrences (LDS atomics), a histogram of run lengths and
+	// a descending scan of it for the mass of the 8 most frequent left parts.  Ties: distinct parts are ranked by
+	// (count desc, first occurrence in the sample asc) — the reference sorts by count only and leaves ties to
+	// libstdc++ internals; the size estimate does not depend on the tie order, the dictionary order does.
 	// (sample t sits at smp[32 * (t / samples_size) + t % samples_size]; with 32-sample blocks that is smp[t])
 	auto smp_at = [&](int t) { return smp[32 * (t / samples_size) + (t % samples_size)]; };
-	const uint64_t my_bits = tid < n_smp ? static_cast<uint64_t>(__double_as_longlong(smp_at(tid))) : 0ull;
-	double         best_est = 1.7976931348623157e308;
-	int            best_rbw = 0, best_lbw = 0, best_ds = 0;
-#pragma unroll 1
-	for (int cut = 1; cut <= 16; ++cut) {
-		const int      rbw  = 64 - cut;
-		const uint64_t left = my_bits >> rbw;
-		uint32_t       cnt = 0;
-		bool           first = true;
-		if (tid < n_smp) {
-			for (int j = 0; j < n_smp; ++j) {
-				const uint64_t lj = static_cast<uint64_t>(__double_as_longlong(smp_at(j))) >> rbw;
-				const bool     eq = lj == left;
-				cnt += eq ? 1u : 0u;
-				first = first && !(eq && j < tid);
-			}
-			s_cnt[tid]   = static_cast<uint16_t>(cnt);
-			s_first[tid] = first ? 1 : 0;
+	if (tid < n_smp) {
+		const uint64_t key  = static_cast<uint64_t>(__double_as_longlong(smp_at(tid)));
+		int            rank = 0;
+		for (int j = 0; j < n_smp; ++j) {
+			const uint64_t kj = static_cast<uint64_t>(__double_as_longlong(smp_at(j)));
+			rank += (kj < key || (kj == key && j < tid)) ? 1 : 0;
 		}
-		__syncthreads();
-		uint32_t rank = 0;
-		if (tid < n_smp && first) {
-			for (int j = 0; j < n_smp; ++j) {
-				const uint32_t cj = s_cnt[j];
-				if (s_first[j] && (cj > cnt || (cj == cnt && j < tid))) { ++rank; }
-			}
-		}
-		const bool     in_dict  = tid < n_smp && first && rank < 8;
-		const uint32_t covered  = block_sum_u32(in_dict ? cnt : 0u, red, lane, wave);
-		const uint32_t distinct = block_sum_u32((tid < n_smp && first) ? 1u : 0u, red, lane, wave);
-		const uint32_t excs     = static_cast<uint32_t>(n_smp) - covered;
-		const int      ds       = distinct < 8 ? static_cast<int>(distinct) : 8;
-		const int      lbw      = ds <= 2 ? 1 : (ds <= 4 ? 2 : 3); // max(1, ceil(log2(ds)))
-		const double   est      = static_cast<double>(rbw + lbw) + static_cast<double>(excs * 32u) / static_cast<double>(n_smp);
-		if (est < best_est) { // block-uniform
-			best_est = est;
-			best_rbw = rbw;
-			best_lbw = lbw;
-			best_ds  = ds;
-			if (in_dict) { s_best_dict[rank] = static_cast<uint16_t>(left); }
-		}
-		__syncthreads();
+		s_key[rank] = key;
+		s_idx[rank] = static_cast<uint16_t>(tid);
 	}
-	if (tid == 0) {
-		rgs[rg].rd_rbw       = static_cast<uint8_t>(best_rbw);
-		rgs[rg].rd_lbw       = static_cast<uint8_t>(best_lbw);
-		rgs[rg].rd_dict_size = static_cast<uint8_t>(best_ds);
-		for (int i = 0; i < 8; ++i) { rgs[rg].rd_dict[i] = i < best_ds ? s_best_dict[i] : 0; }
+	__syncthreads();
+
+	RdWaveScratch& W = s_rd[wave];
+	for (int cut = wave + 1; cut <= 16; cut += kMaxSampledVectors) { // wave-uniform
+		const int rbw = 64 - cut;
+		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
+		// histogram of run lengths; number of distinct left parts
+		int distinct = 0;
+		for (int b = 0; b < n_smp; b += 64) {
+			const int      j = b + lane;
+			const uint32_t L = j < n_smp ? W.len[j] : 0u;
+			if (L) { atomicAdd(&W.hist[L], 1u); }
+			distinct += __builtin_popcountll(__ballot(L != 0));
+		}
+		wave_lds_sync();
+		// mass of the 8 longest runs: walk run lengths from n_smp downwards
+		uint32_t covered = 0;
+		int      taken   = 0;
+		for (int top = n_smp; top >= 1 && taken < 8; top -= 64) {
+			const int      cval = top - lane;
+			const uint32_t h    = cval >= 1 ? W.hist[cval] : 0u;
+			uint32_t       inc  = h;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t t = __shfl_up(inc, d);
+				if (lane >= d) { inc += t; }
+			}
+			const uint32_t before = static_cast<uint32_t>(taken) + inc - h;
+			const uint32_t after  = static_cast<uint32_t>(taken) + inc;
+			const uint32_t mine   = (after < 8u ? after : 8u) - (before < 8u ? before : 8u);
+			uint32_t       part   = mine * static_cast<uint32_t>(cval > 0 ? cval : 0);
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) { part += __shfl_xor(part, d); }
+			covered += part;
+			taken += static_cast<int>(__shfl(inc, 63));
+		}
+		const uint32_t excs = static_cast<uint32_t>(n_smp) - covered;
+		const int      ds   = distinct < 8 ? distinct : 8;
+		const int      lbw  = ds <= 2 ? 1 : (ds <= 4 ? 2 : 3); // max(1, ceil(log2(ds)))
+		if (lane == 0) {
+			s_cut_est[cut] = static_cast<double>(rbw + lbw) + static_cast<double>(excs * 32u) / static_cast<double>(n_smp);
+			s_cut_ds[cut]  = static_cast<uint8_t>(ds);
+		}
+		wave_lds_sync();
+	}
+	__syncthreads();
+	if (tid == 0) { // first strictly smaller estimate in cut order 1..16 (rd.hpp:95-101)
+		double best = 1.7976931348623157e308;
+		int    bc   = 1;
+		for (int cut = 1; cut <= 16; ++cut) {
+			if (s_cut_est[cut] < best) {
+				best = s_cut_est[cut];
+				bc   = cut;
+			}
+		}
+		s_best_cut = bc;
+	}
+	__syncthreads();
+	if (wave == 0) { // the dictionary of the chosen cut: the (<= 8) best-ranked runs
+		const int best_cut = s_best_cut;
+		const int rbw      = 64 - best_cut;
+		const int ds       = s_cut_ds[best_cut];
+		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
+		for (int b = 0; b < n_smp; b += 64) {
+			const int      j  = b + lane;
+			const uint32_t L  = j < n_smp ? W.len[j] : 0u;
+			const uint32_t fo = j < n_smp ? W.first[j] : 0u;
+			int            rank = 0;
+			for (int g = 0; g < n_smp; ++g) { // broadcast reads
+				const uint32_t Lg = W.len[g];
+				rank += (Lg != 0 && (Lg > L || (Lg == L && W.first[g] < fo))) ? 1 : 0;
+			}
+			if (L != 0 && rank < 8) { s_best_dict[rank] = static_cast<uint16_t>(s_key[j] >> rbw); }
+		}
+		wave_lds_sync();
+		if (lane == 0) {
+			const int lbw        = ds <= 2 ? 1 : (ds <= 4 ? 2 : 3);
+			rgs[rg].rd_rbw       = static_cast<uint8_t>(rbw);
+			rgs[rg].rd_lbw       = static_cast<uint8_t>(lbw);
+			rgs[rg].rd_dict_size = static_cast<uint8_t>(ds);
+			for (int i = 0; i < 8; ++i) { rgs[rg].rd_dict[i] = i < ds ? s_best_dict[i] : 0; }
+		}
 	}
 }
 
