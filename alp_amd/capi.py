@@ -65,6 +65,8 @@ _sig("alpgpu_ctx_create", _int, _int, C.POINTER(_vp))
 _sig("alpgpu_ctx_destroy", None, _vp)
 _sig("alpgpu_set_stream", _int, _vp, _vp)
 _sig("alpgpu_synchronize", _int, _vp)
+_sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
+OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES = 1, 2
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
@@ -122,6 +124,9 @@ class Context:
 
     def set_stream(self, stream_handle: int):
         _check(lib.alpgpu_set_stream(self.h, _vp(stream_handle)), "alpgpu_set_stream")
+
+    def set_option(self, option: int, value: int):
+        _check(lib.alpgpu_set_option(self.h, option, value), "alpgpu_set_option")
 
     def synchronize(self):
         _check(lib.alpgpu_synchronize(self.h), "alpgpu_synchronize")

@@ -81,7 +81,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->stream         = ctx->own_stream;
 	ctx->n_cus          = prop.multiProcessorCount;
 	ctx->hbm_bytes      = prop.totalGlobalMem;
-	ctx->decode_variant  = 0;
+	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup (default), bit 1: plain stores
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { ctx->decode_variant = std::atoi(v); }
@@ -108,6 +108,21 @@ int alpgpu_use_own_stream(alpgpu_ctx* ctx) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
 	ctx->stream = ctx->own_stream;
 	return ALPGPU_OK;
+}
+
+int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
+	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+	switch (option) {
+	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
+		if (value != 1 && value != 2) { return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 1 or 2"); }
+		ctx->decode_variant = (ctx->decode_variant & ~1) | (value == 1 ? 1 : 0);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_PLAIN_STORES:
+		ctx->decode_variant = (ctx->decode_variant & ~2) | (value ? 2 : 0);
+		return ALPGPU_OK;
+	default:
+		return fail(ALPGPU_ERR_INVALID, "unknown option");
+	}
 }
 
 int alpgpu_synchronize(alpgpu_ctx* ctx) {

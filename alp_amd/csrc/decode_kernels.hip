@@ -19,11 +19,12 @@
 //      wavefront keeps the 32-word exclusive prefix of the mask's popcounts in registers,
 //   4. each lane unpacks its value pairs, applies base/FACT/FRAC (or the RD dictionary glue), substitutes
 //      exceptions by rank, and stores 16 bytes -> every store instruction writes 1 KiB contiguous.
-// What bounds it now (profiles/r01_time_waves.txt, r01_time_prefetch.txt): a workgroup lives for two dependent HBM
-// round trips (descriptor, then packed words) and 8 workgroups fit per CU (32-wave cap), i.e. ~2 vectors/us/CU
-// regardless of bit width; 2 waves per vector doubles the vectors in flight and lifts narrow widths (bw 4: 4.1 ->
-// 5.4 TB/s) but loses on wide ones and on the mixed-width benchmark column (0.71 vs 0.78 of peak), and an L2
-// prefetch of the descriptor 2-16 Ki vectors ahead did not move anything.  4 waves per vector is the default.
+// What bounds it now (profiles/r01_time_waves.txt, r01_time_prefetch.txt, r01_time_v2.txt): a workgroup lives for two
+// dependent HBM round trips (descriptor, then packed words) and 8 workgroups fit per CU (32-wave cap), i.e.
+// ~2 vectors/us/CU regardless of bit width.  Keeping more vectors in flight (2 waves per vector, or 2 vectors per
+// workgroup = ALPGPU_OPT_DECODE_VECTORS_PER_WG 2) lifts narrow widths (bw 4: 4.1 -> 5.2 TB/s, bw 16: 5.6 -> 6.1) but
+// the larger in-flight window costs 5-8 % on wide widths and on the mixed-width benchmark column (0.72 vs 0.79 of
+// peak); an L2 prefetch of the descriptor 2-16 Ki vectors ahead did not move anything.  Default: 1 vector, 4 waves.
 // HBM traffic per vector is the algorithmic minimum: 32 B descriptor + 128*bw B packed + exception record read,
 // 8192 B written (rocprofv3 FETCH_SIZE/WRITE_SIZE: profiles/*_pmc.json); no intermediate goes to HBM.
 #include "alp_device.hpp"
@@ -91,82 +92,17 @@ __device__ __forceinline__ void store_pair(double2* __restrict__ p, double x, do
 	}
 }
 
+// ---- one vector, after its packed words / exception mask are visible in L --------------------------------------
 template <bool NT_STORE>
-__global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_vector_desc* __restrict__ descs,
-                                                                  const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                                  const uint8_t* __restrict__ packed,
-                                                                  const uint8_t* __restrict__ excs, double* __restrict__ out,
-                                                                  uint64_t n_vectors, uint64_t v_offset) {
-	__shared__ DecodeLds L;
-	const int            tid  = static_cast<int>(threadIdx.x);
-	const int            lane = tid & 63;
-	const int            wave = wave_in_wg();
-	const uint64_t       v    = v_offset + blockIdx.x;
-	if (v >= n_vectors) { return; }
-
-	// The exception mask is zeroed and that write is fenced BEFORE anything waits on memory, so that the only
-	// barrier that sits behind HBM latency is the single one after all of this vector's loads have landed.
-	if (tid < 32) { L.mask[tid] = 0; }
-	__syncthreads();
-
-	const alpgpu_vector_desc d      = descs[v];
-	const int                bw     = d.bw;
-	const int                cnt    = d.exc_cnt;
-	const bool               is_alp = d.scheme == ALPGPU_SCHEME_ALP;
-	const int                lbw    = is_alp ? 0 : d.lbw;
-	const uint8_t*           rec    = excs + d.exc_off;
-	double2*                 dst    = reinterpret_cast<double2*>(out + v * kVec);
-
-	// issue every load of this vector back to back: packed words (<= 3 x 16 B per thread), exception position + value
-	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-	const int       n_units = 8 * (bw + lbw);
-	const ull2*     g       = reinterpret_cast<const ull2*>(packed + d.packed_off);
-	const int       vb      = is_alp ? 8 : 2;
-	const uint16_t* poss    = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * vb);
-	ull2            pk0 = {0, 0}, pk1 = {0, 0}, pk2 = {0, 0};
-	uint32_t        epos = 0;
-	uint64_t        eval = 0;
-	constexpr int T = 64 * kDecWaves;
-	ull2          pk3 = {0, 0}, pk4 = {0, 0}, pk5 = {0, 0};
-	if (tid < n_units) { pk0 = g[tid]; }
-	if (tid + T < n_units) { pk1 = g[tid + T]; }
-	if (tid + 2 * T < n_units) { pk2 = g[tid + 2 * T]; }
-	if (T < 256) {
-		if (tid + 3 * T < n_units) { pk3 = g[tid + 3 * T]; }
-		if (tid + 4 * T < n_units) { pk4 = g[tid + 4 * T]; }
-		if (tid + 5 * T < n_units) { pk5 = g[tid + 5 * T]; }
-	}
-	static_assert(kDecWaves >= 2, "exception staging below assumes T >= kExcStage");
-	if (tid < cnt) {
-		epos = poss[tid];
-		if (tid < kExcStage) { eval = is_alp ? reinterpret_cast<const uint64_t*>(rec)[tid] : static_cast<uint64_t>(reinterpret_cast<const uint16_t*>(rec)[tid]); }
-	}
-	{
-		ull2* s = reinterpret_cast<ull2*>(L.stage);
-		if (tid < n_units) { s[tid] = pk0; }
-		if (tid + T < n_units) { s[tid + T] = pk1; }
-		if (tid + 2 * T < n_units) { s[tid + 2 * T] = pk2; }
-		if (T < 256) {
-			if (tid + 3 * T < n_units) { s[tid + 3 * T] = pk3; }
-			if (tid + 4 * T < n_units) { s[tid + 4 * T] = pk4; }
-			if (tid + 5 * T < n_units) { s[tid + 5 * T] = pk5; }
-		}
-	}
-	if (tid < cnt) {
-		atomicOr(&L.mask[epos >> 5], 1u << (epos & 31));
-		if (tid < kExcStage) { L.excv[tid] = eval; }
-	}
-	for (int j = tid + T; j < cnt; j += T) { // more exceptions than threads in one vector: rare
-		const uint32_t p = poss[j];
-		atomicOr(&L.mask[p >> 5], 1u << (p & 31));
-	}
-	__syncthreads();
-	const int pref_reg = cnt > 0 ? mask_prefix(L, lane) : 0;
-
-	const int      a = lane & 7;
-	const int      r0 = lane >> 3;
+__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
+                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane) {
+	const int      bw       = d.bw;
+	const int      cnt      = d.exc_cnt;
+	const int      pref_reg = cnt > 0 ? mask_prefix(L, lane) : 0;
+	const int      a        = lane & 7;
+	const int      r0       = lane >> 3;
 	const UnitsPtr units {reinterpret_cast<const ulonglong2*>(L.stage)};
-	if (is_alp) {
+	if (d.scheme == ALPGPU_SCHEME_ALP) {
 		const uint64_t base = static_cast<uint64_t>(d.base);
 		const int64_t  fact = kFactArr[d.f];
 		const double   frac = kFracArr[d.e];
@@ -192,10 +128,10 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		// ALP_RD: right parts = u64 lanes (bw = rbw, base 0); left parts = u16 lanes, 64 streams x 16 rows (value i ->
 		// lane64 = i & 63, row = i >> 6, word k at left[64*k + lane64]); a lane's pair shares the row 2m + (lane >> 5)
 		// and is one aligned u32 of the left stream.
-		const alpgpu_rowgroup_state* rgp  = rgs + v / kRowgroup;
-		const int                    rbw  = bw;
-		const uint64_t               mask = bw_mask(rbw);
-		const uint32_t               lmsk = (1u << lbw) - 1u;
+		const int      rbw  = bw;
+		const int      lbw  = d.lbw;
+		const uint64_t mask = bw_mask(rbw);
+		const uint32_t lmsk = (1u << lbw) - 1u;
 		const uint64_t dlo = static_cast<uint64_t>(rgp->rd_dict[0]) | (static_cast<uint64_t>(rgp->rd_dict[1]) << 16) |
 		                     (static_cast<uint64_t>(rgp->rd_dict[2]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[3]) << 48);
 		const uint64_t dhi = static_cast<uint64_t>(rgp->rd_dict[4]) | (static_cast<uint64_t>(rgp->rd_dict[5]) << 16) |
@@ -230,19 +166,114 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	}
 }
 
+// Issues every load of one vector: packed words straight into LDS (global_load_lds, 16 B per lane, no VGPR round trip),
+// exception position + value into registers.
+struct ExcRegs {
+	uint32_t pos;
+	uint64_t val;
+};
+__device__ __forceinline__ ExcRegs issue_vector_loads(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
+                                                      const uint8_t* __restrict__ rec, int tid, int wave) {
+	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+	constexpr int T       = 64 * kDecWaves;
+	const bool    is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
+	const int     n_units = 8 * (d.bw + (is_alp ? 0 : d.lbw));
+	const ull2*   g       = reinterpret_cast<const ull2*>(packed + d.packed_off);
+#pragma unroll
+	for (int j = 0; j < (528 + T - 1) / T; ++j) {
+		const int c = tid + T * j;
+		if (c < n_units) { // LDS destination = wave-uniform base + 16 * lane
+			__builtin_amdgcn_global_load_lds(g + c, reinterpret_cast<ull2*>(L.stage) + (T * j + 64 * wave), 16, 0, 0);
+		}
+	}
+	ExcRegs   e {0u, 0ull};
+	const int cnt = d.exc_cnt;
+	if (tid < cnt) {
+		const int vb = is_alp ? 8 : 2;
+		e.pos        = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * vb)[tid];
+		if (tid < kExcStage) { e.val = is_alp ? reinterpret_cast<const uint64_t*>(rec)[tid] : static_cast<uint64_t>(reinterpret_cast<const uint16_t*>(rec)[tid]); }
+	}
+	return e;
+}
+
+__device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, const ExcRegs& e, int tid) {
+	constexpr int T   = 64 * kDecWaves;
+	const int     cnt = d.exc_cnt;
+	if (tid < cnt) {
+		atomicOr(&L.mask[e.pos >> 5], 1u << (e.pos & 31));
+		if (tid < kExcStage) { L.excv[tid] = e.val; }
+	}
+	if (cnt > T) { // more exceptions than threads in one vector: rare
+		const uint16_t* poss = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2));
+		for (int j = tid + T; j < cnt; j += T) {
+			const uint32_t p = poss[j];
+			atomicOr(&L.mask[p >> 5], 1u << (p & 31));
+		}
+	}
+}
+
+// V consecutive vectors per workgroup: all of their loads are in flight together, then they are unpacked one after the
+// other by the same 4 wavefronts.  V = 2 doubles the bytes in flight per CU for the same residency (8 workgroups per CU).
+template <int V, bool NT_STORE>
+__global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_vector_desc* __restrict__ descs,
+                                                                  const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                  const uint8_t* __restrict__ packed,
+                                                                  const uint8_t* __restrict__ excs, double* __restrict__ out,
+                                                                  uint64_t n_vectors, uint64_t wg_offset) {
+	__shared__ DecodeLds L[V];
+	static_assert(kDecWaves >= 2, "exception staging assumes at least kExcStage threads");
+	const int      tid  = static_cast<int>(threadIdx.x);
+	const int      lane = tid & 63;
+	const int      wave = wave_in_wg();
+	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
+	if (v0 >= n_vectors) { return; }
+
+	// The exception masks are zeroed and that write is fenced BEFORE anything waits on memory, so that the only
+	// barrier that sits behind HBM latency is the single one after all loads have landed.
+	if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
+	__syncthreads();
+
+	alpgpu_vector_desc d[V];
+	ExcRegs            e[V];
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // the odd tail vector is simply loaded twice
+		d[i]             = descs[v];
+	}
+#pragma unroll
+	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+#pragma unroll
+	for (int i = 0; i < V; ++i) { land_exceptions(L[i], d[i], excs + d[i].exc_off, e[i], tid); }
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
+	__syncthreads();
+
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		if (v0 + i < n_vectors) {
+			decode_staged_vector<NT_STORE>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off,
+			                               reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
+		}
+	}
+}
+
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus) {
 	(void)n_cus;
 	const uint64_t n = col->n_vectors;
-	// one workgroup per vector; a grid dimension holds < 2^31 workgroups -> chunk very long columns
-	const uint64_t kMaxGrid = 1ull << 30;
-	for (uint64_t off = 0; off < n; off += kMaxGrid) {
-		const unsigned grid = static_cast<unsigned>(n - off < kMaxGrid ? n - off : kMaxGrid);
-		if (variant == 1) {
-			hipLaunchKernelGGL((k_decode_column<false>), dim3(grid), dim3(64 * kDecWaves), 0, stream, col->d_vectors, col->d_rowgroups,
-			                   col->d_packed, col->d_exc, d_out, n, off);
+	// variant bit 0: one vector per workgroup (default) instead of two; bit 1: plain instead of non-temporal stores
+	const int      V        = (variant & 1) ? 1 : 2;
+	const bool     nt       = !(variant & 2);
+	const uint64_t n_wg     = (n + V - 1) / V;
+	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
+		if (V == 2 && nt) {
+			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+		} else if (V == 2) {
+			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+		} else if (nt) {
+			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<true>), dim3(grid), dim3(64 * kDecWaves), 0, stream, col->d_vectors, col->d_rowgroups,
-			                   col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;

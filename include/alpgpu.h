@@ -126,6 +126,12 @@ int         alpgpu_abi_version(void);
 int         alpgpu_set_stream(alpgpu_ctx* ctx, void* hip_stream);
 int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
+/* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 (default) or 2 consecutive vectors per decode
+ * workgroup; 2 keeps twice the bytes in flight and is faster for narrow columns (average bit width <= ~20), 1 for wide
+ * or mixed ones.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
+#define ALPGPU_OPT_DECODE_VECTORS_PER_WG 1
+#define ALPGPU_OPT_DECODE_PLAIN_STORES 2
+int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
 

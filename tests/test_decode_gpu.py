@@ -81,3 +81,19 @@ def test_falp_every_bit_width_class(ctx, oracle, bw):
     want = oracle.decode_column(enc)
     got = gpu_decode(ctx, enc)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("vectors_per_wg,plain", [(2, 0), (2, 1), (1, 1)])
+def test_tuning_options_do_not_change_results(ctx, oracle, vectors_per_wg, plain):
+    from alp_amd import capi
+    try:
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vectors_per_wg)
+        ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, plain)
+        for name in ("mixed_1pct", "mixed_30pct", "rd_latlon", "adversarial", "one_vector"):
+            col = COLUMNS[name]()
+            enc = oracle.encode_column(col)
+            got = gpu_decode(ctx, enc)
+            assert np.array_equal(got.view(np.uint64), col.view(np.uint64)), (name, vectors_per_wg, plain)
+    finally:
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 1)
+        ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, 0)
