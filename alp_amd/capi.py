@@ -76,6 +76,10 @@ _sig("alpgpu_rowgroup_init_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_vectors_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_column_totals", _int, _vp, C.POINTER(CColumn), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_int))
+_sig("alpgpu_pad_tail_f64", _int, _vp, _vp, _u64)
+_sig("alpgpu_blob_size", _u64, _u64, _u64, _u64)
+_sig("alpgpu_column_to_blob", _int, _vp, C.POINTER(CColumn), _u64, _vp, _u64, C.POINTER(_u64))
+_sig("alpgpu_column_from_blob", _int, _vp, _vp, _u64, C.POINTER(CColumn), C.POINTER(_u64))
 _sig("alpgpu_ffor_i64", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
 _sig("alpgpu_unffor_i64", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
 _sig("alpgpu_ffor_u16", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
@@ -158,6 +162,32 @@ class Context:
         self._check_input(x, col)
         _check(lib.alpgpu_encode_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_encode_f64")
         return col
+
+    # ---- tail padding + serialized container ------------------------------------------------------
+    def pad_tail(self, x, n_values: int):
+        """x: device tensor with room for ceil(n_values/1024)*1024 doubles; fills the incomplete last vector"""
+        assert x.numel() >= (n_values + 1023) // 1024 * 1024
+        _check(lib.alpgpu_pad_tail_f64(self.h, _vp(x.data_ptr()), n_values), "alpgpu_pad_tail_f64")
+
+    def to_blob(self, col: "DeviceColumn", n_values: int) -> np.ndarray:
+        pb, eb, ov = self.column_totals(col)
+        size = int(lib.alpgpu_blob_size(col.n_vectors, pb, eb))
+        blob = np.zeros(size, np.uint8)
+        w = _u64()
+        _check(lib.alpgpu_column_to_blob(self.h, C.byref(col.c), n_values, blob.ctypes.data_as(_vp), size, C.byref(w)), "alpgpu_column_to_blob")
+        assert w.value == size
+        return blob
+
+    def from_blob(self, blob: np.ndarray):
+        """-> (DeviceColumn, n_values); raises AlpGpuError on a malformed blob"""
+        hdr = np.frombuffer(blob[:64].tobytes(), dtype=np.uint64)
+        n_vectors, packed_bytes, exc_bytes = int(hdr[3]), int(hdr[5]), int(hdr[6])
+        if blob.size < 64 or n_vectors > (1 << 40) or packed_bytes > (1 << 50) or exc_bytes > (1 << 50):
+            raise AlpGpuError("blob header is implausible")
+        col = DeviceColumn(n_vectors, self.device, packed_capacity=packed_bytes + 1024, exc_capacity=exc_bytes + 64)
+        nv = _u64()
+        _check(lib.alpgpu_column_from_blob(self.h, blob.ctypes.data_as(_vp), blob.size, C.byref(col.c), C.byref(nv)), "alpgpu_column_from_blob")
+        return col, nv.value
 
     def column_totals(self, col: "DeviceColumn"):
         pb, eb, ov = _u64(), _u64(), _int()

@@ -246,7 +246,8 @@ int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, a
 
 int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
 	ALPGPU_CHECK_CTX(ctx);
-	if (!col || !d_out) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
 	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, ctx->decode_variant, ctx->n_cus);
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
@@ -323,6 +324,115 @@ int alpgpu_rd_decode_vectors_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t*
 	ALPGPU_PRIM(d_out && d_right && d_left && d_states && d_exc && d_pos && d_cnt,
 	            alpgpu::launch_rd_decode(ctx->stream, ctx->n_cus, d_out, d_right, d_left, d_states, d_state_idx, d_exc, d_pos, exc_stride,
 	                                     d_cnt, n_vectors));
+}
+
+// ---- tail padding + blob container ---------------------------------------------------------------------------------
+int alpgpu_pad_tail_f64(alpgpu_ctx* ctx, double* d_in, uint64_t n_values) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in && n_values) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (alpgpu::launch_pad_tail(ctx->stream, d_in, n_values) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "pad launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+
+static uint64_t align8(uint64_t x) { return (x + 7ull) & ~7ull; }
+
+uint64_t alpgpu_blob_size(uint64_t n_vectors, uint64_t packed_bytes, uint64_t exc_bytes) {
+	return sizeof(alpgpu_blob_header) + 32ull * ((n_vectors + 99) / 100) + 32ull * n_vectors + align8(packed_bytes) + align8(exc_bytes);
+}
+
+int alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || !h_blob) { return fail(ALPGPU_ERR_INVALID, "null column or blob"); }
+	if (n_values > col->n_vectors * 1024ull || n_values + 1024ull <= col->n_vectors * 1024ull) {
+		return fail(ALPGPU_ERR_INVALID, "n_values must lie in the column's last vector");
+	}
+	uint64_t t[4] = {0, 0, 0, 0};
+	if (col->n_vectors) {
+		ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	}
+	if (t[2]) { return fail(ALPGPU_ERR_CAPACITY, "the column overflowed its streams; nothing to serialise"); }
+	const uint64_t need = alpgpu_blob_size(col->n_vectors, t[0], t[1]);
+	if (written) { *written = need; }
+	if (capacity < need) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
+	alpgpu_blob_header h;
+	std::memset(&h, 0, sizeof(h));
+	std::memcpy(h.magic, "ALPGPU1", 8);
+	h.version = 1, h.header_bytes = sizeof(h), h.n_values = n_values, h.n_vectors = col->n_vectors, h.n_rowgroups = col->n_rowgroups;
+	h.packed_bytes = t[0], h.exc_bytes = t[1];
+	uint8_t* p = static_cast<uint8_t*>(h_blob);
+	std::memcpy(p, &h, sizeof(h));
+	p += sizeof(h);
+	if (col->n_vectors) {
+		ALPGPU_HIP(hipMemcpyAsync(p, col->d_rowgroups, 32ull * col->n_rowgroups, hipMemcpyDeviceToHost, ctx->stream));
+		p += 32ull * col->n_rowgroups;
+		ALPGPU_HIP(hipMemcpyAsync(p, col->d_vectors, 32ull * col->n_vectors, hipMemcpyDeviceToHost, ctx->stream));
+		p += 32ull * col->n_vectors;
+		if (t[0]) { ALPGPU_HIP(hipMemcpyAsync(p, col->d_packed, t[0], hipMemcpyDeviceToHost, ctx->stream)); }
+		p += align8(t[0]);
+		if (t[1]) { ALPGPU_HIP(hipMemcpyAsync(p, col->d_exc, t[1], hipMemcpyDeviceToHost, ctx->stream)); }
+		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!h_blob || !col) { return fail(ALPGPU_ERR_INVALID, "null blob or column"); }
+	if (size < sizeof(alpgpu_blob_header)) { return fail(ALPGPU_ERR_INVALID, "blob shorter than its header"); }
+	alpgpu_blob_header h;
+	std::memcpy(&h, h_blob, sizeof(h));
+	if (std::memcmp(h.magic, "ALPGPU1", 8) != 0 || h.version != 1 || h.header_bytes != sizeof(h)) { return fail(ALPGPU_ERR_INVALID, "not an ALPGPU v1 blob"); }
+	if (h.n_rowgroups != (h.n_vectors + 99) / 100 || h.n_values > h.n_vectors * 1024ull || (h.n_vectors && h.n_values + 1024ull <= h.n_vectors * 1024ull)) {
+		return fail(ALPGPU_ERR_INVALID, "inconsistent blob header");
+	}
+	if (h.packed_bytes > (1ull << 56) || h.exc_bytes > (1ull << 56) || size < alpgpu_blob_size(h.n_vectors, h.packed_bytes, h.exc_bytes)) {
+		return fail(ALPGPU_ERR_INVALID, "blob truncated");
+	}
+	if (col->n_vectors != h.n_vectors || col->n_rowgroups != h.n_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column was allocated for a different vector count"); }
+	if (col->packed_capacity < h.packed_bytes || col->exc_capacity < h.exc_bytes) { return fail(ALPGPU_ERR_CAPACITY, "column streams too small for the blob"); }
+	const uint8_t* p   = static_cast<const uint8_t*>(h_blob) + sizeof(h);
+	const auto*    rgs = reinterpret_cast<const alpgpu_rowgroup_state*>(p);
+	const auto*    vds = reinterpret_cast<const alpgpu_vector_desc*>(p + 32ull * h.n_rowgroups);
+	// every extent a kernel will dereference is checked here, so a corrupt blob cannot make the decoder read out of bounds
+	for (uint64_t v = 0; v < h.n_vectors; ++v) {
+		alpgpu_vector_desc d;
+		std::memcpy(&d, vds + v, sizeof(d));
+		alpgpu_rowgroup_state rg;
+		std::memcpy(&rg, rgs + v / 100, sizeof(rg));
+		const bool alp = d.scheme == ALPGPU_SCHEME_ALP, rd = d.scheme == ALPGPU_SCHEME_ALP_RD;
+		if ((!alp && !rd) || rg.scheme != d.scheme) { return fail(ALPGPU_ERR_INVALID, "blob: bad scheme in a descriptor"); }
+		const uint64_t psz = 128ull * (d.bw + (rd ? d.lbw : 0));
+		const uint64_t esz = align8((alp ? 10ull : 4ull) * d.exc_cnt);
+		if (d.bw > 64 || d.exc_cnt > 1024 || (alp && (d.e > 18 || d.f > d.e)) || (rd && (d.lbw < 1 || d.lbw > 3 || d.bw > 63 || d.bw != rg.rd_rbw || d.lbw != rg.rd_lbw))) {
+			return fail(ALPGPU_ERR_INVALID, "blob: descriptor field out of range");
+		}
+		if ((d.packed_off & 127ull) || (d.exc_off & 7ull) || d.packed_off > h.packed_bytes || psz > h.packed_bytes - d.packed_off || d.exc_off > h.exc_bytes ||
+		    esz > h.exc_bytes - d.exc_off) {
+			return fail(ALPGPU_ERR_INVALID, "blob: descriptor extent outside its stream");
+		}
+		if (d.exc_cnt) { // positions must be < 1024
+			const uint8_t*  rec = p + 32ull * h.n_rowgroups + 32ull * h.n_vectors + align8(h.packed_bytes) + d.exc_off;
+			const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec + (alp ? 8ull : 2ull) * d.exc_cnt);
+			for (uint32_t j = 0; j < d.exc_cnt; ++j) {
+				uint16_t q;
+				std::memcpy(&q, pos + j, 2);
+				if (q >= 1024) { return fail(ALPGPU_ERR_INVALID, "blob: exception position out of range"); }
+			}
+		}
+	}
+	if (h.n_vectors) {
+		ALPGPU_HIP(hipMemcpyAsync(col->d_rowgroups, rgs, 32ull * h.n_rowgroups, hipMemcpyHostToDevice, ctx->stream));
+		ALPGPU_HIP(hipMemcpyAsync(col->d_vectors, vds, 32ull * h.n_vectors, hipMemcpyHostToDevice, ctx->stream));
+		const uint8_t* ps = p + 32ull * h.n_rowgroups + 32ull * h.n_vectors;
+		if (h.packed_bytes) { ALPGPU_HIP(hipMemcpyAsync(col->d_packed, ps, h.packed_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+		if (h.exc_bytes) { ALPGPU_HIP(hipMemcpyAsync(col->d_exc, ps + align8(h.packed_bytes), h.exc_bytes, hipMemcpyHostToDevice, ctx->stream)); }
+	}
+	const uint64_t t[4] = {h.packed_bytes, h.exc_bytes, 0, 0};
+	ALPGPU_HIP(hipMemcpyAsync(col->d_totals, t, sizeof(t), hipMemcpyHostToDevice, ctx->stream));
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	if (n_values) { *n_values = h.n_values; }
+	return ALPGPU_OK;
 }
 
 int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {

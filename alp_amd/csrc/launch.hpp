@@ -20,6 +20,9 @@ uint64_t encode_workspace_bytes(uint64_t n_vectors);
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus);
 
+// container.hip
+int launch_pad_tail(hipStream_t stream, double* d_in, uint64_t n_values);
+
 // primitive_kernels.hip
 int launch_ffor_i64(hipStream_t stream, int n_cus, const int64_t* in, int64_t* packed, size_t stride, const uint8_t* bw,
                     const int64_t* base, uint64_t n);

@@ -176,6 +176,31 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
 int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes,
                          int* overflow);
 
+/* ---- tail padding and a serialized container ---------------------------------------------
+ * The codec works on whole 1024-value vectors (reference PRIMITIVES.md:141-144 leaves incomplete last vectors to the
+ * caller; its drivers drop them).  alpgpu_pad_tail_f64 fills d_in[n_values .. next multiple of 1024) with the first
+ * value of the incomplete vector; d_in must have room for that many doubles.  Encode ceil(n_values/1024) vectors. */
+int alpgpu_pad_tail_f64(alpgpu_ctx* ctx, double* d_in, uint64_t n_values);
+
+/* Blob = 64-byte header, rowgroup states, vector descriptors, packed stream, exception stream (all little-endian,
+ * exactly the HBM records of this header).  Host memory.  Both calls synchronise the context's stream. */
+typedef struct alpgpu_blob_header {
+	char     magic[8];      /* "ALPGPU1\0" */
+	uint32_t version;       /* 1 */
+	uint32_t header_bytes;  /* 64 */
+	uint64_t n_values;      /* values that are data (<= n_vectors * 1024; the rest is tail padding) */
+	uint64_t n_vectors;
+	uint64_t n_rowgroups;
+	uint64_t packed_bytes;
+	uint64_t exc_bytes;
+	uint64_t reserved;
+} alpgpu_blob_header;
+uint64_t alpgpu_blob_size(uint64_t n_vectors, uint64_t packed_bytes, uint64_t exc_bytes);
+int      alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity,
+                               uint64_t* written);
+/* validates the blob (sizes, every descriptor's extents) and copies it into the caller-allocated column buffers */
+int      alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values);
+
 /* ---- vector primitives on batches (fixed strides; the reference's per-vector API, n at a time) ------
  * Each processes n_vectors independent vectors.  "stride" arguments are in ELEMENTS of the pointed type
  * between consecutive vectors (the reference's callers use 1024-element buffers for everything). */
