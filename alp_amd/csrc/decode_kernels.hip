@@ -46,17 +46,25 @@ struct __attribute__((aligned(16))) DecodeLds {
 	uint64_t excv[kExcStage];
 };
 
-// exclusive prefix over the 32 mask words' popcounts, held by lanes 0..31 of every wavefront
-__device__ __forceinline__ int mask_prefix(const DecodeLds& L, int lane) {
-	const uint32_t w   = L.mask[lane & 31];
-	const int      c   = lane < 32 ? __builtin_popcount(w) : 0;
-	int            inc = c;
-#pragma unroll
-	for (int d = 1; d < 32; d <<= 1) {
-		const int t = __shfl_up(inc, d);
-		if (lane >= d) { inc += t; }
-	}
-	return inc - c;
+// The exception mask (32 words) as seen by one wavefront: lane l < 32 holds word l and the number of exceptions in the
+// words before it.  The prefix is a DPP row scan (register-to-register; a __shfl_up chain would be five dependent trips
+// through the LDS crossbar on the critical path of a latency-bound workgroup), the per-step lookups below are readlanes.
+struct ExcMask {
+	uint32_t word; // mask word (lane & 31)
+	int      excl; // exceptions in words 0 .. (lane & 31) - 1
+};
+__device__ __forceinline__ ExcMask load_exception_mask(const DecodeLds& L, int lane) {
+	ExcMask   m;
+	m.word  = L.mask[lane & 31];
+	const int c = lane < 32 ? __builtin_popcount(m.word) : 0;
+	int       v = c;
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8   -> inclusive scan inside each 16-lane row
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> row 1 += total of row 0 (lanes 0..31 done)
+	m.excl = v - c;
+	return m;
 }
 
 template <int VAL_BYTES>
@@ -69,13 +77,21 @@ __device__ __forceinline__ uint64_t fetch_exception(const DecodeLds& L, const ui
 	}
 }
 
-// exception lookup for the pair (128*m + 2*lane, +1): 2-bit hit mask and the rank of the first hit
-__device__ __forceinline__ uint32_t exception_hits(const DecodeLds& L, int pref_reg, int m, int lane, int& rank) {
-	const int      wi   = 4 * m + (lane >> 4);
-	const uint32_t word = L.mask[wi];
+// exception lookup for the pair (128*m + 2*lane, +1): 2-bit hit mask and the rank of the first hit.  m is wave-uniform.
+__device__ __forceinline__ uint32_t exception_hits(const ExcMask& em, int m, int lane, int& rank) {
+	const int g = lane >> 4; // the pair's mask word is 4m + g
+	uint32_t  word = __builtin_amdgcn_readlane(em.word, 4 * m);
+	int       pref = __builtin_amdgcn_readlane(em.excl, 4 * m);
+#pragma unroll
+	for (int k = 1; k < 4; ++k) {
+		const uint32_t wk = __builtin_amdgcn_readlane(em.word, 4 * m + k);
+		const int      pk = __builtin_amdgcn_readlane(em.excl, 4 * m + k);
+		word              = g == k ? wk : word;
+		pref              = g == k ? pk : pref;
+	}
 	const int      b0   = (2 * lane) & 31;
 	const uint32_t hits = (word >> b0) & 3u;
-	rank                = __shfl(pref_reg, wi) + __builtin_popcount(word & ((1u << b0) - 1u));
+	rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
 	return hits;
 }
 
@@ -98,7 +114,8 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
                                                      const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane) {
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
-	const int      pref_reg = cnt > 0 ? mask_prefix(L, lane) : 0;
+	ExcMask        em {0u, 0};
+	if (cnt > 0) { em = load_exception_mask(L, lane); }
 	const int      a        = lane & 7;
 	const int      r0       = lane >> 3;
 	const UnitsPtr units {reinterpret_cast<const ulonglong2*>(L.stage)};
@@ -107,15 +124,34 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 		const int64_t  fact = kFactArr[d.f];
 		const double   frac = kFracArr[d.e];
 		const uint64_t mask = bw_mask(bw);
+		// Conversion shortcut, decided once per vector from its descriptor.  If every value base + digit of this vector
+		// lies in (-2^51, 2^51) and times 10^f stays inside int64, then
+		//   * (double)value is exact and equals  bitcast(bits(2^52+2^51) + value) - (2^52+2^51)   (one 64-bit add, one f64 add),
+		//   * (double)(int64)(value * 10^f) is the correctly rounded product of two exactly representable doubles,
+		//     i.e. the IEEE product  (double)value * 10^f,
+		// which replaces the 64-bit integer multiply and the software int64->double conversion (src/falp.cpp:114-121 does
+		// them per value) and yields the same bits.  Anything else takes the literal path.
+		const int64_t lo     = d.base;
+		const double  fact_d = kExpArr[d.f];
+		const bool    narrow = bw <= 50 && lo > -(1ll << 51) && lo < (1ll << 51) && lo + static_cast<int64_t>(mask) < (1ll << 51);
+		const double  maxabs = narrow ? __builtin_fmax(__builtin_fabs(static_cast<double>(lo)), __builtin_fabs(static_cast<double>(lo + static_cast<int64_t>(mask)))) : 0.0;
+		const bool    shortcut = narrow && maxabs * fact_d < 9.2233720368547e18;
+		const uint64_t kbits   = 0x4338000000000000ull + base;
 #pragma unroll
 		for (int mm = 0; mm < kStepsPerWave; ++mm) {
-			const int     m  = kStepsPerWave * wave + mm;
-			const U64Pair u  = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
-			double        ox = decode_value(static_cast<int64_t>(u.x + base), fact, frac);
-			double        oy = decode_value(static_cast<int64_t>(u.y + base), fact, frac);
+			const int     m = kStepsPerWave * wave + mm;
+			const U64Pair u = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
+			double        ox, oy;
+			if (shortcut) { // wave-uniform
+				ox = ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac;
+				oy = ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac;
+			} else {
+				ox = decode_value(static_cast<int64_t>(u.x + base), fact, frac);
+				oy = decode_value(static_cast<int64_t>(u.y + base), fact, frac);
+			}
 			if (cnt > 0) {
 				int            rank;
-				const uint32_t hits = exception_hits(L, pref_reg, m, lane, rank);
+				const uint32_t hits = exception_hits(em, m, lane, rank);
 				if (hits & 1u) {
 					ox = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank)));
 					++rank;
@@ -153,7 +189,7 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 			uint64_t       l1  = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
 			if (cnt > 0) {
 				int            rank;
-				const uint32_t hits = exception_hits(L, pref_reg, m, lane, rank);
+				const uint32_t hits = exception_hits(em, m, lane, rank);
 				if (hits & 1u) {
 					l0 = fetch_exception<2>(L, rec, rank);
 					++rank;
@@ -214,7 +250,7 @@ __device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vecto
 
 // V consecutive vectors per workgroup: all of their loads are in flight together, then they are unpacked one after the
 // other by the same 4 wavefronts.  V = 2 doubles the bytes in flight per CU for the same residency (8 workgroups per CU).
-template <int V, bool NT_STORE>
+template <int V, bool NT_STORE, bool SEQ = false>
 __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_vector_desc* __restrict__ descs,
                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                   const uint8_t* __restrict__ packed,
@@ -239,6 +275,20 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	for (int i = 0; i < V; ++i) {
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // the odd tail vector is simply loaded twice
 		d[i]             = descs[v];
+	}
+	if constexpr (SEQ) { // experiment: same grid as V = 2 but one vector in flight at a time
+#pragma unroll
+		for (int i = 0; i < V; ++i) {
+			e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave);
+			land_exceptions(L[i], d[i], excs + d[i].exc_off, e[i], tid);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			if (v0 + i < n_vectors) {
+				decode_staged_vector<NT_STORE>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off,
+				                               reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
+			}
+		}
+		return;
 	}
 #pragma unroll
 	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
@@ -266,7 +316,11 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
-		if (V == 2 && nt) {
+		if (variant & 4) {
+			const uint64_t n2 = (n + 1) / 2;
+			hipLaunchKernelGGL((k_decode_column<2, true, true>), dim3(static_cast<unsigned>(n2)), block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed,
+			                   col->d_exc, d_out, n, off);
+		} else if (V == 2 && nt) {
 			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
 		} else if (V == 2) {
 			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
