@@ -66,7 +66,7 @@ _sig("alpgpu_ctx_destroy", None, _vp)
 _sig("alpgpu_set_stream", _int, _vp, _vp)
 _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
-OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES = 1, 2
+OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS = 1, 2, 3
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
@@ -264,7 +264,7 @@ class DeviceColumn:
         self.vectors = torch.zeros(max(1, self.n_vectors) * 32, dtype=torch.uint8, device=dev)
         self.packed = torch.zeros(pc, dtype=torch.uint8, device=dev)
         self.exc = torch.zeros(ec, dtype=torch.uint8, device=dev)
-        self.totals = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.totals = torch.zeros(8, dtype=torch.int64, device=dev)
         self.c = CColumn(self.n_vectors, self.n_rowgroups, self.rowgroups.data_ptr(), self.vectors.data_ptr(),
                          self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr())
 

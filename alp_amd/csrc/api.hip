@@ -19,7 +19,8 @@ struct alpgpu_ctx {
 	int         decode_variant;
 	char        name[128];
 	uint64_t    hbm_bytes;
-	void*       workspace;       // scan workspace (tile sums), grown on demand
+	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
+	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
 };
 
@@ -82,6 +83,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->n_cus          = prop.multiProcessorCount;
 	ctx->hbm_bytes      = prop.totalGlobalMem;
 	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup (default), bit 1: plain stores
+	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { ctx->decode_variant = std::atoi(v); }
@@ -116,6 +118,9 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
 		if (value != 1 && value != 2) { return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 1 or 2"); }
 		ctx->decode_variant = (ctx->decode_variant & ~1) | (value == 1 ? 1 : 0);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_ENCODE_TWO_PASS:
+		ctx->encode_two_pass = value ? 1 : 0;
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_PLAIN_STORES:
 		ctx->decode_variant = (ctx->decode_variant & ~2) | (value ? 2 : 0);
@@ -182,6 +187,7 @@ static int ensure_workspace(alpgpu_ctx* ctx, uint64_t bytes) {
 	// grows only between launches of different sizes; the old buffer may still be in use by queued work
 	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
 	if (ctx->workspace) { ALPGPU_HIP(hipFree(ctx->workspace)); }
+	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	const uint64_t want  = bytes < (1ull << 20) ? (1ull << 20) : bytes * 2;
@@ -233,9 +239,10 @@ int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
 	if (int rc = ensure_workspace(ctx, alpgpu::encode_workspace_bytes(n_vectors))) { return rc; }
-	if (alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace), ctx->n_cus) != ALPGPU_OK) {
-		return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError());
-	}
+	const int rc = ctx->encode_two_pass
+	                   ? alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace), ctx->n_cus)
+	                   : alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace));
+	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
 
@@ -444,6 +451,7 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* pa
 	if (packed_bytes) { *packed_bytes = t[0]; }
 	if (exc_bytes) { *exc_bytes = t[1]; }
 	if (overflow) { *overflow = static_cast<int>(t[2]); }
+	if (t[3]) { return fail(ALPGPU_ERR_HIP, "single-pass encode stalled in its offset look-back; re-encode with ALPGPU_OPT_ENCODE_TWO_PASS"); }
 	return t[2] ? fail(ALPGPU_ERR_CAPACITY, "an output stream overflowed its capacity") : ALPGPU_OK;
 }
 

@@ -260,6 +260,291 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 	}
 }
 
+// ---- single pass: analysis, ordered offsets (decoupled look-back) and pack in ONE kernel -------------------------------
+// The two-pass form above reads the input twice and does the encode arithmetic twice (the kernels are VALU-bound:
+// profiles/r01_pmc_sq_encode.txt).  Here a workgroup (tile) of kWavesPerWg wavefronts = kWavesPerWg consecutive vectors
+//   1. encodes its vectors (registers -> LDS), knows their sizes,
+//   2. publishes the tile's size as ONE 64-bit status word {flag | packed 128-B units | exception 8-B units},
+//   3. wavefront 0 looks back over the preceding tiles' status words (kLookWindow per round) until it meets a tile that
+//      already knows its inclusive prefix, adds up the aggregates in between, publishes its own inclusive prefix and
+//      hands the tile's exclusive prefix to the other wavefronts through LDS words (no workgroup barrier is involved),
+//   4. every wavefront writes its packed words / exception record / descriptor at the now-known offsets.
+// Offsets are therefore the same vector-order exclusive scan as in the two-pass form: the output is byte-identical.
+// Status words are written with one agent-scope relaxed atomic store (the data IS the flag) and polled with agent-scope
+// relaxed atomic loads (cdna_hip_programming.md §6 G16, recipe R2).  Forward progress needs the predecessor tiles to be
+// resident or finished, which the in-order dispatch of a 1-D grid provides in practice but HIP does not promise:
+// every spin is bounded, and a stall sets totals[3] (reported as ALPGPU_ERR_HIP by alpgpu_column_totals; the two-pass
+// form is selectable with ALPGPU_OPT_ENCODE_TWO_PASS).  The field widths bound one launch to kFusedMaxVectors vectors;
+// longer columns are chained launch by launch through totals[0..1].
+constexpr uint64_t kFusedMaxVectors = 1ull << 20; // 2^20 vectors * 1280 exception units < 2^31
+constexpr uint64_t kFlagAggregate   = 1ull << 62;
+constexpr uint64_t kFlagPrefix      = 2ull << 62;
+constexpr uint32_t kSpinLimit       = 1u << 20;
+#ifndef ALPGPU_LOOK_WINDOW
+#define ALPGPU_LOOK_WINDOW 64
+#endif
+#ifndef ALPGPU_LOOK_SLEEP
+#define ALPGPU_LOOK_SLEEP 64 // x64 cycles between polls of a window that still holds an unfinished tile
+#endif
+constexpr int      kLookWindow      = ALPGPU_LOOK_WINDOW; // status words examined per look-back round
+
+__device__ __forceinline__ uint64_t status_pack(uint64_t flag, uint64_t packed_units, uint64_t exc_units) {
+	return flag | (packed_units << 31) | exc_units;
+}
+
+// The look-back of one tile (run by wavefront 0 after it has posted its own size): finds the tile's exclusive prefix,
+// waits for the tile's aggregate, publishes the inclusive prefix and releases the workgroup through LDS.
+__device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
+                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
+		uint64_t* my_status = status + tile;
+		uint64_t  excl      = 0;
+		bool      stalled   = false;
+#ifdef ALPGPU_FUSED_NO_LOOKBACK // timing experiment only: worst-case strides instead of the scan (output is NOT compact)
+		excl = status_pack(0, tile * kWavesPerWg * 66, tile * kWavesPerWg * 1280);
+		if (false) {
+#else
+		if (tile != 0) {
+#endif
+			int64_t  look  = static_cast<int64_t>(tile) - 1; // nearest tile not yet accounted for
+			uint32_t spins = 0;
+			while (look >= 0) {
+				uint64_t st[kLookWindow / 64];
+#pragma unroll
+				for (int k = 0; k < kLookWindow / 64; ++k) {
+					const int64_t idx = look - (lane + 64 * k);
+					st[k]             = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;
+				}
+				// entries are ordered nearest-first (k major): take everything up to and including the first prefix,
+				// provided nothing before it is still invalid; otherwise poll again
+				bool     done = false, retry = false;
+				uint64_t part = 0;
+#pragma unroll
+				for (int k = 0; k < kLookWindow / 64; ++k) {
+					if (!done && !retry) { // wave-uniform
+						const uint64_t fl         = st[k] >> 62;
+						const uint64_t has_prefix = __ballot(fl == 2);
+						const uint64_t invalid    = __ballot(fl == 0);
+						const int      first_p    = has_prefix ? __builtin_ctzll(has_prefix) : 64;
+						const uint64_t upto       = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull); // lanes 0..first_p
+						if (invalid & upto) {
+							retry = true;
+						} else {
+							part += (first_p == 64 || lane <= first_p) ? (st[k] & ~(3ull << 62)) : 0ull;
+							done = first_p != 64;
+						}
+					}
+				}
+				if (retry) {
+					if (++spins > kSpinLimit || __hip_atomic_load(totals + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+						stalled = true;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
+					continue;
+				}
+#pragma unroll
+				for (int dd = 32; dd >= 1; dd >>= 1) { part += static_cast<uint64_t>(__shfl_xor(static_cast<long long>(part), dd)); }
+				excl += part;
+				if (done) { break; }
+				look -= kLookWindow;
+			}
+		}
+		// the tile's own aggregate: wait (LDS only) until every worker has posted its size
+		uint32_t spins = 0;
+		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kWavesPerWg) {
+			if (++spins > kSpinLimit) {
+				stalled = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+		uint64_t aggregate = 0;
+#pragma unroll
+		for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+		if (lane == 0) {
+			if (stalled) {
+				__hip_atomic_store(totals + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				*s_excl = ~0ull;
+			} else {
+				__hip_atomic_store(my_status, kFlagPrefix | (excl + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				*s_excl = excl;
+				if (tile == gridDim.x - 1) { // running totals of the column, published by k_fused_finish
+					const uint64_t incl = excl + aggregate;
+					totals[4]           = totals[0] + ((incl >> 31) & 0x7FFFFFFFull) * 128ull;
+					totals[5]           = totals[1] + (incl & 0x7FFFFFFFull) * 8ull;
+				}
+			}
+			__hip_atomic_store(s_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+}
+
+__global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double* __restrict__ in,
+                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                   alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
+                                                                   uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
+                                                                   uint64_t* __restrict__ totals, uint64_t packed_capacity,
+                                                                   uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch) {
+	__shared__ EncodeLds lds[kWavesPerWg];
+	__shared__ uint64_t  s_size[kWavesPerWg]; // per vector: (packed units << 31) | exception units
+	__shared__ uint64_t  s_excl;              // tile's exclusive prefix in the same packing, or ~0 on a stall
+	__shared__ uint32_t  s_count;             // worker wavefronts that have posted their size
+	__shared__ uint32_t  s_ready;             // set by the scout once s_excl is valid
+	const int            lane = lane_id();
+	const int            wave = wave_in_wg();
+	const uint64_t       tile = blockIdx.x;
+	if (threadIdx.x == 0) {
+		s_count = 0;
+		s_ready = 0;
+	}
+	__syncthreads(); // the only workgroup barrier: nothing waits on memory here
+
+	// ---- the workers: one vector each -------------------------------------------------------------------------------
+	EncodeLds&     L    = lds[wave];
+	const uint64_t vl   = tile * kWavesPerWg + wave; // vector index inside this launch
+	const bool     live = vl < n_vectors_launch;
+	const uint64_t v    = v_first + vl;
+	// ---- 1. encode into registers / LDS ----
+	VecIn              x;
+	alpgpu_vector_desc d;
+	uint32_t           flags = 0;
+	uint64_t           acc0 = 0, acc1 = 0; // ALP_RD: packed left streams of this lane's two lane64 columns
+	uint64_t           ballots[8][2];
+	int                cnt = 0;
+	d.packed_off = d.exc_off = 0;
+	d.base                   = 0;
+	d.bw = d.e = d.f = d.lbw = 0;
+	d.exc_cnt = d.scheme = 0;
+	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
+	if (live) {
+		x        = load_vector(in, v, lane);
+		d.scheme = rgp->scheme;
+		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
+			int e, f;
+			if (rgp->k > 1) {
+				second_level_select(x, rgp, L, lane, e, f);
+			} else {
+				e = rgp->combos[0];
+				f = rgp->combos[1];
+			}
+			AlpEncoded R;
+			encode_alp_registers(x, e, f, lane, R);
+			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
+			cnt   = R.cnt;
+			flags = R.flags;
+			ulonglong2*    lv   = reinterpret_cast<ulonglong2*>(L.vals);
+			const uint64_t base = static_cast<uint64_t>(R.base);
+#pragma unroll
+			for (int m = 0; m < 8; ++m) {
+				lv[64 * m + lane] = make_ulonglong2(static_cast<uint64_t>(R.enc[m][0]) - base, static_cast<uint64_t>(R.enc[m][1]) - base);
+				ballots[m][0]     = R.ballot[m][0];
+				ballots[m][1]     = R.ballot[m][1];
+			}
+		} else {
+			RdEncoded R;
+			encode_rd_registers(x, *rgp, lane, R);
+			d.bw = rgp->rd_rbw, d.lbw = rgp->rd_lbw;
+			cnt   = R.cnt;
+			flags = R.flags;
+			ulonglong2*    lv    = reinterpret_cast<ulonglong2*>(L.vals);
+			const int      lbw   = d.lbw;
+			const uint64_t lmask = (1ull << lbw) - 1ull;
+#pragma unroll
+			for (int m = 0; m < 8; ++m) {
+				lv[64 * m + lane] = make_ulonglong2(R.right[m][0], R.right[m][1]);
+				ballots[m][0]     = R.ballot[m][0];
+				ballots[m][1]     = R.ballot[m][1];
+				const int row     = 2 * m + (lane >> 5);
+				acc0 |= (static_cast<uint64_t>(R.idx[m][0]) & lmask) << (row * lbw);
+				acc1 |= (static_cast<uint64_t>(R.idx[m][1]) & lmask) << (row * lbw);
+			}
+			acc0 |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(acc0), 32));
+			acc1 |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(acc1), 32));
+		}
+		d.exc_cnt = static_cast<uint16_t>(cnt);
+	}
+	uint64_t my_p = 0, my_e = 0; // bytes
+	if (live) { desc_sizes(d, my_p, my_e); }
+	// post this vector's size; the last worker to arrive publishes the tile's aggregate (so successors never wait for
+	// this tile's own look-back), then everybody waits — on LDS words only — for the scout's exclusive prefix
+	if (lane == 0) {
+		s_size[wave] = status_pack(0, my_p >> 7, my_e >> 3);
+		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (arrived == kWavesPerWg - 1 && tile != 0) {
+			uint64_t aggregate = 0;
+#pragma unroll
+			for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+			// a scout that already finished may have written the prefix word; never overwrite a prefix with an aggregate
+			uint64_t expected = 0;
+			__hip_atomic_compare_exchange_strong(status + tile, &expected, kFlagAggregate | aggregate, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+			                                     __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
+	{
+		uint32_t spins = 0;
+		while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+			if (++spins > 64u * kSpinLimit) { return; }
+			__builtin_amdgcn_s_sleep(2);
+		}
+	}
+	uint64_t local = 0;
+#pragma unroll
+	for (int w = 0; w < kWavesPerWg; ++w) { local += w < wave ? s_size[w] : 0; }
+	const uint64_t excl = s_excl;
+	if (excl == ~0ull) { return; } // stalled: nothing of this tile is written
+
+	// ---- 4. write at the final offsets ----
+	const uint64_t base_p = totals[0], base_e = totals[1]; // bytes used by earlier launches of this column
+	const uint64_t pre    = excl + local;
+	d.packed_off          = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
+	d.exc_off             = base_e + (pre & 0x7FFFFFFFull) * 8ull;
+	if (!live) { return; }
+	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) {
+		if (lane == 0) { __hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		return; // this vector does not fit: report, write nothing past the buffers
+	}
+	uint8_t* dst = packed + d.packed_off;
+	uint8_t* rec = excs + d.exc_off;
+	if (cnt > 0) {
+		const bool alp  = d.scheme == ALPGPU_SCHEME_ALP;
+		const int  rbw  = d.bw;
+		int        soff = 0;
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+				if (flags & (1u << (2 * m + j))) {
+					const int      r    = exception_rank(ballots, flags, m, j, lane, soff);
+					const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
+					const uint16_t pos  = static_cast<uint16_t>(128 * m + 2 * lane + j);
+					if (alp) {
+						reinterpret_cast<uint64_t*>(rec)[r]                    = bits;
+						reinterpret_cast<uint16_t*>(rec + 8ull * cnt)[r] = pos;
+					} else {
+						reinterpret_cast<uint16_t*>(rec)[r]                    = static_cast<uint16_t>(bits >> rbw);
+						reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
+					}
+				}
+			}
+			soff += __builtin_popcountll(ballots[m][0]) + __builtin_popcountll(ballots[m][1]);
+		}
+	}
+	pack_u64_from_lds(L, d.bw, reinterpret_cast<ulonglong2*>(dst), lane);
+	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 32) {
+		uint32_t* out32 = reinterpret_cast<uint32_t*>(dst + 128ull * d.bw);
+		for (int k = 0; k < d.lbw; ++k) {
+			out32[32 * k + lane] = (static_cast<uint32_t>(acc0 >> (16 * k)) & 0xFFFFu) | ((static_cast<uint32_t>(acc1 >> (16 * k)) & 0xFFFFu) << 16);
+		}
+	}
+	if (lane == 0) { descs[v] = d; }
+}
+
+// publishes the running totals after a fused launch (single thread; keeps totals[0..1] stable while the launch runs)
+__global__ void k_fused_finish(uint64_t* __restrict__ totals) {
+	totals[0] = totals[4];
+	totals[1] = totals[5];
+}
+
 // One workgroup per kWavesPerWg consecutive vectors, handed out by the hardware dispatcher in order (the kernels' loops
 // then run once): measured 15-25 % more HBM bandwidth than a persistent grid-stride launch for this access pattern
 // (profiles/r01_membw2_waves_per_vector.txt).  ALPGPU_ENCODE_PERSISTENT=1 restores the capped grid for A/B runs.
@@ -270,12 +555,32 @@ static unsigned grid_for(uint64_t n_vectors, int n_cus, int wgs_per_cu) {
 	return static_cast<unsigned>(need < cap ? (need ? need : 1) : cap);
 }
 
-uint64_t encode_workspace_bytes(uint64_t n_vectors) { return ((n_vectors + kScanTile - 1) / kScanTile) * 16 + 16; }
+uint64_t encode_workspace_bytes(uint64_t n_vectors) {
+	const uint64_t two_pass = ((n_vectors + kScanTile - 1) / kScanTile) * 16 + 16;
+	const uint64_t per_launch = n_vectors < kFusedMaxVectors ? n_vectors : kFusedMaxVectors;
+	const uint64_t fused    = ((per_launch + kWavesPerWg - 1) / kWavesPerWg) * 8 + 64;
+	return two_pass > fused ? two_pass : fused;
+}
+
+int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+	// d_totals: [0] packed bytes, [1] exception bytes, [2] overflow, [3] look-back stall, [4..5] running totals of the launch in flight
+	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+	for (uint64_t first = 0; first < n_vectors; first += kFusedMaxVectors) {
+		const uint64_t n_launch = n_vectors - first < kFusedMaxVectors ? n_vectors - first : kFusedMaxVectors;
+		const uint64_t n_tiles  = (n_launch + kWavesPerWg - 1) / kWavesPerWg;
+		if (hipMemsetAsync(d_workspace, 0, n_tiles * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
+		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
+		                   n_launch);
+		hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, stream, col->d_totals);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
 
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus) {
 	if (n_vectors == 0) {
-		(void)hipMemsetAsync(col->d_totals, 0, 32, stream);
+		(void)hipMemsetAsync(col->d_totals, 0, 64, stream);
 		return ALPGPU_OK;
 	}
 	const uint64_t n_tiles = (n_vectors + kScanTile - 1) / kScanTile;

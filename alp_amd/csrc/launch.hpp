@@ -17,6 +17,7 @@ int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint3
 
 // encode_kernels.hip
 uint64_t encode_workspace_bytes(uint64_t n_vectors);
+int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace);
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus);
 

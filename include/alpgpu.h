@@ -113,7 +113,7 @@ typedef struct alpgpu_column {
 	uint64_t               packed_capacity; /* bytes; worst case n_vectors * 8448 */
 	uint8_t*               d_exc;           /* exception stream, 8-byte aligned */
 	uint64_t               exc_capacity;    /* bytes; worst case n_vectors * 10240 */
-	uint64_t*              d_totals;        /* [4]: packed bytes used, exception bytes used, overflow flag, reserved */
+	uint64_t*              d_totals;        /* [8]: packed bytes used, exception bytes used, overflow flag, encode stall flag, 4 scratch words */
 } alpgpu_column;
 
 /* ---- context / plumbing ------------------------------------------------------------------------- */
@@ -131,6 +131,9 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * or mixed ones.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
 #define ALPGPU_OPT_DECODE_VECTORS_PER_WG 1
 #define ALPGPU_OPT_DECODE_PLAIN_STORES 2
+/* ALPGPU_OPT_ENCODE_TWO_PASS: 1 = analysis pass + scan + pack pass (reads the input twice) instead of the default
+ * single-pass encode whose output offsets come from an in-kernel look-back; both give byte-identical columns. */
+#define ALPGPU_OPT_ENCODE_TWO_PASS 3
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
@@ -162,7 +165,8 @@ int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, u
 /* Vector encode of the whole column given col->d_rowgroups (from alpgpu_rowgroup_init_f64 or supplied by
  * the caller): second-level sampling, encode + exception compaction, analyze_ffor, FFOR pack (ALP);
  * split + dictionary encode + FFOR pack of right/left (ALP_RD).  Single pass over the input; output
- * offsets are assigned in vector order.  Writes d_vectors, d_packed, d_exc, d_totals. */
+ * offsets are assigned in vector order.  Writes d_vectors, d_packed, d_exc, d_totals.  If a stream is too small the
+ * overflow flag is raised, nothing is written past the buffers and the column content is unspecified. */
 int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
 
 /* alpgpu_rowgroup_init_f64 followed by alpgpu_encode_vectors_f64 */

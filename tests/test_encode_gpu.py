@@ -153,3 +153,29 @@ def test_rd_rowgroup_init_matches_reference_decisions(ctx, oracle, name):
     out = ctx.decode(dcol)
     ctx.synchronize()
     assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+
+
+@pytest.mark.parametrize("name", ["mixed_1pct", "drifting_k", "adversarial"])
+def test_two_pass_encode_gives_the_same_column(ctx, oracle, name):
+    """ALPGPU_OPT_ENCODE_TWO_PASS (analysis + scan + pack) and the default single-pass encode are byte-identical"""
+    from alp_amd import capi
+    col_np = COLUMNS[name]()
+    d1, x = gpu_encode(ctx, col_np)
+    try:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 1)
+        d2, _ = gpu_encode(ctx, col_np)
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
+    for a, b in zip(d1.to_host(), d2.to_host()):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_long_column_spans_several_fused_launches_worth_of_tiles(ctx, oracle):
+    """many tiles: the look-back chain across > 1000 workgroups must give the oracle's offsets"""
+    col_np = datagen.mixed_column(6000, seed=77, exc_rate=0.02)
+    want = oracle.encode_column(col_np)
+    dcol, x = gpu_encode(ctx, col_np)
+    rg, vec, packed, exc = dcol.to_host()
+    w_rg, w_vec, w_packed, w_exc = layout.compact(want)
+    assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
+    assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc)
