@@ -290,10 +290,20 @@ def main():
             sweep[str(bw)] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
             del c
         extras["decode_sweep_by_bit_width"] = sweep
-        c, _, ab = build_decode_column(ns, local_rank, seed=8, bw_of_rowgroup=16, exc_per_vec=20)
-        med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
-        extras["decode_bw16_2pct_exceptions"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
-        del c
+        # 2 % exceptions (second run) and the 2-vectors-per-workgroup tuning option, which keeps twice the
+        # bytes in flight: better for narrow widths and for vectors with exceptions, worse for wide ones
+        exc_cases = {}
+        for label, bw_, exc_ in (("bw16_exc0", 16, 0), ("bw16_exc20", 16, 20), ("bw28_exc10", 28, 10), ("bw8_exc0", 8, 0)):
+            c, _, ab = build_decode_column(ns, local_rank, seed=8, bw_of_rowgroup=bw_, exc_per_vec=exc_)
+            row = {}
+            for vpw in (1, 2):
+                ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+                med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+                row[f"vectors_per_wg_{vpw}"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 1)
+            exc_cases[label] = row
+            del c
+        extras["decode_exceptions_and_tuning"] = exc_cases
         # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
         for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
             ne = min(n, 1 << 18)
