@@ -47,7 +47,7 @@ class CColumn(C.Structure):
     _fields_ = [
         ("n_vectors", C.c_uint64), ("n_rowgroups", C.c_uint64), ("d_rowgroups", C.c_void_p), ("d_vectors", C.c_void_p),
         ("d_packed", C.c_void_p), ("packed_capacity", C.c_uint64), ("d_exc", C.c_void_p), ("exc_capacity", C.c_uint64),
-        ("d_totals", C.c_void_p),
+        ("d_totals", C.c_void_p), ("packed_bytes_hint", C.c_uint64), ("exc_bytes_hint", C.c_uint64),
     ]
 
 
@@ -266,7 +266,7 @@ class DeviceColumn:
         self.exc = torch.zeros(ec, dtype=torch.uint8, device=dev)
         self.totals = torch.zeros(8, dtype=torch.int64, device=dev)
         self.c = CColumn(self.n_vectors, self.n_rowgroups, self.rowgroups.data_ptr(), self.vectors.data_ptr(),
-                         self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr())
+                         self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr(), 0, 0)
 
     @classmethod
     def from_host(cls, rowgroups: np.ndarray, vectors: np.ndarray, packed: np.ndarray, exc: np.ndarray, device: int = 0):
@@ -280,6 +280,7 @@ class DeviceColumn:
         col.exc[: exc.size] = torch.from_numpy(exc).to(col.exc.device)
         col.totals[0] = packed.size
         col.totals[1] = exc.size
+        col.c.packed_bytes_hint, col.c.exc_bytes_hint = packed.size, exc.size
         return col
 
     def to_host(self):

@@ -17,6 +17,7 @@ struct alpgpu_ctx {
 	hipStream_t stream;
 	int         n_cus;
 	int         decode_variant;
+	int         decode_auto;     // 1: vectors per decode workgroup chosen from the column's size hints
 	char        name[128];
 	uint64_t    hbm_bytes;
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
@@ -82,11 +83,15 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->stream         = ctx->own_stream;
 	ctx->n_cus          = prop.multiProcessorCount;
 	ctx->hbm_bytes      = prop.totalGlobalMem;
-	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup (default), bit 1: plain stores
+	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup, bit 1: plain stores
+	ctx->decode_auto     = 1;
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
-	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { ctx->decode_variant = std::atoi(v); }
+	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { // A/B runs
+		ctx->decode_variant = std::atoi(v);
+		ctx->decode_auto    = 0;
+	}
 	std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
 	*out_ctx = ctx;
 	return ALPGPU_OK;
@@ -116,8 +121,9 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
 	switch (option) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
-		if (value != 1 && value != 2) { return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 1 or 2"); }
-		ctx->decode_variant = (ctx->decode_variant & ~1) | (value == 1 ? 1 : 0);
+		if (value < 0 || value > 2) { return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1 or 2"); }
+		ctx->decode_auto    = value == 0;
+		ctx->decode_variant = (ctx->decode_variant & ~1) | (value == 2 ? 0 : 1);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_TWO_PASS:
 		ctx->encode_two_pass = value ? 1 : 0;
@@ -256,7 +262,15 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, ctx->decode_variant, ctx->n_cus);
+	int variant = ctx->decode_variant;
+	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
+		const double n        = static_cast<double>(col->n_vectors);
+		const bool   hinted   = col->packed_bytes_hint != 0 || col->exc_bytes_hint != 0;
+		const bool   narrow   = static_cast<double>(col->packed_bytes_hint) <= 20.0 * 128.0 * n;
+		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
+		variant               = (variant & ~1) | ((hinted && (narrow || with_exc)) ? 0 : 1);
+	}
+	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus);
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
@@ -438,11 +452,13 @@ int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 	const uint64_t t[4] = {h.packed_bytes, h.exc_bytes, 0, 0};
 	ALPGPU_HIP(hipMemcpyAsync(col->d_totals, t, sizeof(t), hipMemcpyHostToDevice, ctx->stream));
 	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	col->packed_bytes_hint = h.packed_bytes;
+	col->exc_bytes_hint    = h.exc_bytes;
 	if (n_values) { *n_values = h.n_values; }
 	return ALPGPU_OK;
 }
 
-int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
+int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || !col->d_totals) { return fail(ALPGPU_ERR_INVALID, "null column"); }
 	uint64_t t[4] = {0, 0, 0, 0};
@@ -451,6 +467,8 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* pa
 	if (packed_bytes) { *packed_bytes = t[0]; }
 	if (exc_bytes) { *exc_bytes = t[1]; }
 	if (overflow) { *overflow = static_cast<int>(t[2]); }
+	col->packed_bytes_hint = t[0];
+	col->exc_bytes_hint    = t[1];
 	if (t[3]) { return fail(ALPGPU_ERR_HIP, "single-pass encode stalled in its offset look-back; re-encode with ALPGPU_OPT_ENCODE_TWO_PASS"); }
 	return t[2] ? fail(ALPGPU_ERR_CAPACITY, "an output stream overflowed its capacity") : ALPGPU_OK;
 }

@@ -84,6 +84,7 @@ def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=N
         col.exc[: n_vectors * rec] = torch.from_numpy(np.tile(one, n_vectors)).to(dev)
     col.totals[0] = packed_bytes
     col.totals[1] = n_vectors * rec
+    col.c.packed_bytes_hint, col.c.exc_bytes_hint = packed_bytes, n_vectors * rec  # what alpgpu_column_totals would report
     # algorithmic bytes per launch: read 128*bw + 10*exc + 13, write 8192, per vector
     alg_bytes = int((128 * bw + 10 * exc_per_vec + 13 + 8192).sum())
     return col, vec, alg_bytes
@@ -262,7 +263,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "falp fused decode, synthetic decimal doubles, 1024-value vectors, bit-width sweep 1-53 across rowgroups, "
                                "no exceptions (BASELINE.json configs[1])",
-                   "vectors_per_gpu": n, "decoded_bytes_per_gpu": decoded_bytes, "parallelism": f"{world} independent shards (no collective)"},
+                   "vectors_per_gpu": n, "decoded_bytes_per_gpu": decoded_bytes,
+                   "decode_launch_shape": "auto from the column's size hints (this column: 1 vector per 4-wave workgroup)", "parallelism": f"{world} independent shards (no collective)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "k_decode_column", "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
@@ -300,7 +302,9 @@ def main():
                 ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
                 med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
                 row[f"vectors_per_wg_{vpw}"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
-            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 1)
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+            med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+            row["auto"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
             exc_cases[label] = row
             del c
         extras["decode_exceptions_and_tuning"] = exc_cases

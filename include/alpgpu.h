@@ -114,6 +114,10 @@ typedef struct alpgpu_column {
 	uint8_t*               d_exc;           /* exception stream, 8-byte aligned */
 	uint64_t               exc_capacity;    /* bytes; worst case n_vectors * 10240 */
 	uint64_t*              d_totals;        /* [8]: packed bytes used, exception bytes used, overflow flag, encode stall flag, 4 scratch words */
+	/* host-side hints (0 = unknown): stream sizes as last seen by the host.  Filled by alpgpu_column_totals and
+	 * alpgpu_column_from_blob; decode uses them only to pick its launch shape (ALPGPU_OPT_DECODE_VECTORS_PER_WG = 0 "auto") */
+	uint64_t               packed_bytes_hint;
+	uint64_t               exc_bytes_hint;
 } alpgpu_column;
 
 /* ---- context / plumbing ------------------------------------------------------------------------- */
@@ -126,9 +130,10 @@ int         alpgpu_abi_version(void);
 int         alpgpu_set_stream(alpgpu_ctx* ctx, void* hip_stream);
 int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
-/* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 (default) or 2 consecutive vectors per decode
- * workgroup; 2 keeps twice the bytes in flight and is faster for narrow columns (average bit width <= ~20), 1 for wide
- * or mixed ones.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
+/* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 or 2 consecutive vectors per decode
+ * workgroup, or 0 (default) = choose from the column's size hints: 2 keeps twice the bytes in flight and is faster for
+ * narrow columns (average bit width <= 20) and for columns with exceptions, 1 for wide exception-free ones and when no
+ * hint is present.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
 #define ALPGPU_OPT_DECODE_VECTORS_PER_WG 1
 #define ALPGPU_OPT_DECODE_PLAIN_STORES 2
 /* ALPGPU_OPT_ENCODE_TWO_PASS: 1 = analysis pass + scan + pack pass (reads the input twice) instead of the default
@@ -177,8 +182,7 @@ int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, a
 int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
 
 /* host copy of d_totals after the stream has drained: packed bytes, exception bytes, overflow flag */
-int alpgpu_column_totals(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes,
-                         int* overflow);
+int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow);
 
 /* ---- tail padding and a serialized container ---------------------------------------------
  * The codec works on whole 1024-value vectors (reference PRIMITIVES.md:141-144 leaves incomplete last vectors to the

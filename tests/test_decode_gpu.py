@@ -95,5 +95,5 @@ def test_tuning_options_do_not_change_results(ctx, oracle, vectors_per_wg, plain
             got = gpu_decode(ctx, enc)
             assert np.array_equal(got.view(np.uint64), col.view(np.uint64)), (name, vectors_per_wg, plain)
     finally:
-        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 1)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
         ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, 0)

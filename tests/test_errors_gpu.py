@@ -42,7 +42,7 @@ def test_invalid_arguments_are_rejected(ctx):
     assert lib.alpgpu_encode_f64(ctx.h, C.c_void_p(x.data_ptr()), 11, C.byref(col.c)) == -2, "n_vectors must match the column"
     assert lib.alpgpu_encode_f64(ctx.h, C.c_void_p(0), 10, C.byref(col.c)) == -2
     assert lib.alpgpu_decode_f64(ctx.h, C.byref(col.c), C.c_void_p(0)) == -2
-    assert lib.alpgpu_set_option(ctx.h, 1, 3) == -2 and lib.alpgpu_set_option(ctx.h, 99, 0) == -2
+    assert lib.alpgpu_set_option(ctx.h, 1, 3) == -2 and lib.alpgpu_set_option(ctx.h, 1, -1) == -2 and lib.alpgpu_set_option(ctx.h, 99, 0) == -2
     assert b"" != lib.alpgpu_last_error()
     h = C.c_void_p()
     assert lib.alpgpu_ctx_create(99, C.byref(h)) == -2 and not h.value
