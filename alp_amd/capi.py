@@ -72,6 +72,7 @@ _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
 _sig("alpgpu_use_own_stream", _int, _vp)
 _sig("alpgpu_decode_f64", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_decode_sum_f64", _int, _vp, C.POINTER(CColumn), _vp)
 _sig("alpgpu_rowgroup_init_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_vectors_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
@@ -239,6 +240,14 @@ class Context:
     def rd_decode_vectors(self, out, right, left, states, state_idx, exc, pos, cnt):
         _check(lib.alpgpu_rd_decode_vectors_f64(self.h, self._p(out), self._p(right), self._p(left), self._p(states), self._p(state_idx),
                                                 self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_rd_decode_vectors_f64")
+
+    def decode_sum(self, col: "DeviceColumn", out=None):
+        """per-vector sums of the decoded values without materialising them (alpgpu_decode_sum_f64)"""
+        import torch
+        if out is None:
+            out = torch.empty(col.n_vectors, dtype=torch.float64, device=f"cuda:{self.device}")
+        _check(lib.alpgpu_decode_sum_f64(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_decode_sum_f64")
+        return out
 
     def decode(self, col: "DeviceColumn", out=None):
         import torch

@@ -257,11 +257,7 @@ int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, a
 	return alpgpu_encode_vectors_f64(ctx, d_in, n_vectors, col);
 }
 
-int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
-	ALPGPU_CHECK_CTX(ctx);
-	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
-	if (col->n_vectors == 0) { return ALPGPU_OK; }
-	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	int variant = ctx->decode_variant;
 	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
 		const double n        = static_cast<double>(col->n_vectors);
@@ -270,6 +266,26 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
 		variant               = (variant & ~1) | ((hinted && (narrow || with_exc)) ? 0 : 1);
 	}
+	return variant;
+}
+
+int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	if (alpgpu::launch_decode_sum(ctx->stream, col, d_sums, decode_variant_for(ctx, col)) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	const int variant = decode_variant_for(ctx, col);
 	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus);
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;

@@ -109,9 +109,13 @@ __device__ __forceinline__ void store_pair(double2* __restrict__ p, double x, do
 }
 
 // ---- one vector, after its packed words / exception mask are visible in L --------------------------------------
-template <bool NT_STORE>
+// SUM = false: the decoded pair is stored (dst).  SUM = true: it is added to `acc` instead, x then y, in step order —
+// the fixed order tests/test_decode_sum_gpu.py reproduces on the host (decode fused into its
+// consumer, the shape of publication/source_code/bench_end_to_end/src/benchmarks/alp/queries/q1.cpp:63-104, without the
+// 8 KiB per vector of decoded doubles ever reaching HBM).
+template <bool NT_STORE, bool SUM = false>
 __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
-                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane) {
+                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr) {
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
 	ExcMask        em {0u, 0};
@@ -158,7 +162,12 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 				}
 				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank))); }
 			}
-			store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
+			if constexpr (SUM) {
+				*acc += ox;
+				*acc += oy;
+			} else {
+				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
+			}
 		}
 	} else {
 		// ALP_RD: right parts = u64 lanes (bw = rbw, base 0); left parts = u16 lanes, 64 streams x 16 rows (value i ->
@@ -196,8 +205,14 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 				}
 				if (hits & 2u) { l1 = fetch_exception<2>(L, rec, rank); }
 			}
-			store_pair<NT_STORE>(dst + 64 * m + lane, __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x)),
-			                     __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y)));
+			const double ox = __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x));
+			const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
+			if constexpr (SUM) {
+				*acc += ox;
+				*acc += oy;
+			} else {
+				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
+			}
 		}
 	}
 }
@@ -250,7 +265,7 @@ __device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vecto
 
 // V consecutive vectors per workgroup: all of their loads are in flight together, then they are unpacked one after the
 // other by the same 4 wavefronts.  V = 2 doubles the bytes in flight per CU for the same residency (8 workgroups per CU).
-template <int V, bool NT_STORE, bool SEQ = false>
+template <int V, bool NT_STORE, bool SUM = false>
 __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_vector_desc* __restrict__ descs,
                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                   const uint8_t* __restrict__ packed,
@@ -276,20 +291,6 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // the odd tail vector is simply loaded twice
 		d[i]             = descs[v];
 	}
-	if constexpr (SEQ) { // experiment: same grid as V = 2 but one vector in flight at a time
-#pragma unroll
-		for (int i = 0; i < V; ++i) {
-			e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave);
-			land_exceptions(L[i], d[i], excs + d[i].exc_off, e[i], tid);
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__syncthreads();
-			if (v0 + i < n_vectors) {
-				decode_staged_vector<NT_STORE>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off,
-				                               reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
-			}
-		}
-		return;
-	}
 #pragma unroll
 	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
 #pragma unroll
@@ -297,6 +298,26 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
 	__syncthreads();
 
+	if constexpr (SUM) {
+		// per-vector sums: lane partial (step order) -> wavefront butterfly (xor 32,16,..,1) -> (w0 + w1) + (w2 + w3)
+		__shared__ double s_part[V][kDecWaves];
+#pragma unroll
+		for (int i = 0; i < V; ++i) {
+			double acc = 0.0;
+			if (v0 + i < n_vectors) {
+				decode_staged_vector<NT_STORE, true>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, nullptr, wave, lane, &acc);
+			}
+#pragma unroll
+			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
+			if (lane == 0) { s_part[i][wave] = acc; }
+		}
+		__syncthreads();
+		if (tid < V && v0 + tid < n_vectors) {
+			static_assert(kDecWaves == 4, "the documented summation order is for 4 wavefronts per vector");
+			out[v0 + tid] = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+		}
+		return;
+	}
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {
@@ -316,11 +337,7 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
-		if (variant & 4) {
-			const uint64_t n2 = (n + 1) / 2;
-			hipLaunchKernelGGL((k_decode_column<2, true, true>), dim3(static_cast<unsigned>(n2)), block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed,
-			                   col->d_exc, d_out, n, off);
-		} else if (V == 2 && nt) {
+		if (V == 2 && nt) {
 			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
 		} else if (V == 2) {
 			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
@@ -328,6 +345,22 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
 		} else {
 			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+		}
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int variant) {
+	const uint64_t n        = col->n_vectors;
+	const int      V        = (variant & 1) ? 1 : 2;
+	const uint64_t n_wg     = (n + V - 1) / V;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
+		if (V == 2) {
+			hipLaunchKernelGGL((k_decode_column<2, false, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off);
+		} else {
+			hipLaunchKernelGGL((k_decode_column<1, false, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;

@@ -308,6 +308,14 @@ def main():
             exc_cases[label] = row
             del c
         extras["decode_exceptions_and_tuning"] = exc_cases
+        # decode fused into a SUM consumer: the 8 KiB per vector of decoded doubles never reach HBM
+        sums = torch.empty(n, dtype=torch.float64, device=dev)
+        med, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 2)
+        read_bytes = alg_bytes - n * 8192 + n * 8
+        extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
+                                      "roofline_frac_algorithmic": round(read_bytes / med / 1e6 / HBM_PEAK_GBPS, 4),
+                                      "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector"}
+        del sums
         # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
         for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
             ne = min(n, 1 << 18)

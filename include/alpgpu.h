@@ -24,6 +24,7 @@
  *                              alp::decoder<double>::patch_exceptions include/alp/decoder.hpp:141-149
  *                              unffor::unffor(uint64/uint16)          include/fastlanes/unffor.hpp:7-15
  *                              alp::rd_encoder<double>::decode        include/alp/rd.hpp:152-178
+ *   alpgpu_decode_sum_f64      falp + patch_exceptions fused with a SUM consumer (bench_end_to_end .../queries/q1.cpp:63-104)
  *   alpgpu_ffor_i64 / alpgpu_unffor_i64 / alpgpu_ffor_u16 / alpgpu_unffor_u16
  *                              ffor::ffor / unffor::unffor            include/fastlanes/{ffor,unffor}.hpp:7-15
  *   alpgpu_falp_f64            falp (no exception patching)           include/alp/falp.hpp:10-26
@@ -180,6 +181,14 @@ int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, a
 /* Fused decode of the whole column: ALP vectors = falp (unFFOR + int->double) + patch_exceptions;
  * ALP_RD vectors = unFFOR(right,left) + dictionary glue + patch.  d_out receives n_vectors*1024 doubles. */
 int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
+
+/* Decode fused into a consumer (the SCAN/SUM shape of the reference's end-to-end bench,
+ * publication/source_code/bench_end_to_end/src/benchmarks/alp/queries/q1.cpp:63-104): d_sums[v] = sum of the 1024 decoded
+ * values of vector v, exceptions patched in; the doubles themselves never reach HBM.  Summation order (so that the
+ * result can be reproduced bit for bit): wavefront q of 4 owns values 256q..256q+255; lane L adds its values
+ * 256q+2L, +1, 256q+128+2L, +1 in that order starting from 0; lanes combine by a butterfly (partner L^32, ^16, .., ^1);
+ * the four wavefront sums combine as (w0 + w1) + (w2 + w3). */
+int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 
 /* host copy of d_totals after the stream has drained: packed bytes, exception bytes, overflow flag */
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow);
