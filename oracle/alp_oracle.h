@@ -73,6 +73,36 @@ double alpo_time_falp_column(const int64_t* packed, size_t stride_words, const u
                              const uint8_t* f, const int64_t* base, const uint16_t* exc_cnt, const double* exc,
                              const uint16_t* pos, size_t exc_stride, size_t n_vectors, double* out, int reps);
 
+/* ---- single precision (alp_oracle_f32.c): alp::encoder<float> / decoder<float> / rd_encoder<float>, 32-bit FFOR -- */
+int32_t alpof_cast32(float x);
+int32_t alpof_encode_value(float v, int fac, int exp);
+float   alpof_decode_value(int32_t enc, int fac, int exp);
+int     alpof_count_bits(int32_t max, int32_t min);
+size_t  alpof_first_level_sample(const float* data, size_t data_offset, size_t data_size, float* data_sample);
+void    alpof_find_top_k(const float* smp, alpo_state* st);
+void    alpof_encoder_init(const float* col, size_t off, size_t n, float* sample_arr, alpo_state* st);
+void    alpof_find_best_ef(const alpo_state* st, const float* in, int vector_size, uint8_t* fac, uint8_t* exp);
+void    alpof_encode_simdized(const float* in, float* exc, uint16_t* pos, uint16_t* cnt, int32_t* enc, int fac, int exp);
+void    alpof_encode(const float* in, float* exc, uint16_t* pos, uint16_t* cnt, int32_t* enc, alpo_state* st);
+void    alpof_analyze_ffor(const int32_t* in, uint8_t* bw, int32_t* base);
+void    alpof_ffor_u32(const uint32_t* in, uint32_t* out, int bw, uint32_t base);
+void    alpof_unffor_u32(const uint32_t* in, uint32_t* out, int bw, uint32_t base);
+void    alpof_decode(const int32_t* enc, int fac, int exp, float* out);
+void    alpof_falp(const uint32_t* in, float* out, int bw, uint32_t base, int fac, int exp);
+void    alpof_patch(float* out, const float* exc, const uint16_t* pos, uint16_t cnt);
+void    alpof_rd_init(const float* col, size_t off, size_t n, float* sample_arr, alpo_state* st);
+void    alpof_rd_encode(const float* in, uint16_t* exc, uint16_t* pos, uint16_t* cnt, uint32_t* right, uint16_t* left,
+                        const alpo_state* st);
+void    alpof_rd_decode(float* out, const uint32_t* right, const uint16_t* left, const uint16_t* exc, const uint16_t* pos,
+                        uint16_t cnt, const alpo_state* st);
+/* fixed-stride column layout with 32-bit words: packed [n*1024] int32, packed_left [n*1024] u16, exc [n*1024] float */
+void alpof_encode_column(const float* column, size_t n_vectors, uint8_t* scheme, uint8_t* e, uint8_t* f, uint8_t* bw,
+                         uint8_t* lbw, int64_t* base, uint16_t* exc_cnt, int32_t* packed, uint16_t* packed_left, float* exc,
+                         uint16_t* pos, uint16_t* dict, uint8_t* dict_size, uint8_t* k_out, int* combos_out);
+void alpof_decode_column(size_t n_vectors, const uint8_t* scheme, const uint8_t* e, const uint8_t* f, const uint8_t* bw,
+                         const uint8_t* lbw, const int64_t* base, const uint16_t* exc_cnt, const int32_t* packed,
+                         const uint16_t* packed_left, const float* exc, const uint16_t* pos, const uint16_t* dict, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,3 +222,149 @@ class Reference(_Base):
         s = np.zeros(1, np.uint64)
         t = self.fn("time_encode_column", C.c_double)(_p(col), C.c_size_t(n), _p(scratch), C.c_int(reps), _p(s))
         return t, int(s[0])
+
+
+# ===================================================================================================
+# single precision: alp_oracle_f32.c (prefix alpof_) and the reference's float instantiation (reff_)
+# ===================================================================================================
+def _encode_column_f32(fn, col: np.ndarray) -> dict:
+    col = np.ascontiguousarray(col, dtype=np.float32)
+    assert col.size % VECTOR_SIZE == 0
+    n = col.size // VECTOR_SIZE
+    nrg = (n + ROWGROUP_VECTORS - 1) // ROWGROUP_VECTORS
+    o = dict(
+        scheme=np.zeros(n, np.uint8), e=np.zeros(n, np.uint8), f=np.zeros(n, np.uint8), bw=np.zeros(n, np.uint8),
+        lbw=np.zeros(n, np.uint8), base=np.zeros(n, np.int64), exc_cnt=np.zeros(n, np.uint16),
+        packed=np.zeros((n, 1024), np.int32), packed_left=np.zeros((n, 1024), np.uint16),
+        exc=np.zeros((n, 1024), np.float32), pos=np.zeros((n, 1024), np.uint16),
+        dict=np.zeros((nrg, 8), np.uint16), dict_size=np.zeros(nrg, np.uint8), k=np.zeros(nrg, np.uint8),
+        combos=np.zeros((nrg, 10), np.int32),
+    )
+    fn(_p(col), C.c_size_t(n), _p(o["scheme"]), _p(o["e"]), _p(o["f"]), _p(o["bw"]), _p(o["lbw"]), _p(o["base"]),
+       _p(o["exc_cnt"]), _p(o["packed"]), _p(o["packed_left"]), _p(o["exc"]), _p(o["pos"]), _p(o["dict"]),
+       _p(o["dict_size"]), _p(o["k"]), _p(o["combos"]))
+    return o
+
+
+class OracleF32(_Base):
+    """Plain-C restatement of the float path (oracle/alp_oracle_f32.c)."""
+    prefix = "alpof_"
+
+    def __init__(self, path: str = ORACLE_SO):
+        if not os.path.exists(path):
+            build(ref=False)
+        super().__init__(path)
+
+    def encode_column(self, col):
+        return _encode_column_f32(self.fn("encode_column"), col)
+
+    def decode_column(self, o: dict) -> np.ndarray:
+        n = o["scheme"].size
+        out = np.empty(n * VECTOR_SIZE, np.float32)
+        self.fn("decode_column")(
+            C.c_size_t(n), _p(o["scheme"]), _p(o["e"]), _p(o["f"]), _p(o["bw"]), _p(o["lbw"]), _p(o["base"]),
+            _p(o["exc_cnt"]), _p(o["packed"]), _p(o["packed_left"]), _p(o["exc"]), _p(o["pos"]), _p(o["dict"]), _p(out))
+        return out
+
+    def ffor_u32(self, vals, bw, base=0):
+        vals = np.ascontiguousarray(vals).view(np.uint32)
+        out = np.zeros(1024, np.uint32)
+        self.fn("ffor_u32")(_p(vals), _p(out), C.c_int(bw), C.c_uint32(base & 0xFFFFFFFF))
+        return out
+
+    def unffor_u32(self, packed, bw, base=0):
+        packed = np.ascontiguousarray(packed).view(np.uint32)
+        out = np.zeros(1024, np.uint32)
+        self.fn("unffor_u32")(_p(packed), _p(out), C.c_int(bw), C.c_uint32(base & 0xFFFFFFFF))
+        return out
+
+    def falp(self, packed, bw, base, fac, exp):
+        packed = np.ascontiguousarray(packed).view(np.uint32)
+        out = np.zeros(1024, np.float32)
+        self.fn("falp")(_p(packed), _p(out), C.c_int(bw), C.c_uint32(base & 0xFFFFFFFF), C.c_int(fac), C.c_int(exp))
+        return out
+
+    def encode_simdized(self, vec, fac, exp):
+        vec = np.ascontiguousarray(vec, np.float32)
+        exc, pos, cnt, enc = np.zeros(1024, np.float32), np.zeros(1024, np.uint16), np.zeros(1, np.uint16), np.zeros(1024, np.int32)
+        self.fn("encode_simdized")(_p(vec), _p(exc), _p(pos), _p(cnt), _p(enc), C.c_int(fac), C.c_int(exp))
+        return enc, exc, pos, int(cnt[0])
+
+    def analyze_ffor(self, enc):
+        enc = np.ascontiguousarray(enc, np.int32)
+        bw, base = np.zeros(1, np.uint8), np.zeros(1, np.int32)
+        self.fn("analyze_ffor")(_p(enc), _p(bw), _p(base))
+        return int(bw[0]), int(base[0])
+
+    def encode_value(self, v, fac, exp):
+        return self.fn("encode_value", C.c_int32)(C.c_float(v), C.c_int(fac), C.c_int(exp))
+
+    def decode_value(self, enc, fac, exp):
+        return self.fn("decode_value", C.c_float)(C.c_int32(enc), C.c_int(fac), C.c_int(exp))
+
+
+class ReferenceF32(_Base):
+    """The real reference's float instantiation (ref_harness.cpp, reff_*)."""
+    prefix = "reff_"
+
+    def __init__(self, path: str = REF_SO):
+        super().__init__(path)
+
+    @staticmethod
+    def available(path: str = REF_SO) -> bool:
+        if not os.path.exists(path):
+            return False
+        try:
+            getattr(C.CDLL(path), "reff_encode_column")
+            return True
+        except AttributeError:
+            return False
+
+    def encode_column(self, col):
+        return _encode_column_f32(self.fn("encode_column"), col)
+
+    def ffor_u32(self, vals, bw, base=0):
+        vals = np.ascontiguousarray(vals).view(np.uint32)
+        out = np.zeros(1024, np.uint32)
+        b = np.array([base & 0xFFFFFFFF], np.uint32)
+        self.fn("ffor_u32")(_p(vals), _p(out), C.c_uint8(bw), _p(b))
+        return out
+
+    def unffor_u32(self, packed, bw, base=0):
+        packed = np.ascontiguousarray(packed).view(np.uint32)
+        out = np.zeros(1024, np.uint32)
+        b = np.array([base & 0xFFFFFFFF], np.uint32)
+        self.fn("unffor_u32")(_p(packed), _p(out), C.c_uint8(bw), _p(b))
+        return out
+
+    def falp(self, packed, bw, base, fac, exp):
+        packed = np.ascontiguousarray(packed).view(np.int32)
+        out = np.zeros(1024, np.float32)
+        b = np.array([base & 0xFFFFFFFF], np.uint32).view(np.int32)
+        self.fn("falp")(_p(packed), _p(out), C.c_uint8(bw), _p(b), C.c_uint8(fac), C.c_uint8(exp))
+        return out
+
+    def unffor_decode(self, packed, bw, base, fac, exp):
+        packed = np.ascontiguousarray(packed).view(np.int32)
+        out = np.zeros(1024, np.float32)
+        b = np.array([base & 0xFFFFFFFF], np.uint32).view(np.int32)
+        self.fn("unffor_decode")(_p(packed), _p(out), C.c_uint8(bw), _p(b), C.c_uint8(fac), C.c_uint8(exp))
+        return out
+
+    def encode_simdized(self, vec, fac, exp):
+        vec = np.ascontiguousarray(vec, np.float32)
+        exc, pos, cnt, enc = np.zeros(1024, np.float32), np.zeros(1024, np.uint16), np.zeros(1, np.uint16), np.zeros(1024, np.int32)
+        self.fn("encode_simdized")(_p(vec), _p(exc), _p(pos), _p(cnt), _p(enc), C.c_uint8(fac), C.c_uint8(exp))
+        return enc, exc, pos, int(cnt[0])
+
+    def analyze_ffor(self, enc):
+        enc = np.ascontiguousarray(enc, np.int32)
+        bw, base = np.zeros(1, np.uint8), np.zeros(1, np.int32)
+        self.fn("analyze_ffor")(_p(enc), _p(bw), _p(base))
+        return int(bw[0]), int(base[0])
+
+    def encode_value(self, v, fac, exp):
+        return self.fn("encode_value", C.c_int32)(C.c_float(v), C.c_uint8(fac), C.c_uint8(exp))
+
+    def decode_value(self, enc, fac, exp):
+        return self.fn("decode_value", C.c_float)(C.c_int32(enc), C.c_uint8(fac), C.c_uint8(exp))

@@ -280,3 +280,85 @@ double ref_time_encode_column(const double* column, size_t n_vectors, int64_t* p
 }
 
 } // extern "C"
+
+// =====================================================================================================================
+// float (32-bit) path of the reference — same shim, second instantiation.
+//   alp::encoder<float>::{init,encode,encode_simdized,analyze_ffor}, alp::decoder<float>::{decode,patch_exceptions},
+//   alp::rd_encoder<float>::{init,encode,decode}, ffor/unffor (int32/uint32), falp (float): include/alp/falp.hpp:28-44
+// =====================================================================================================================
+using fstate = alp::state<float>;
+
+extern "C" {
+
+void reff_ffor_u32(const uint32_t* in, uint32_t* out, uint8_t bw, const uint32_t* base) { ffor::ffor(in, out, bw, base); }
+void reff_unffor_u32(const uint32_t* in, uint32_t* out, uint8_t bw, const uint32_t* base) { unffor::unffor(in, out, bw, base); }
+void reff_falp(const int32_t* in, float* out, uint8_t bw, const int32_t* base, uint8_t fac, uint8_t exp) {
+	generated::falp::fallback::scalar::falp(in, out, bw, base, fac, exp);
+}
+void reff_unffor_decode(const int32_t* in, float* out, uint8_t bw, const int32_t* base, uint8_t fac, uint8_t exp) {
+	int32_t tmp[1024];
+	unffor::unffor(in, tmp, bw, base);
+	alp::decoder<float>::decode(tmp, fac, exp, out);
+}
+void reff_encode_simdized(const float* in, float* exc, uint16_t* pos, uint16_t* cnt, int32_t* enc, uint8_t fac, uint8_t exp) {
+	alp::encoder<float>::encode_simdized(in, exc, pos, cnt, enc, fac, exp);
+}
+void reff_analyze_ffor(const int32_t* in, uint8_t* bw, int32_t* base) {
+	alp::bw_t b = 0;
+	alp::encoder<float>::analyze_ffor(in, b, base);
+	*bw = b;
+}
+float reff_decode_value(int32_t enc, uint8_t fac, uint8_t exp) { return alp::decoder<float>::decode_value(enc, fac, exp); }
+int32_t reff_encode_value(float v, uint8_t fac, uint8_t exp) { return alp::encoder<float>::encode_value<true>(v, fac, exp); }
+
+// whole-column driver, float: same contract as ref_encode_column with 32-bit words
+// (packed: [n*1024] int32, base: int32 widened to int64, exc: [n*1024] float, RD exceptions as u16 in the low bytes of exc)
+void reff_encode_column(const float* column, size_t n_vectors, uint8_t* scheme, uint8_t* e, uint8_t* f, uint8_t* bw, uint8_t* lbw,
+                        int64_t* base, uint16_t* exc_cnt, int32_t* packed, uint16_t* packed_left, float* exc, uint16_t* pos,
+                        uint16_t* dict, uint8_t* dict_size, uint8_t* k_out, int* combos_out) {
+	const size_t          n_values = n_vectors * 1024;
+	fstate                stt;
+	std::vector<float>    sample(1024);
+	std::vector<int32_t>  enc(1024);
+	std::vector<uint32_t> right(1024);
+	std::vector<uint16_t> left(1024);
+	std::vector<uint16_t> rd_exc(1024);
+	for (size_t v = 0; v < n_vectors; ++v) {
+		const size_t rg = v / 100;
+		if (v % 100 == 0) {
+			stt = fstate();
+			alp::encoder<float>::init(column, rg * 102400, n_values, sample.data(), stt);
+			if (stt.scheme == alp::Scheme::ALP_RD) { alp::rd_encoder<float>::init(column, rg * 102400, n_values, sample.data(), stt); }
+			std::memcpy(dict + rg * 8, stt.left_parts_dict, 16);
+			dict_size[rg] = stt.scheme == alp::Scheme::ALP_RD ? stt.actual_dictionary_size : 0;
+			k_out[rg]     = stt.scheme == alp::Scheme::ALP ? static_cast<uint8_t>(stt.k_combinations) : 0;
+			for (int i = 0; i < 5; ++i) {
+				const bool have = stt.scheme == alp::Scheme::ALP && i < static_cast<int>(stt.best_k_combinations.size());
+				combos_out[rg * 10 + 2 * i]     = have ? stt.best_k_combinations[i].first : -1;
+				combos_out[rg * 10 + 2 * i + 1] = have ? stt.best_k_combinations[i].second : -1;
+			}
+		}
+		const float* in = column + v * 1024;
+		scheme[v]       = static_cast<uint8_t>(stt.scheme);
+		uint16_t cnt    = 0;
+		if (stt.scheme == alp::Scheme::ALP) {
+			alp::encoder<float>::encode(in, exc + v * 1024, pos + v * 1024, &cnt, enc.data(), stt);
+			alp::bw_t b  = 0;
+			int32_t   bs = 0;
+			alp::encoder<float>::analyze_ffor(enc.data(), b, &bs);
+			std::memset(packed + v * 1024, 0, 4096);
+			ffor::ffor(enc.data(), packed + v * 1024, b, &bs);
+			e[v] = stt.exp, f[v] = stt.fac, bw[v] = b, lbw[v] = 0, base[v] = bs, exc_cnt[v] = cnt;
+		} else {
+			alp::rd_encoder<float>::encode(in, rd_exc.data(), pos + v * 1024, &cnt, right.data(), left.data(), stt);
+			std::memset(packed + v * 1024, 0, 4096);
+			std::memset(packed_left + v * 1024, 0, 2048);
+			ffor::ffor(right.data(), reinterpret_cast<uint32_t*>(packed + v * 1024), stt.right_bit_width, &stt.right_for_base);
+			ffor::ffor(left.data(), packed_left + v * 1024, stt.left_bit_width, &stt.left_for_base);
+			std::memcpy(exc + v * 1024, rd_exc.data(), cnt * 2);
+			e[v] = 0, f[v] = 0, bw[v] = stt.right_bit_width, lbw[v] = stt.left_bit_width, base[v] = 0, exc_cnt[v] = cnt;
+		}
+	}
+}
+
+} // extern "C"

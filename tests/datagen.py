@@ -62,3 +62,65 @@ def adversarial_vectors():
     a = base.copy(); a[7] = 2.0**63; a[8] = -2.0**63; a[9] = 1e300; a[10] = 5e-324; cases["huge_tiny"] = a
     a = base.copy(); a[100:200] = np.random.default_rng(4).random(100); cases["exception_block"] = a
     return cases
+
+
+# ---- single precision --------------------------------------------------------------------
+def decimal_column_f32(n_vectors, decimals=2, lo=0.0, hi=1000.0, seed=42):
+    rng = np.random.default_rng(seed)
+    return np.round(rng.uniform(lo, hi, n_vectors * VEC), decimals).astype(np.float32)
+
+
+def mixed_column_f32(n_vectors, seed=42, exc_rate=0.01, special_rate=0.001, decimals_per_rowgroup=(1, 2, 3)):
+    rng = np.random.default_rng(seed)
+    n = n_vectors * VEC
+    x = rng.uniform(-1000.0, 1000.0, n)
+    out = np.empty(n, np.float32)
+    for r in range((n_vectors + 99) // 100):
+        s = slice(r * 100 * VEC, min(n, (r + 1) * 100 * VEC))
+        out[s] = np.round(x[s], decimals_per_rowgroup[r % len(decimals_per_rowgroup)]).astype(np.float32)
+    m = rng.random(n) < exc_rate
+    out[m] = (x[m] * np.pi).astype(np.float32)
+    sp = rng.random(n) < special_rate
+    specials = np.array([np.nan, np.inf, -np.inf, -0.0], np.float32)
+    out[sp] = specials[rng.integers(0, 4, int(sp.sum()))]
+    return out
+
+
+def rd_column_f32(n_vectors, seed=42, kind="unit"):
+    rng = np.random.default_rng(seed)
+    n = n_vectors * VEC
+    if kind == "unit":
+        return rng.random(n, dtype=np.float32)
+    return rng.uniform(-90.0, 90.0, n).astype(np.float32)
+
+
+def drifting_column_f32(n_vectors, seed=7):
+    rng = np.random.default_rng(seed)
+    n = n_vectors * VEC
+    x = rng.uniform(0, 100, n)
+    out = np.empty(n, np.float32)
+    for v in range(n_vectors):
+        d = (1, 3, 4, 2)[(v // 7) % 4]
+        out[v * VEC:(v + 1) * VEC] = np.round(x[v * VEC:(v + 1) * VEC], d).astype(np.float32)
+    return out
+
+
+def adversarial_vectors_f32():
+    base = np.round(np.random.default_rng(3).uniform(0, 100, VEC), 2).astype(np.float32)
+    cases = {}
+    cases["plain"] = base.copy()
+    a = base.copy(); a[:] = (np.pi * (np.arange(VEC) + 1)).astype(np.float32); cases["all_exceptions"] = a
+    a = base.copy(); a[:1023] = (np.e * (np.arange(1023) + 1)).astype(np.float32); cases["exceptions_0_to_1022"] = a
+    a = base.copy(); a[:5] = np.nan; cases["prefix_nan"] = a
+    a = base.copy(); a[1023] = np.inf; a[0] = -np.inf; cases["inf_ends"] = a
+    a = base.copy(); a[::2] = -0.0; cases["half_negzero"] = a
+    cases["all_zero"] = np.zeros(VEC, np.float32)
+    cases["constant"] = np.full(VEC, 10.23, np.float32)
+    a = base.copy(); a[7] = 2.0**31; a[8] = -2.0**31; a[9] = 1e30; a[10] = 1e-45; a[11] = 2.0**63; a[12] = -2.0**63
+    a[13] = 2147483520.0; a[14] = -2147483904.0; a[15] = 1.1754942e-38; a[16] = 16777216.0; a[17] = 8388609.0; a[18] = 4194303.5
+    cases["huge_tiny"] = a
+    a = base.copy(); a[100:200] = np.random.default_rng(4).random(100, dtype=np.float32); cases["exception_block"] = a
+    a = np.random.default_rng(5).integers(-2**31, 2**31, VEC).astype(np.float32); cases["big_integers"] = a
+    a = (np.random.default_rng(6).integers(-2**24, 2**24, VEC)).astype(np.float32); cases["exact_integers"] = a
+    a = np.random.default_rng(7).integers(0, 1 << 23, VEC).astype(np.uint32).view(np.float32).copy(); cases["denormals"] = a
+    return cases

@@ -29,7 +29,7 @@ def rowgroup_samples():
     return cases
 
 
-def assert_same_encoding(a, b, what=""):
+def assert_same_encoding(a, b, what="", word=np.uint64):
     """bit-exact comparison of two fixed-stride encode outputs (only the used prefix of exception arrays)"""
     n = a["scheme"].size
     for k in ("scheme", "e", "f", "bw", "lbw", "base", "exc_cnt", "packed", "packed_left", "dict", "dict_size", "k", "combos"):
@@ -38,7 +38,7 @@ def assert_same_encoding(a, b, what=""):
         c = int(a["exc_cnt"][v])
         assert np.array_equal(a["pos"][v, :c], b["pos"][v, :c]), f"{what}: exception positions differ in vector {v}"
         if a["scheme"][v] == 2:
-            x, y = a["exc"][v].view(np.uint64)[:c], b["exc"][v].view(np.uint64)[:c]
+            x, y = a["exc"][v].view(word)[:c], b["exc"][v].view(word)[:c]
         else:
             x, y = a["exc"][v].view(np.uint16)[:c], b["exc"][v].view(np.uint16)[:c]
         assert np.array_equal(x, y), f"{what}: exception values differ in vector {v}"
