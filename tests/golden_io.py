@@ -29,6 +29,17 @@ def rowgroup_samples():
     return cases
 
 
+def float_vectors():
+    """[(name, float32 column, reference outputs, (known bit width, known exception count) or -1)]"""
+    z = np.load(os.path.join(GOLDEN, "float_vectors.npz"))
+    cases = []
+    for nm in [str(x) for x in z["names"]]:
+        o = {k: z[f"{nm}__{k}"] for k in KEYS}
+        o["exc"] = z[f"{nm}__exc"].view(np.float32)
+        cases.append((nm, z[f"{nm}__input_bits"].view(np.float32), o, z[f"{nm}__known_bw_exc"]))
+    return cases
+
+
 def assert_same_encoding(a, b, what="", word=np.uint64):
     """bit-exact comparison of two fixed-stride encode outputs (only the used prefix of exception arrays)"""
     n = a["scheme"].size

@@ -34,3 +34,23 @@ def test_known_multi_vector_statistics():
             "gov26_tw": (35, 818), "nyc29_tw": (5096, 1044)}
     for name, _, gold in RG:
         assert (int(gold["bw"].sum()), int(gold["exc_cnt"].sum())) == want[name]
+
+
+# ---- single precision -------------------------------------------------------------------------------------------
+FLOATS = golden_io.float_vectors()
+
+
+@pytest.mark.parametrize("name,col,gold,known", FLOATS, ids=[c[0] for c in FLOATS])
+def test_float_column_matches_reference(name, col, gold, known):
+    """oracle/alp_oracle_f32.c against the reference's float outputs; the first five are the reference's own float
+    test columns with the bit widths / exception count its unit test asserts (data/include/float/test.hpp:10-14,
+    float/edge_case.hpp:10)"""
+    from oracle.pyoracle import OracleF32
+    o = OracleF32()
+    got = o.encode_column(col)
+    golden_io.assert_same_encoding(got, gold, name, word=np.uint32)
+    if known[0] >= 0:
+        assert got["scheme"][0] == 2 and int(got["bw"][0]) == int(known[0])
+    if known[1] >= 0:
+        assert int(got["exc_cnt"][0]) == int(known[1])
+    assert np.array_equal(o.decode_column(got).view(np.uint32), col.view(np.uint32))

@@ -21,7 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle.pyoracle import Reference  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle.pyoracle import Reference, ReferenceF32  # noqa: E402
+import datagen  # noqa: E402
 
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -99,8 +101,45 @@ def main():
             rg[key + "__" + k] = v.view(np.uint64) if v.dtype == np.float64 else v
         print(key, "sum bw", int(o["bw"].sum()), "sum exc", int(o["exc_cnt"].sum()), "k", o["k"].tolist())
     np.savez_compressed(os.path.join(OUT, "rowgroup_samples.npz"), **rg)
+    float_fixtures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+# the reference's float test columns and the answers its unit test asserts: data/include/float/test.hpp:10-14
+# (bit widths), data/include/float/edge_case.hpp:10 (exceptions 192, bit width 0); read the way
+# test/test_alp_sample.cpp:118-134 does (std::stof per token; avx512dq.csv has 1023 values, the rest of the buffer is 0)
+FLOAT_KNOWN = {"float/test_0.csv": (4, -1), "float/test_1.csv": (10, -1), "float/test_2.csv": (17, -1),
+               "float/test_3.csv": (0, -1), "edge_case/avx512dq.csv": (0, 192)}
+
+
+def float_fixtures():
+    R = ReferenceF32()
+    z = {}
+    names = []
+    for rel, known in FLOAT_KNOWN.items():
+        vals = [np.float32(t.rstrip(",")) for t in open(f"{REF}/data/{rel}").read().split()][:1024]
+        col = np.array(vals + [0.0] * (1024 - len(vals)), np.float32)
+        key = rel.replace("/", "_").replace(".csv", "")
+        names.append(key)
+        z[key + "__known_bw_exc"] = np.array(known, np.int32)
+        z[key + "__input_bits"] = col.view(np.uint32)
+        for k, v in R.encode_column(col).items():
+            z[key + "__" + k] = v.view(np.uint32) if v.dtype == np.float32 else v
+    synth = {"mixed_1pct": datagen.mixed_column_f32(120, seed=3, exc_rate=0.01),
+             "rd_unit": datagen.rd_column_f32(110, seed=5, kind="unit"),
+             "drifting_k": datagen.drifting_column_f32(110, seed=7),
+             "adversarial": np.concatenate(list(datagen.adversarial_vectors_f32().values()))}
+    for key, col in synth.items():
+        names.append(key)
+        z[key + "__known_bw_exc"] = np.array((-1, -1), np.int32)
+        z[key + "__input_bits"] = col.view(np.uint32)
+        o = R.encode_column(col)
+        for k, v in o.items():
+            z[key + "__" + k] = v.view(np.uint32) if v.dtype == np.float32 else v
+        print("float", key, "schemes", np.unique(o["scheme"]).tolist(), "sum bw", int(o["bw"].sum()), "sum exc", int(o["exc_cnt"].sum()))
+    z["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "float_vectors.npz"), **z)
 
 
 if __name__ == "__main__":
