@@ -93,6 +93,30 @@ _sig("alpgpu_encode_values_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _
 _sig("alpgpu_analyze_ffor_i64", _int, _vp, _vp, _vp, _vp, _u64)
 _sig("alpgpu_rd_encode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
 _sig("alpgpu_rd_decode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
+# single precision (same argument shapes; 32-bit words)
+_sig("alpgpu_packed_capacity_f32", _u64, _u64)
+_sig("alpgpu_exc_capacity_f32", _u64, _u64)
+_sig("alpgpu_decode_f32", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_rowgroup_init_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn))
+_sig("alpgpu_encode_vectors_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn))
+_sig("alpgpu_encode_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn))
+_sig("alpgpu_state_from_samples_f32", _int, _vp, _vp, C.c_uint32, _vp)
+_sig("alpgpu_rd_state_from_samples_f32", _int, _vp, _vp, C.c_uint32, _vp)
+_sig("alpgpu_state_from_samples_f64", _int, _vp, _vp, C.c_uint32, _vp)
+_sig("alpgpu_rd_state_from_samples_f64", _int, _vp, _vp, C.c_uint32, _vp)
+_sig("alpgpu_pad_tail_f32", _int, _vp, _vp, _u64)
+_sig("alpgpu_column_to_blob_f32", _int, _vp, C.POINTER(CColumn), _u64, _vp, _u64, C.POINTER(_u64))
+_sig("alpgpu_column_from_blob_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn), C.POINTER(_u64))
+_sig("alpgpu_ffor_i32", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
+_sig("alpgpu_unffor_i32", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
+_sig("alpgpu_falp_f32", _int, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_decode_values_f32", _int, _vp, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_patch_f32", _int, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
+_sig("alpgpu_encode_simdized_f32", _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_encode_values_f32", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_analyze_ffor_i32", _int, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_rd_encode_vectors_f32", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
+_sig("alpgpu_rd_decode_vectors_f32", _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
 
 
 class AlpGpuError(RuntimeError):
@@ -143,39 +167,56 @@ class Context:
         return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": hbm.value}
 
     # ---- whole-column path ------------------------------------------------------------------------
-    def _check_input(self, x, col):
+    # Every whole-column call dispatches on the value type: float64 tensors / DeviceColumn(dtype="f64") -> *_f64 entry
+    # points, float32 / "f32" -> *_f32.
+    @staticmethod
+    def _sfx(x):
         import torch
-        assert x.dtype == torch.float64 and x.is_contiguous() and x.is_cuda
-        assert x.numel() == col.n_vectors * VECTOR_SIZE, "input must hold exactly n_vectors * 1024 doubles"
+        assert x.dtype in (torch.float64, torch.float32)
+        return "f64" if x.dtype == torch.float64 else "f32"
+
+    def _check_input(self, x, col):
+        assert x.is_contiguous() and x.is_cuda and self._sfx(x) == col.dtype, "input tensor and column must have the same value type"
+        assert x.numel() == col.n_vectors * VECTOR_SIZE, "input must hold exactly n_vectors * 1024 values"
+
+    def _call(self, stem, sfx, *args):
+        name = f"alpgpu_{stem}_{sfx}"
+        _check(getattr(lib, name)(self.h, *args), name)
 
     def rowgroup_init(self, x, col: "DeviceColumn"):
         self._check_input(x, col)
-        _check(lib.alpgpu_rowgroup_init_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_rowgroup_init_f64")
+        self._call("rowgroup_init", col.dtype, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c))
 
     def encode_vectors(self, x, col: "DeviceColumn"):
         self._check_input(x, col)
-        _check(lib.alpgpu_encode_vectors_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_encode_vectors_f64")
+        self._call("encode_vectors", col.dtype, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c))
 
     def encode(self, x, col: "DeviceColumn" = None):
-        """rowgroup init + vector encode of a device tensor of n_vectors*1024 doubles"""
+        """rowgroup init + vector encode of a device tensor of n_vectors*1024 doubles (or floats)"""
         if col is None:
-            col = DeviceColumn(x.numel() // VECTOR_SIZE, self.device)
+            col = DeviceColumn(x.numel() // VECTOR_SIZE, self.device, dtype=self._sfx(x))
         self._check_input(x, col)
-        _check(lib.alpgpu_encode_f64(self.h, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c)), "alpgpu_encode_f64")
+        self._call("encode", col.dtype, _vp(x.data_ptr()), col.n_vectors, C.byref(col.c))
         return col
+
+    def state_from_samples(self, samples, state, rd_only: bool = False):
+        """samples: device tensor of 1..288 first-level samples; state: 32-byte uint8 device tensor"""
+        self._call("rd_state_from_samples" if rd_only else "state_from_samples", self._sfx(samples), _vp(samples.data_ptr()), samples.numel(),
+                   _vp(state.data_ptr()))
 
     # ---- tail padding + serialized container ------------------------------------------------------
     def pad_tail(self, x, n_values: int):
         """x: device tensor with room for ceil(n_values/1024)*1024 doubles; fills the incomplete last vector"""
         assert x.numel() >= (n_values + 1023) // 1024 * 1024
-        _check(lib.alpgpu_pad_tail_f64(self.h, _vp(x.data_ptr()), n_values), "alpgpu_pad_tail_f64")
+        self._call("pad_tail", self._sfx(x), _vp(x.data_ptr()), n_values)
 
     def to_blob(self, col: "DeviceColumn", n_values: int) -> np.ndarray:
         pb, eb, ov = self.column_totals(col)
         size = int(lib.alpgpu_blob_size(col.n_vectors, pb, eb))
         blob = np.zeros(size, np.uint8)
         w = _u64()
-        _check(lib.alpgpu_column_to_blob(self.h, C.byref(col.c), n_values, blob.ctypes.data_as(_vp), size, C.byref(w)), "alpgpu_column_to_blob")
+        fn = lib.alpgpu_column_to_blob if col.dtype == "f64" else lib.alpgpu_column_to_blob_f32
+        _check(fn(self.h, C.byref(col.c), n_values, blob.ctypes.data_as(_vp), size, C.byref(w)), "alpgpu_column_to_blob")
         assert w.value == size
         return blob
 
@@ -185,9 +226,11 @@ class Context:
         n_vectors, packed_bytes, exc_bytes = int(hdr[3]), int(hdr[5]), int(hdr[6])
         if blob.size < 64 or n_vectors > (1 << 40) or packed_bytes > (1 << 50) or exc_bytes > (1 << 50):
             raise AlpGpuError("blob header is implausible")
-        col = DeviceColumn(n_vectors, self.device, packed_capacity=packed_bytes + 1024, exc_capacity=exc_bytes + 64)
+        dtype = "f32" if int(hdr[7]) == 4 else "f64"
+        col = DeviceColumn(n_vectors, self.device, packed_capacity=packed_bytes + 1024, exc_capacity=exc_bytes + 64, dtype=dtype)
         nv = _u64()
-        _check(lib.alpgpu_column_from_blob(self.h, blob.ctypes.data_as(_vp), blob.size, C.byref(col.c), C.byref(nv)), "alpgpu_column_from_blob")
+        fn = lib.alpgpu_column_from_blob if dtype == "f64" else lib.alpgpu_column_from_blob_f32
+        _check(fn(self.h, blob.ctypes.data_as(_vp), blob.size, C.byref(col.c), C.byref(nv)), "alpgpu_column_from_blob")
         return col, nv.value
 
     def column_totals(self, col: "DeviceColumn"):
@@ -251,24 +294,65 @@ class Context:
 
     def decode(self, col: "DeviceColumn", out=None):
         import torch
+        tdt = torch.float64 if col.dtype == "f64" else torch.float32
         if out is None:
-            out = torch.empty(col.n_vectors * VECTOR_SIZE, dtype=torch.float64, device=f"cuda:{self.device}")
-        assert out.is_contiguous() and out.numel() >= col.n_vectors * VECTOR_SIZE and out.dtype == torch.float64
-        _check(lib.alpgpu_decode_f64(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_decode_f64")
+            out = torch.empty(col.n_vectors * VECTOR_SIZE, dtype=tdt, device=f"cuda:{self.device}")
+        assert out.is_contiguous() and out.numel() >= col.n_vectors * VECTOR_SIZE and out.dtype == tdt
+        self._call("decode", col.dtype, C.byref(col.c), _vp(out.data_ptr()))
         return out
+
+    # ---- batch primitives, 32-bit words (float) --------------------------------------------------------
+    def ffor_i32(self, vals, packed, bw, base):
+        _check(lib.alpgpu_ffor_i32(self.h, self._p(vals), self._p(packed), packed.shape[1], self._p(bw), self._p(base), vals.shape[0]), "alpgpu_ffor_i32")
+
+    def unffor_i32(self, packed, out, bw, base):
+        _check(lib.alpgpu_unffor_i32(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), out.shape[0]), "alpgpu_unffor_i32")
+
+    def falp_f32(self, packed, out, bw, base, fac, exp):
+        _check(lib.alpgpu_falp_f32(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), self._p(fac), self._p(exp),
+                                   out.shape[0]), "alpgpu_falp_f32")
+
+    def decode_values_f32(self, enc, out, fac, exp):
+        _check(lib.alpgpu_decode_values_f32(self.h, self._p(enc), self._p(out), self._p(fac), self._p(exp), out.shape[0]), "alpgpu_decode_values_f32")
+
+    def patch_f32(self, out, exc, pos, cnt):
+        _check(lib.alpgpu_patch_f32(self.h, self._p(out), self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_patch_f32")
+
+    def encode_simdized_f32(self, x, exc, pos, cnt, enc, fac, exp):
+        _check(lib.alpgpu_encode_simdized_f32(self.h, self._p(x), self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), self._p(enc),
+                                              self._p(fac), self._p(exp), x.shape[0]), "alpgpu_encode_simdized_f32")
+
+    def encode_values_f32(self, x, states, state_idx, exc, pos, cnt, enc, fac, exp):
+        _check(lib.alpgpu_encode_values_f32(self.h, self._p(x), self._p(states), self._p(state_idx), self._p(exc), self._p(pos), exc.shape[1],
+                                            self._p(cnt), self._p(enc), self._p(fac), self._p(exp), x.shape[0]), "alpgpu_encode_values_f32")
+
+    def analyze_ffor_i32(self, enc, bw, base):
+        _check(lib.alpgpu_analyze_ffor_i32(self.h, self._p(enc), self._p(bw), self._p(base), enc.shape[0]), "alpgpu_analyze_ffor_i32")
+
+    def rd_encode_vectors_f32(self, x, states, state_idx, exc, pos, cnt, right, left):
+        _check(lib.alpgpu_rd_encode_vectors_f32(self.h, self._p(x), self._p(states), self._p(state_idx), self._p(exc), self._p(pos), exc.shape[1],
+                                                self._p(cnt), self._p(right), self._p(left), x.shape[0]), "alpgpu_rd_encode_vectors_f32")
+
+    def rd_decode_vectors_f32(self, out, right, left, states, state_idx, exc, pos, cnt):
+        _check(lib.alpgpu_rd_decode_vectors_f32(self.h, self._p(out), self._p(right), self._p(left), self._p(states), self._p(state_idx),
+                                                self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_rd_decode_vectors_f32")
 
 
 class DeviceColumn:
     """A compressed column in HBM (struct alpgpu_column) whose buffers are torch uint8 tensors."""
 
     def __init__(self, n_vectors: int, device: int = 0, packed_capacity: int | None = None,
-                 exc_capacity: int | None = None):
+                 exc_capacity: int | None = None, dtype: str = "f64"):
         import torch
+        assert dtype in ("f64", "f32")
         dev = f"cuda:{device}"
+        self.dtype = dtype
         self.n_vectors = int(n_vectors)
         self.n_rowgroups = (self.n_vectors + ROWGROUP_VECTORS - 1) // ROWGROUP_VECTORS
-        pc = int(lib.alpgpu_packed_capacity(self.n_vectors)) if packed_capacity is None else int(packed_capacity)
-        ec = int(lib.alpgpu_exc_capacity(self.n_vectors)) if exc_capacity is None else int(exc_capacity)
+        pcap = lib.alpgpu_packed_capacity if dtype == "f64" else lib.alpgpu_packed_capacity_f32
+        ecap = lib.alpgpu_exc_capacity if dtype == "f64" else lib.alpgpu_exc_capacity_f32
+        pc = int(pcap(self.n_vectors)) if packed_capacity is None else int(packed_capacity)
+        ec = int(ecap(self.n_vectors)) if exc_capacity is None else int(exc_capacity)
         self.rowgroups = torch.zeros(max(1, self.n_rowgroups) * 32, dtype=torch.uint8, device=dev)
         self.vectors = torch.zeros(max(1, self.n_vectors) * 32, dtype=torch.uint8, device=dev)
         self.packed = torch.zeros(pc, dtype=torch.uint8, device=dev)
@@ -278,11 +362,11 @@ class DeviceColumn:
                          self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr(), 0, 0)
 
     @classmethod
-    def from_host(cls, rowgroups: np.ndarray, vectors: np.ndarray, packed: np.ndarray, exc: np.ndarray, device: int = 0):
+    def from_host(cls, rowgroups: np.ndarray, vectors: np.ndarray, packed: np.ndarray, exc: np.ndarray, device: int = 0, dtype: str = "f64"):
         """Upload host-side records/streams (numpy; see ROWGROUP_DTYPE / VECTOR_DTYPE)."""
         import torch
         n = vectors.size
-        col = cls(n, device, packed_capacity=packed.size + 1024, exc_capacity=exc.size + 64)
+        col = cls(n, device, packed_capacity=packed.size + 1024, exc_capacity=exc.size + 64, dtype=dtype)
         col.rowgroups[: rowgroups.size * 32] = torch.from_numpy(rowgroups.view(np.uint8).reshape(-1)).to(col.rowgroups.device)
         col.vectors[: n * 32] = torch.from_numpy(vectors.view(np.uint8).reshape(-1)).to(col.vectors.device)
         col.packed[: packed.size] = torch.from_numpy(packed).to(col.packed.device)

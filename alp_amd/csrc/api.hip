@@ -18,6 +18,7 @@ struct alpgpu_ctx {
 	int         n_cus;
 	int         decode_variant;
 	int         decode_auto;     // 1: vectors per decode workgroup chosen from the column's size hints
+	int         decode_vpw;      // the value last given to ALPGPU_OPT_DECODE_VECTORS_PER_WG (0 auto, 1, 2, 4); float decode reads this
 	char        name[128];
 	uint64_t    hbm_bytes;
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
@@ -85,6 +86,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->hbm_bytes      = prop.totalGlobalMem;
 	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup, bit 1: plain stores
 	ctx->decode_auto     = 1;
+	ctx->decode_vpw      = 0;
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
@@ -121,9 +123,12 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
 	switch (option) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
-		if (value < 0 || value > 2) { return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1 or 2"); }
+		if (value != 0 && value != 1 && value != 2 && value != 4) {
+			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2 or (float columns) 4");
+		}
 		ctx->decode_auto    = value == 0;
-		ctx->decode_variant = (ctx->decode_variant & ~1) | (value == 2 ? 0 : 1);
+		ctx->decode_vpw     = static_cast<int>(value);
+		ctx->decode_variant = (ctx->decode_variant & ~1) | (value >= 2 ? 0 : 1); // double columns: 4 behaves as 2
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_TWO_PASS:
 		ctx->encode_two_pass = value ? 1 : 0;
@@ -193,7 +198,6 @@ static int ensure_workspace(alpgpu_ctx* ctx, uint64_t bytes) {
 	// grows only between launches of different sizes; the old buffer may still be in use by queued work
 	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
 	if (ctx->workspace) { ALPGPU_HIP(hipFree(ctx->workspace)); }
-	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	const uint64_t want  = bytes < (1ull << 20) ? (1ull << 20) : bytes * 2;
@@ -377,7 +381,8 @@ uint64_t alpgpu_blob_size(uint64_t n_vectors, uint64_t packed_bytes, uint64_t ex
 	return sizeof(alpgpu_blob_header) + 32ull * ((n_vectors + 99) / 100) + 32ull * n_vectors + align8(packed_bytes) + align8(exc_bytes);
 }
 
-int alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+static int column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written,
+                          uint64_t value_bytes) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || !h_blob) { return fail(ALPGPU_ERR_INVALID, "null column or blob"); }
 	if (n_values > col->n_vectors * 1024ull || n_values + 1024ull <= col->n_vectors * 1024ull) {
@@ -397,6 +402,7 @@ int alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_
 	std::memcpy(h.magic, "ALPGPU1", 8);
 	h.version = 1, h.header_bytes = sizeof(h), h.n_values = n_values, h.n_vectors = col->n_vectors, h.n_rowgroups = col->n_rowgroups;
 	h.packed_bytes = t[0], h.exc_bytes = t[1];
+	h.reserved     = value_bytes == 8 ? 0 : value_bytes; // double blobs keep the version-1 encoding (0)
 	uint8_t* p = static_cast<uint8_t*>(h_blob);
 	std::memcpy(p, &h, sizeof(h));
 	p += sizeof(h);
@@ -413,13 +419,23 @@ int alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_
 	return ALPGPU_OK;
 }
 
-int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values) {
+int alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	return column_to_blob(ctx, col, n_values, h_blob, capacity, written, 8);
+}
+int alpgpu_column_to_blob_f32(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	return column_to_blob(ctx, col, n_values, h_blob, capacity, written, 4);
+}
+
+static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values, uint64_t value_bytes) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!h_blob || !col) { return fail(ALPGPU_ERR_INVALID, "null blob or column"); }
 	if (size < sizeof(alpgpu_blob_header)) { return fail(ALPGPU_ERR_INVALID, "blob shorter than its header"); }
 	alpgpu_blob_header h;
 	std::memcpy(&h, h_blob, sizeof(h));
 	if (std::memcmp(h.magic, "ALPGPU1", 8) != 0 || h.version != 1 || h.header_bytes != sizeof(h)) { return fail(ALPGPU_ERR_INVALID, "not an ALPGPU v1 blob"); }
+	if ((h.reserved == 0 ? 8ull : h.reserved) != value_bytes) { return fail(ALPGPU_ERR_INVALID, "blob holds a column of the other value type"); }
+	const unsigned vbits = static_cast<unsigned>(8 * value_bytes); // 64 or 32
+	const unsigned max_e = value_bytes == 8 ? 18u : 10u;
 	if (h.n_rowgroups != (h.n_vectors + 99) / 100 || h.n_values > h.n_vectors * 1024ull || (h.n_vectors && h.n_values + 1024ull <= h.n_vectors * 1024ull)) {
 		return fail(ALPGPU_ERR_INVALID, "inconsistent blob header");
 	}
@@ -440,8 +456,9 @@ int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 		const bool alp = d.scheme == ALPGPU_SCHEME_ALP, rd = d.scheme == ALPGPU_SCHEME_ALP_RD;
 		if ((!alp && !rd) || rg.scheme != d.scheme) { return fail(ALPGPU_ERR_INVALID, "blob: bad scheme in a descriptor"); }
 		const uint64_t psz = 128ull * (d.bw + (rd ? d.lbw : 0));
-		const uint64_t esz = align8((alp ? 10ull : 4ull) * d.exc_cnt);
-		if (d.bw > 64 || d.exc_cnt > 1024 || (alp && (d.e > 18 || d.f > d.e)) || (rd && (d.lbw < 1 || d.lbw > 3 || d.bw > 63 || d.bw != rg.rd_rbw || d.lbw != rg.rd_lbw))) {
+		const uint64_t esz = align8((alp ? value_bytes + 2ull : 4ull) * d.exc_cnt);
+		if (d.bw > vbits || d.exc_cnt > 1024 || (alp && (d.e > max_e || d.f > d.e)) ||
+		    (rd && (d.lbw < 1 || d.lbw > 3 || d.bw > vbits - 1 || d.bw != rg.rd_rbw || d.lbw != rg.rd_lbw))) {
 			return fail(ALPGPU_ERR_INVALID, "blob: descriptor field out of range");
 		}
 		if ((d.packed_off & 127ull) || (d.exc_off & 7ull) || d.packed_off > h.packed_bytes || psz > h.packed_bytes - d.packed_off || d.exc_off > h.exc_bytes ||
@@ -450,7 +467,7 @@ int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 		}
 		if (d.exc_cnt) { // positions must be < 1024
 			const uint8_t*  rec = p + 32ull * h.n_rowgroups + 32ull * h.n_vectors + align8(h.packed_bytes) + d.exc_off;
-			const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec + (alp ? 8ull : 2ull) * d.exc_cnt);
+			const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec + (alp ? value_bytes : 2ull) * d.exc_cnt);
 			for (uint32_t j = 0; j < d.exc_cnt; ++j) {
 				uint16_t q;
 				std::memcpy(&q, pos + j, 2);
@@ -474,6 +491,13 @@ int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 	return ALPGPU_OK;
 }
 
+int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values) {
+	return column_from_blob(ctx, h_blob, size, col, n_values, 8);
+}
+int alpgpu_column_from_blob_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values) {
+	return column_from_blob(ctx, h_blob, size, col, n_values, 4);
+}
+
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || !col->d_totals) { return fail(ALPGPU_ERR_INVALID, "null column"); }
@@ -487,6 +511,122 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_b
 	col->exc_bytes_hint    = t[1];
 	if (t[3]) { return fail(ALPGPU_ERR_HIP, "single-pass encode stalled in its offset look-back; re-encode with ALPGPU_OPT_ENCODE_TWO_PASS"); }
 	return t[2] ? fail(ALPGPU_ERR_CAPACITY, "an output stream overflowed its capacity") : ALPGPU_OK;
+}
+
+// ==== single precision =================================================================================================
+// worst case per vector: ALP bw=32 -> 4096 B; ALP_RD rbw=31,lbw=3 -> 4352 B.  +1 KiB slack at the end.
+uint64_t alpgpu_packed_capacity_f32(uint64_t n_vectors) { return n_vectors * 4352ull + 1024ull; }
+// worst case per vector: 1024 exceptions x (4 B value + 2 B position)
+uint64_t alpgpu_exc_capacity_f32(uint64_t n_vectors) { return n_vectors * 6144ull + 64ull; }
+
+int alpgpu_rowgroup_init_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (alpgpu::launch_rowgroup_init_f32(ctx->stream, d_in, n_vectors, col->d_rowgroups) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+static int state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_samples || !d_state) { return fail(ALPGPU_ERR_INVALID, "null samples or state"); }
+	if (n_samples == 0 || n_samples > 288) { return fail(ALPGPU_ERR_INVALID, "n_samples must be 1..288 (9 sampled vectors x 32)"); }
+	if (alpgpu::launch_state_from_samples_f32(ctx->stream, d_samples, n_samples, d_state, force_rd) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "state-from-samples launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+int alpgpu_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state) {
+	return state_from_samples_f32(ctx, d_samples, n_samples, d_state, 0);
+}
+int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state) {
+	return state_from_samples_f32(ctx, d_samples, n_samples, d_state, 1);
+}
+
+int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (int rc = ensure_workspace(ctx, alpgpu::encode_workspace_bytes(n_vectors))) { return rc; }
+	if (alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace)) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	if (int rc = alpgpu_rowgroup_init_f32(ctx, d_in, n_vectors, col)) { return rc; }
+	return alpgpu_encode_vectors_f32(ctx, d_in, n_vectors, col);
+}
+
+int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	const int vpw = ctx->decode_vpw ? ctx->decode_vpw : 2; // a float vector is 4 KiB: two per workgroup = the bytes of one double vector
+	if (alpgpu::launch_decode_column_f32(ctx->stream, col, d_out, vpw, (ctx->decode_variant & 2) != 0) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "decode launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
+int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in && n_values) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (alpgpu::launch_pad_tail_f32(ctx->stream, d_in, n_values) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "pad launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+
+int alpgpu_ffor_i32(alpgpu_ctx* ctx, const int32_t* d_in, int32_t* d_packed, size_t packed_stride, const uint8_t* d_bw, const int32_t* d_base,
+                    uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_packed && d_bw && d_base, alpgpu::launch_ffor_i32(ctx->stream, ctx->n_cus, d_in, d_packed, packed_stride, d_bw, d_base, n_vectors));
+}
+int alpgpu_unffor_i32(alpgpu_ctx* ctx, const int32_t* d_packed, size_t packed_stride, int32_t* d_out, const uint8_t* d_bw, const int32_t* d_base,
+                      uint64_t n_vectors) {
+	ALPGPU_PRIM(d_packed && d_out && d_bw && d_base, alpgpu::launch_unffor_i32(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, n_vectors));
+}
+int alpgpu_falp_f32(alpgpu_ctx* ctx, const int32_t* d_packed, size_t packed_stride, float* d_out, const uint8_t* d_bw, const int32_t* d_base,
+                    const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_packed && d_out && d_bw && d_base && d_fac && d_exp,
+	            alpgpu::launch_falp_f32(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, d_fac, d_exp, n_vectors));
+}
+int alpgpu_decode_values_f32(alpgpu_ctx* ctx, const int32_t* d_enc, float* d_out, const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_enc && d_out && d_fac && d_exp, alpgpu::launch_decode_values_f32(ctx->stream, ctx->n_cus, d_enc, d_out, d_fac, d_exp, n_vectors));
+}
+int alpgpu_patch_f32(alpgpu_ctx* ctx, float* d_out, const float* d_exc, const uint16_t* d_pos, size_t exc_stride, const uint16_t* d_cnt,
+                     uint64_t n_vectors) {
+	ALPGPU_PRIM(d_out && d_exc && d_pos && d_cnt, alpgpu::launch_patch_f32(ctx->stream, ctx->n_cus, d_out, d_exc, d_pos, exc_stride, d_cnt, n_vectors));
+}
+int alpgpu_encode_simdized_f32(alpgpu_ctx* ctx, const float* d_in, float* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, int32_t* d_enc,
+                               const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_exc && d_pos && d_cnt && d_enc && d_fac && d_exp,
+	            alpgpu::launch_encode_simdized_f32(ctx->stream, ctx->n_cus, d_in, d_exc, d_pos, exc_stride, d_cnt, d_enc, d_fac, d_exp, n_vectors));
+}
+int alpgpu_encode_values_f32(alpgpu_ctx* ctx, const float* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx, float* d_exc,
+                             uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, int32_t* d_enc, uint8_t* d_fac, uint8_t* d_exp, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_states && d_exc && d_pos && d_cnt && d_enc && d_fac && d_exp,
+	            alpgpu::launch_encode_values_f32(ctx->stream, ctx->n_cus, d_in, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, d_enc, d_fac,
+	                                             d_exp, n_vectors));
+}
+int alpgpu_analyze_ffor_i32(alpgpu_ctx* ctx, const int32_t* d_enc, uint8_t* d_bw, int32_t* d_base, uint64_t n_vectors) {
+	ALPGPU_PRIM(d_enc && d_bw && d_base, alpgpu::launch_analyze_ffor_i32(ctx->stream, ctx->n_cus, d_enc, d_bw, d_base, n_vectors));
+}
+int alpgpu_rd_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
+                                 uint16_t* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, uint32_t* d_right, uint16_t* d_left,
+                                 uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_states && d_exc && d_pos && d_cnt && d_right && d_left,
+	            alpgpu::launch_rd_encode_f32(ctx->stream, ctx->n_cus, d_in, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, d_right, d_left,
+	                                         n_vectors));
+}
+int alpgpu_rd_decode_vectors_f32(alpgpu_ctx* ctx, float* d_out, const uint32_t* d_right, const uint16_t* d_left, const alpgpu_rowgroup_state* d_states,
+                                 const uint32_t* d_state_idx, const uint16_t* d_exc, const uint16_t* d_pos, size_t exc_stride, const uint16_t* d_cnt,
+                                 uint64_t n_vectors) {
+	ALPGPU_PRIM(d_out && d_right && d_left && d_states && d_exc && d_pos && d_cnt,
+	            alpgpu::launch_rd_decode_f32(ctx->stream, ctx->n_cus, d_out, d_right, d_left, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt,
+	                                         n_vectors));
 }
 
 } // extern "C"

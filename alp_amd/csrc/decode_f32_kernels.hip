@@ -1,0 +1,243 @@
+// decode_f32_kernels.hip — fused ALP / ALP_RD column decode for gfx950, single precision.
+//
+// Replaces, per vector (reference file:line relative to /root/reference):
+//   ALP    : generated::falp::fallback::scalar::falp (float)  include/alp/falp.hpp:28-44, src/falp.cpp 32-bit section
+//            + alp::decoder<float>::patch_exceptions          include/alp/decoder.hpp:141-149
+//   ALP_RD : unffor::unffor (u32 right, u16 left)             include/fastlanes/unffor.hpp:7-15
+//            + alp::rd_encoder<float>::decode                 include/alp/rd.hpp:152-178
+//
+// Same structure as decode_kernels.hip (the measurements that motivate it are listed there): the hardware dispatcher
+// hands out small workgroups in vector order; the packed words go HBM -> LDS by LDS-DMA, the exception record becomes
+// a 1024-bit mask + staged values, one barrier sits behind the memory latency.  A float vector is 4 KiB of output, so a
+// 256-thread workgroup covers one vector with ONE 16-byte store per thread (thread t owns values 4t..4t+3 = one 16-byte
+// unit of the FastLanes u32 layout, alp_device_f32.hpp), and V consecutive vectors per workgroup keep the bytes in flight
+// per CU at the level of the double-precision kernel (V = 2 moves as many bytes per workgroup as one double vector).
+#include "alp_device_f32.hpp"
+#include "launch.hpp"
+
+namespace alpgpu {
+
+constexpr int kDecThreadsF  = 256;
+constexpr int kStageBytesF  = 4480; // >= 31*128 (RD right) + 3*128 (RD left) + 128 pad, and >= 32*128 + 128 (ALP bw 32)
+constexpr int kExcStageF    = 128;
+
+struct __attribute__((aligned(16))) DecodeLdsF32 {
+	uint8_t  stage[kStageBytesF];
+	uint32_t mask[32];
+	uint32_t excv[kExcStageF];
+};
+
+struct ExcMaskF {
+	uint32_t word;
+	int      excl;
+};
+// lane l < 32: mask word l and the number of exceptions in the words before it (DPP row scan, see decode_kernels.hip)
+__device__ __forceinline__ ExcMaskF load_exception_mask_f32(const DecodeLdsF32& L, int lane) {
+	ExcMaskF  m;
+	m.word      = L.mask[lane & 31];
+	const int c = lane < 32 ? __builtin_popcount(m.word) : 0;
+	int       v = c;
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+	m.excl = v - c;
+	return m;
+}
+
+template <int VAL_BYTES>
+__device__ __forceinline__ uint32_t fetch_exception_f32(const DecodeLdsF32& L, const uint8_t* __restrict__ rec, int rank) {
+	if (rank < kExcStageF) { return L.excv[rank]; }
+	if constexpr (VAL_BYTES == 4) {
+		return reinterpret_cast<const uint32_t*>(rec)[rank];
+	} else {
+		return reinterpret_cast<const uint16_t*>(rec)[rank];
+	}
+}
+
+template <bool NT_STORE>
+__device__ __forceinline__ void store_quad(float* __restrict__ p, const u32x4& bits) {
+	if constexpr (NT_STORE) {
+		__builtin_nontemporal_store(bits, reinterpret_cast<u32x4*>(p));
+	} else {
+		*reinterpret_cast<u32x4*>(p) = bits;
+	}
+}
+
+struct ExcRegsF {
+	uint32_t pos;
+	uint32_t val;
+};
+
+__device__ __forceinline__ ExcRegsF issue_vector_loads_f32(DecodeLdsF32& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
+                                                           const uint8_t* __restrict__ rec, int tid, int wave) {
+	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+	const bool  is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
+	const int   n_units = 8 * (d.bw + (is_alp ? 0 : d.lbw));
+	const ull2* g       = reinterpret_cast<const ull2*>(packed + d.packed_off);
+#pragma unroll
+	for (int j = 0; j < 2; ++j) { // <= 272 units
+		const int c = tid + kDecThreadsF * j;
+		if (c < n_units) { __builtin_amdgcn_global_load_lds(g + c, reinterpret_cast<ull2*>(L.stage) + (kDecThreadsF * j + 64 * wave), 16, 0, 0); }
+	}
+	ExcRegsF  e {0u, 0u};
+	const int cnt = d.exc_cnt;
+	if (tid < cnt) {
+		const int vb = is_alp ? 4 : 2;
+		e.pos        = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * vb)[tid];
+		if (tid < kExcStageF) { e.val = is_alp ? reinterpret_cast<const uint32_t*>(rec)[tid] : static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(rec)[tid]); }
+	}
+	return e;
+}
+
+__device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, const ExcRegsF& e, int tid) {
+	const int cnt = d.exc_cnt;
+	if (tid < cnt) {
+		atomicOr(&L.mask[e.pos >> 5], 1u << (e.pos & 31));
+		if (tid < kExcStageF) { L.excv[tid] = e.val; }
+	}
+	if (cnt > kDecThreadsF) {
+		const uint16_t* poss = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * (d.scheme == ALPGPU_SCHEME_ALP ? 4 : 2));
+		for (int j = tid + kDecThreadsF; j < cnt; j += kDecThreadsF) {
+			const uint32_t p = poss[j];
+			atomicOr(&L.mask[p >> 5], 1u << (p & 31));
+		}
+	}
+}
+
+// one vector, after its packed words / exception mask are visible in L; thread tid owns values 4*tid .. 4*tid+3
+template <bool NT_STORE>
+__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
+                                                         const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane) {
+	const int    bw    = d.bw;
+	const int    cnt   = d.exc_cnt;
+	const int    a     = tid & 7;
+	const int    row   = tid >> 3;
+	const u32x4* units = reinterpret_cast<const u32x4*>(L.stage);
+	uint32_t     hits  = 0;
+	int          rank  = 0;
+	if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
+		const ExcMaskF em   = load_exception_mask_f32(L, lane);
+		const int      wi   = 8 * wave + (lane >> 3);
+		const uint32_t word = static_cast<uint32_t>(__shfl(static_cast<int>(em.word), wi));
+		const int      pref = __shfl(em.excl, wi);
+		const int      b0   = 4 * a;
+		hits                = (word >> b0) & 0xFu;
+		rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
+	}
+	u32x4 out;
+	if (d.scheme == ALPGPU_SCHEME_ALP) {
+		const uint32_t base = static_cast<uint32_t>(d.base);
+		const uint32_t fact = kFactArrF[d.f];
+		const float    frac = kFracArrF[d.e];
+		const u32x4    q    = unpack_quad_u32(units, bw, bw_mask32(bw), row, a);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint(decode_value_f32(static_cast<int32_t>(q[c] + base), fact, frac)); }
+		if (hits) {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				if (hits & (1u << c)) {
+					out[c] = fetch_exception_f32<4>(L, rec, rank);
+					++rank;
+				}
+			}
+		}
+	} else {
+		// ALP_RD: right parts = u32 lanes (bw = rbw, base 0); left parts = u16 lanes, 64 streams x 16 rows (value i ->
+		// lane64 = i & 63, row = i >> 6, word k at left[64*k + lane64]): the quad shares row tid >> 4 and is the aligned
+		// 8-byte group (tid & 15) of every left word row.
+		const int      rbw  = bw;
+		const int      lbw  = d.lbw;
+		const uint32_t lmsk = (1u << lbw) - 1u;
+		const uint64_t dlo = static_cast<uint64_t>(rgp->rd_dict[0]) | (static_cast<uint64_t>(rgp->rd_dict[1]) << 16) |
+		                     (static_cast<uint64_t>(rgp->rd_dict[2]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[3]) << 48);
+		const uint64_t dhi = static_cast<uint64_t>(rgp->rd_dict[4]) | (static_cast<uint64_t>(rgp->rd_dict[5]) << 16) |
+		                     (static_cast<uint64_t>(rgp->rd_dict[6]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[7]) << 48);
+		const u32x4     q    = unpack_quad_u32(units, rbw, bw_mask32(rbw), row, a);
+		const uint64_t* lsrc = reinterpret_cast<const uint64_t*>(L.stage + 128 * rbw);
+		const int       p    = (tid >> 4) * lbw;
+		const int       k    = p >> 4;
+		const int       s    = p & 15;
+		const uint64_t  w0   = lsrc[16 * k + (tid & 15)];
+		const uint64_t  w1   = lsrc[16 * k + 16 + (tid & 15)];
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const uint32_t f0  = static_cast<uint32_t>(w0 >> (16 * c)) & 0xFFFFu;
+			const uint32_t f1  = static_cast<uint32_t>(w1 >> (16 * c)) & 0xFFFFu;
+			const uint32_t idx = ((f0 >> s) | (f1 << (16 - s))) & lmsk;
+			uint32_t       l   = static_cast<uint32_t>((idx < 4 ? dlo >> (16 * idx) : dhi >> (16 * (idx & 3))) & 0xFFFFull);
+			if (hits & (1u << c)) {
+				l = fetch_exception_f32<2>(L, rec, rank);
+				++rank;
+			}
+			out[c] = (l << rbw) | q[c];
+		}
+	}
+	store_quad<NT_STORE>(dst + 4 * tid, out);
+}
+
+template <int V, bool NT_STORE>
+__global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu_vector_desc* __restrict__ descs,
+                                                                    const alpgpu_rowgroup_state* __restrict__ rgs, const uint8_t* __restrict__ packed,
+                                                                    const uint8_t* __restrict__ excs, float* __restrict__ out, uint64_t n_vectors,
+                                                                    uint64_t wg_offset) {
+	__shared__ DecodeLdsF32 L[V];
+	const int      tid  = static_cast<int>(threadIdx.x);
+	const int      lane = tid & 63;
+	const int      wave = wave_in_wg();
+	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
+	if (v0 >= n_vectors) { return; }
+	if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
+	__syncthreads(); // before anything waits on memory
+
+	alpgpu_vector_desc d[V];
+	ExcRegsF           e[V];
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // tail vectors of the last workgroup are simply loaded again
+		d[i]             = descs[v];
+	}
+#pragma unroll
+	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads_f32(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+#pragma unroll
+	for (int i = 0; i < V; ++i) { land_exceptions_f32(L[i], d[i], excs + d[i].exc_off, e[i], tid); }
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		if (v0 + i < n_vectors) {
+			decode_staged_vector_f32<NT_STORE>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, out + (v0 + i) * kVec, tid, wave, lane);
+		}
+	}
+}
+
+template <int V>
+static void launch_v(hipStream_t stream, const alpgpu_column* col, float* d_out, bool nt) {
+	const uint64_t n        = col->n_vectors;
+	const uint64_t n_wg     = (n + V - 1) / V;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
+		if (nt) {
+			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+		} else {
+			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+		}
+	}
+}
+
+// vectors_per_wg in {1, 2, 4}
+int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores) {
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (vectors_per_wg == 1) {
+		launch_v<1>(stream, col, d_out, !plain_stores);
+	} else if (vectors_per_wg == 2) {
+		launch_v<2>(stream, col, d_out, !plain_stores);
+	} else {
+		launch_v<4>(stream, col, d_out, !plain_stores);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+} // namespace alpgpu

@@ -1,0 +1,214 @@
+// encode_f32_device.hpp — wavefront-level building blocks of the single-precision ALP / ALP_RD vector encode (gfx950).
+//
+// One 64-lane wavefront per 1024-value vector; lane L holds the value quads i = 256*m + 4*L + j (m = 0..3, j = 0..3), so the
+// 4 KiB input is read with four 1-KiB-contiguous 16-byte-per-lane loads; in the FastLanes u32 layout (alp_device_f32.hpp) a
+// quad is one 16-byte unit: row = 8*m + (L >> 3), unit column a = L & 7.
+// Reference functions restated here (file:line relative to /root/reference), PT = float:
+//   second-level sampling  alp::encoder<float>::find_best_exponent_factor_from_combinations  include/alp/encoder.hpp:241-305
+//   value encode + verify  alp::encoder<float>::encode_simdized                              include/alp/encoder.hpp:307-400
+//   FOR analysis           alp::encoder<float>::analyze_ffor                                 include/alp/encoder.hpp:109-120
+//   FFOR bit-packing       ffor::ffor (u32: src/fastlanes_generated_ffor.cpp:1776-7378)
+#pragma once
+#include "alp_device_f32.hpp"
+
+namespace alpgpu {
+
+struct __attribute__((aligned(16))) EncodeLdsF32 {
+	uint32_t vals[kVec]; // (enc - base) or RD right parts, natural index order: 4 KiB
+	float    smp[32];    // second-level samples
+};
+
+struct VecInF {
+	f32x4 x[4];
+};
+
+__device__ __forceinline__ uint64_t lanemask_lt64(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+__device__ __forceinline__ VecInF load_vector_f32(const float* __restrict__ in, uint64_t v, int lane) {
+	const f32x4* p = reinterpret_cast<const f32x4*>(in + v * kVec);
+	VecInF       r;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) { r.x[m] = p[64 * m + lane]; }
+	return r;
+}
+
+// ---- second-level sampling (encoder.hpp:241-305), PT = float: exception cost 32 + 16 bits -----------------------
+// sample s = input[32*s] = element j = 0 of step s >> 3 in lane 8*(s & 7).  All candidates are evaluated (two per round,
+// one per half-wave); replaying the reference's sequential decision over the sizes gives its (e,f), early exit included.
+__device__ __forceinline__ void second_level_select_f32(const VecInF& in, const alpgpu_rowgroup_state* __restrict__ rgp, EncodeLdsF32& L, int lane,
+                                                        int& e_out, int& f_out) {
+	const int k = rgp->k;
+	if ((lane & 7) == 0) {
+#pragma unroll
+		for (int m = 0; m < 4; ++m) { L.smp[8 * m + (lane >> 3)] = in.x[m][0]; }
+	}
+	wave_lds_sync();
+	const float sv   = L.smp[lane & 31];
+	const int   half = lane >> 5;
+	uint32_t    sizes[5];
+#pragma unroll
+	for (int i = 0; i < 5; ++i) { sizes[i] = 0xFFFFFFFFu; }
+#pragma unroll
+	for (int kk = 0; kk < 6; kk += 2) {
+		if (kk < k) { // wave-uniform
+			const int      c     = kk + half;
+			const int      cc    = c < k ? c : 0;
+			const int      e     = rgp->combos[2 * cc];
+			const int      f     = rgp->combos[2 * cc + 1];
+			const int32_t  enc   = encode_value_f32(sv, kExpArrF[e], kFracArrF[f]);
+			const float    dec   = decode_value_f32(enc, kFactArrF[f], kFracArrF[e]);
+			const bool     ok    = dec == sv;
+			const uint64_t bal   = __ballot(!ok);
+			const uint32_t excs  = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
+			int32_t        mx    = ok ? enc : INT32_MIN;
+			int32_t        mn    = ok ? enc : INT32_MAX;
+#pragma unroll
+			for (int d = 16; d >= 1; d >>= 1) { // stays inside the 32-lane half
+				const int32_t omx = __shfl_xor(mx, d);
+				const int32_t omn = __shfl_xor(mn, d);
+				mx                = omx > mx ? omx : mx;
+				mn                = omn < mn ? omn : mn;
+			}
+			const uint32_t size = 32u * static_cast<uint32_t>(count_bits32(mx, mn)) + excs * 48u;
+			sizes[kk]           = __builtin_amdgcn_readlane(size, 0);
+			if (kk + 1 < 5) { sizes[kk + 1] = __builtin_amdgcn_readlane(size, 32); }
+		}
+	}
+	int      best = 0, worse = 0;
+	uint32_t best_size = sizes[0];
+	bool     stopped   = false;
+#pragma unroll
+	for (int i = 1; i < 5; ++i) { // encoder.hpp:283-301
+		if (i < k && !stopped) {
+			if (sizes[i] >= best_size) {
+				if (++worse == 2) { stopped = true; }
+			} else {
+				best_size = sizes[i];
+				best      = i;
+				worse     = 0;
+			}
+		}
+	}
+	e_out = rgp->combos[2 * best];
+	f_out = rgp->combos[2 * best + 1];
+	wave_lds_sync();
+}
+
+// ---- encode_simdized + analyze_ffor for one vector held in registers --------------------------------------------------
+struct AlpEncodedF {
+	int32_t  enc[4][4];
+	uint64_t ballot[4][4];
+	uint32_t flags; // bit 4m + j
+	int      cnt;
+	int32_t  base;
+	int      bw;
+};
+
+__device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e, int f, int lane, AlpEncodedF& R) {
+	const float    exp10  = kExpArrF[e];
+	const float    frac_f = kFracArrF[f];
+	const uint32_t fact   = kFactArrF[f];
+	const float    frac_e = kFracArrF[e];
+	R.flags = 0;
+	R.cnt   = 0;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float    v    = in.x[m][j];
+			const uint32_t bits = __float_as_uint(v);
+			// pass 1 (encoder.hpp:326-338): NaN, +-Inf and -0.0 are replaced by (float)ENCODING_UPPER_LIMIT
+			const bool    special = ((bits & 0x7FFFFFFFu) >= 0x7F800000u) || bits == 0x80000000u;
+			const float   vv      = special ? kUpperLimitF : v;
+			const int32_t enc     = encode_value_f32(vv, exp10, frac_f);
+			const float   dec     = decode_value_f32(enc, fact, frac_e);
+			const bool    exc     = dec != vv;
+			R.enc[m][j]           = enc;
+			R.ballot[m][j]        = __ballot(exc);
+			R.flags |= exc ? (1u << (4 * m + j)) : 0u;
+			R.cnt += __builtin_popcountll(R.ballot[m][j]);
+		}
+	}
+	// filler = encoded value at the first non-exception position p (encoder.hpp:382-388); 0 when there is none or p == 1023
+	int32_t filler = 0;
+	bool    found  = false;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		const uint64_t any = ~(R.ballot[m][0] & R.ballot[m][1] & R.ballot[m][2] & R.ballot[m][3]);
+		if (!found && any != 0) { // wave-uniform
+			int best_pos = 1 << 20, best_j = 0, best_l = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint64_t nj = ~R.ballot[m][j];
+				const int      lj = nj ? __builtin_ctzll(nj) : 64;
+				const int      pj = nj ? 4 * lj + j : (1 << 20);
+				if (pj < best_pos) {
+					best_pos = pj;
+					best_j   = j;
+					best_l   = lj;
+				}
+			}
+			int32_t cand = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (best_j == j) { cand = __builtin_amdgcn_readlane(R.enc[m][j], best_l); }
+			}
+			filler = (256 * m + best_pos == 1023) ? 0 : cand;
+			found  = true;
+		}
+	}
+	int32_t mn = INT32_MAX, mx = INT32_MIN;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (R.flags & (1u << (4 * m + j))) { R.enc[m][j] = filler; }
+			mn = R.enc[m][j] < mn ? R.enc[m][j] : mn;
+			mx = R.enc[m][j] > mx ? R.enc[m][j] : mx;
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		const int32_t omn = __shfl_xor(mn, d);
+		const int32_t omx = __shfl_xor(mx, d);
+		mn                = omn < mn ? omn : mn;
+		mx                = omx > mx ? omx : mx;
+	}
+	R.base = mn;
+	R.bw   = count_bits32(mx, mn);
+}
+
+// rank of this lane's (m, j) exception among the vector's exceptions in ascending position order
+__device__ __forceinline__ int exception_rank_f32(const uint64_t (&ballot)[4][4], uint32_t flags, int m, int j, int lane, int step_offset) {
+	const uint64_t lt = lanemask_lt64(lane);
+	int            r  = step_offset;
+#pragma unroll
+	for (int jj = 0; jj < 4; ++jj) { r += __builtin_popcountll(ballot[m][jj] & lt); }
+	r += __builtin_popcount((flags >> (4 * m)) & ((1u << j) - 1u));
+	return r;
+}
+
+// ---- FFOR u32 pack from LDS: vals[i] = value - base (< 2^bw), natural order.  Output unit u = 8*k + a is the 16-byte group
+// of stream word k for lane32 columns 4a..4a+3; lane handles units lane, lane + 64, ... -> 1-KiB contiguous stores.
+__device__ __forceinline__ void pack_u32_from_lds(const EncodeLdsF32& L, int bw, u32x4* __restrict__ out, int lane) {
+	const u32x4* vals4   = reinterpret_cast<const u32x4*>(L.vals);
+	const int    n_units = 8 * bw;
+	for (int u = lane; u < n_units; u += 64) {
+		const int k    = u >> 3;
+		const int a    = u & 7;
+		const int bit0 = 32 * k;
+		int       r    = bit0 / bw;
+		int       p    = r * bw;
+		u32x4     acc  = {0u, 0u, 0u, 0u};
+		while (p < bit0 + 32 && r < 32) {
+			const u32x4 v  = vals4[8 * r + a];
+			const int   sh = p - bit0;
+			acc |= sh >= 0 ? (v << static_cast<uint32_t>(sh)) : (v >> static_cast<uint32_t>(-sh));
+			p += bw;
+			++r;
+		}
+		out[u] = acc;
+	}
+}
+
+} // namespace alpgpu

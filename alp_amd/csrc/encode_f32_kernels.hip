@@ -1,0 +1,227 @@
+// encode_f32_kernels.hip — whole-column ALP / ALP_RD vector encode for gfx950, single precision.
+//
+// Replaces, per vector (file:line relative to /root/reference):
+//   alp::encoder<float>::encode           include/alp/encoder.hpp:402-418 (second-level sampling :241-305, encode_simdized :307-400)
+//   alp::encoder<float>::analyze_ffor     include/alp/encoder.hpp:109-120
+//   ffor::ffor (int32 / uint32 / uint16)  include/fastlanes/ffor.hpp:7-15 -> src/fastlanes_generated_ffor.cpp:1776-7378, :357-1775
+//   alp::rd_encoder<float>::encode        include/alp/rd.hpp:109-147
+//
+// Single pass, same scheme as k_encode_fused (encode_kernels.hip): one wavefront per 1024-value vector, four vectors per
+// workgroup (tile), output offsets in vector order from the decoupled look-back of encode_lookback.hpp.
+// Ownership: lane L holds the value quads i = 256*m + 4*L + j (m = 0..3, j = 0..3), so the 4 KiB input is read with four
+// 1-KiB-contiguous 16-byte-per-lane loads; in the FastLanes u32 layout (alp_device_f32.hpp) a quad is one 16-byte unit:
+// row = 8*m + (L >> 3), unit column a = L & 7.
+#include "encode_f32_device.hpp"
+#include "encode_lookback.hpp"
+#include "launch.hpp"
+
+namespace alpgpu {
+
+__device__ __forceinline__ void desc_sizes_f32(const alpgpu_vector_desc& d, uint64_t& packed, uint64_t& exc) {
+	if (d.scheme == ALPGPU_SCHEME_ALP) {
+		packed = 128ull * d.bw;
+		exc    = (6ull * d.exc_cnt + 7ull) & ~7ull; // cnt x f32 bits, then cnt x u16 positions
+	} else {
+		packed = 128ull * (static_cast<uint64_t>(d.bw) + d.lbw);
+		exc    = (4ull * d.exc_cnt + 7ull) & ~7ull; // cnt x u16 left parts, then cnt x u16 positions
+	}
+}
+
+__global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                       alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
+                                                                       uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
+                                                                       uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
+                                                                       uint64_t v_first, uint64_t n_vectors_launch) {
+	__shared__ EncodeLdsF32 lds[kWavesPerWg];
+	__shared__ uint64_t     s_size[kWavesPerWg];
+	__shared__ uint64_t     s_excl;
+	__shared__ uint32_t     s_count;
+	__shared__ uint32_t     s_ready;
+	const int               lane = lane_id();
+	const int               wave = wave_in_wg();
+	const uint64_t          tile = blockIdx.x;
+	if (threadIdx.x == 0) {
+		s_count = 0;
+		s_ready = 0;
+	}
+	__syncthreads();
+
+	EncodeLdsF32&  L    = lds[wave];
+	const uint64_t vl   = tile * kWavesPerWg + wave;
+	const bool     live = vl < n_vectors_launch;
+	const uint64_t v    = v_first + vl;
+	VecInF             x;
+	alpgpu_vector_desc d;
+	uint32_t           flags = 0;
+	uint64_t           lacc[4] = {0, 0, 0, 0}; // ALP_RD: packed left streams of this lane's four lane64 columns
+	uint64_t           ballots[4][4];
+	int                cnt = 0;
+	d.packed_off = d.exc_off = 0;
+	d.base                   = 0;
+	d.bw = d.e = d.f = d.lbw = 0;
+	d.exc_cnt = d.scheme = 0;
+	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
+	if (live) {
+		x        = load_vector_f32(in, v, lane);
+		d.scheme = rgp->scheme;
+		u32x4* lv = reinterpret_cast<u32x4*>(L.vals);
+		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
+			int e, f;
+			if (rgp->k > 1) {
+				second_level_select_f32(x, rgp, L, lane, e, f);
+			} else {
+				e = rgp->combos[0];
+				f = rgp->combos[1];
+			}
+			AlpEncodedF R;
+			encode_alp_registers_f32(x, e, f, lane, R);
+			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
+			cnt   = R.cnt;
+			flags = R.flags;
+			const uint32_t base = static_cast<uint32_t>(R.base);
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				u32x4 q;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					q[j]          = static_cast<uint32_t>(R.enc[m][j]) - base;
+					ballots[m][j] = R.ballot[m][j];
+				}
+				lv[64 * m + lane] = q;
+			}
+		} else {
+			// rd.hpp:109-147: right = bits & mask, left = bits >> rbw; left -> dictionary index, not found = exception.
+			// Left index streams: value i -> lane64 = i & 63 = 4*(lane & 15) + j, row = i >> 6 = 4*m + (lane >> 4).
+			const int      rbw   = rgp->rd_rbw;
+			const int      lbw   = rgp->rd_lbw;
+			const int      ds    = rgp->rd_dict_size;
+			const uint32_t rmask = bw_mask32(rbw);
+			const uint64_t lmask = (1ull << lbw) - 1ull;
+			d.bw = static_cast<uint8_t>(rbw), d.lbw = static_cast<uint8_t>(lbw);
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				u32x4     q;
+				const int row = 4 * m + (lane >> 4);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const uint32_t bits = __float_as_uint(x.x[m][j]);
+					q[j]                = bits & rmask;
+					const uint32_t left = (bits >> rbw) & 0xFFFFu;
+					int            idx  = ds;
+#pragma unroll
+					for (int dd = 7; dd >= 0; --dd) {
+						if (dd < ds && rgp->rd_dict[dd] == left) { idx = dd; }
+					}
+					const bool exc = idx == ds;
+					ballots[m][j]  = __ballot(exc);
+					flags |= exc ? (1u << (4 * m + j)) : 0u;
+					cnt += __builtin_popcountll(ballots[m][j]);
+					lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
+				}
+				lv[64 * m + lane] = q;
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 16));
+				lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 32));
+			}
+		}
+		d.exc_cnt = static_cast<uint16_t>(cnt);
+	}
+	uint64_t my_p = 0, my_e = 0;
+	if (live) { desc_sizes_f32(d, my_p, my_e); }
+	if (lane == 0) {
+		s_size[wave]           = status_pack(0, my_p >> 7, my_e >> 3);
+		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (arrived == kWavesPerWg - 1 && tile != 0) {
+			uint64_t aggregate = 0;
+#pragma unroll
+			for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+			uint64_t expected = 0;
+			__hip_atomic_compare_exchange_strong(status + tile, &expected, kFlagAggregate | aggregate, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+			                                     __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
+	{
+		uint32_t spins = 0;
+		while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+			if (++spins > 64u * kSpinLimit) { return; }
+			__builtin_amdgcn_s_sleep(2);
+		}
+	}
+	uint64_t local = 0;
+#pragma unroll
+	for (int w = 0; w < kWavesPerWg; ++w) { local += w < wave ? s_size[w] : 0; }
+	const uint64_t excl = s_excl;
+	if (excl == ~0ull) { return; }
+
+	const uint64_t base_p = totals[0], base_e = totals[1];
+	const uint64_t pre    = excl + local;
+	d.packed_off          = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
+	d.exc_off             = base_e + (pre & 0x7FFFFFFFull) * 8ull;
+	if (!live) { return; }
+	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) {
+		if (lane == 0) { __hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		return;
+	}
+	uint8_t* dst = packed + d.packed_off;
+	uint8_t* rec = excs + d.exc_off;
+	if (cnt > 0) {
+		const bool alp  = d.scheme == ALPGPU_SCHEME_ALP;
+		const int  rbw  = d.bw;
+		int        soff = 0;
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (flags & (1u << (4 * m + j))) {
+					const int      r    = exception_rank_f32(ballots, flags, m, j, lane, soff);
+					const uint32_t bits = __float_as_uint(x.x[m][j]);
+					const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
+					if (alp) {
+						reinterpret_cast<uint32_t*>(rec)[r]              = bits;
+						reinterpret_cast<uint16_t*>(rec + 4ull * cnt)[r] = pos;
+					} else {
+						reinterpret_cast<uint16_t*>(rec)[r]              = static_cast<uint16_t>(bits >> rbw);
+						reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
+					}
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { soff += __builtin_popcountll(ballots[m][j]); }
+		}
+	}
+	pack_u32_from_lds(L, d.bw, reinterpret_cast<u32x4*>(dst), lane);
+	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 16) {
+		uint64_t* out64 = reinterpret_cast<uint64_t*>(dst + 128ull * d.bw);
+		for (int k = 0; k < d.lbw; ++k) { // word k of lane64 columns 4*lane .. 4*lane+3
+			uint64_t w = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { w |= ((lacc[j] >> (16 * k)) & 0xFFFFull) << (16 * j); }
+			out64[16 * k + lane] = w;
+		}
+	}
+	if (lane == 0) { descs[v] = d; }
+}
+
+__global__ void k_fused_finish_f32(uint64_t* __restrict__ totals) {
+	totals[0] = totals[4];
+	totals[1] = totals[5];
+}
+
+int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+	for (uint64_t first = 0; first < n_vectors; first += kFusedMaxVectors) {
+		const uint64_t n_launch = n_vectors - first < kFusedMaxVectors ? n_vectors - first : kFusedMaxVectors;
+		const uint64_t n_tiles  = (n_launch + kWavesPerWg - 1) / kWavesPerWg;
+		if (hipMemsetAsync(d_workspace, 0, n_tiles * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		hipLaunchKernelGGL(k_encode_fused_f32, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
+		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
+		                   n_launch);
+		hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(1), 0, stream, col->d_totals);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+} // namespace alpgpu

@@ -13,23 +13,22 @@
 // cross-lane traffic until the final arg-min.  The candidate order (e = 18..0, f = e..0) and the reference's
 // update rule make the winner "the first candidate in that order with the minimum estimated size", i.e. the
 // minimum of (size, candidate index).
-#include "alp_device.hpp"
+#include "alp_device_f32.hpp"
 #include "launch.hpp"
 
 namespace alpgpu {
 
 constexpr int kMaxSampledVectors = 9; // ceil(100 / 12)
-constexpr int kNumCombos         = 190;
 constexpr int kInitThreads       = 64 * kMaxSampledVectors;
 
 struct ComboTable {
 	uint8_t e[192];
 	uint8_t f[192];
 };
-constexpr ComboTable make_combo_table() {
+constexpr ComboTable make_combo_table(int max_exponent) {
 	ComboTable t {};
 	int        c = 0;
-	for (int e = 18; e >= 0; --e) {
+	for (int e = max_exponent; e >= 0; --e) {
 		for (int f = e; f >= 0; --f) {
 			t.e[c] = static_cast<uint8_t>(e);
 			t.f[c] = static_cast<uint8_t>(f);
@@ -38,7 +37,53 @@ constexpr ComboTable make_combo_table() {
 	}
 	return t;
 }
-__device__ __constant__ const ComboTable kCombos = make_combo_table();
+__device__ __constant__ const ComboTable kCombos64 = make_combo_table(18); // Constants<double>::MAX_EXPONENT: 190 candidates
+__device__ __constant__ const ComboTable kCombos32 = make_combo_table(10); // Constants<float>::MAX_EXPONENT: 66 candidates
+
+// What differs between alp::encoder<double> and alp::encoder<float> in the rowgroup search (constants.hpp:30-64 / :66-154).
+// Encoded integers travel as int64 in both (sign-extended for float).
+struct PrecF64 {
+	using value_t = double;
+	static constexpr int      kBits        = 64;
+	static constexpr int      kNumCombos   = 190;
+	static constexpr uint32_t kExcBits     = 64u;        // EXCEPTION_SIZE
+	static constexpr uint32_t kRdThreshold = 48u * 32u;  // RD_SIZE_THRESHOLD_LIMIT
+	static constexpr int64_t  kEncMin = INT64_MIN, kEncMax = INT64_MAX;
+	struct Coef {
+		double  exp10, frac_f, frac_e;
+		int64_t fact;
+	};
+	static __device__ __forceinline__ const ComboTable& combos() { return kCombos64; }
+	static __device__ __forceinline__ Coef coef(int e, int f) { return Coef {kExpArr[e], kFracArr[f], kFracArr[e], kFactArr[f]}; }
+	// encode_value<true> + decode_value + compare (encoder.hpp:172-175)
+	static __device__ __forceinline__ bool roundtrip(double v, const Coef& c, int64_t& enc) {
+		enc = encode_value_safe(v, c.exp10, c.frac_f);
+		return decode_value(enc, c.fact, c.frac_e) == v;
+	}
+	static __device__ __forceinline__ int      bits(int64_t mx, int64_t mn) { return count_bits(mx, mn); }
+	static __device__ __forceinline__ uint64_t pattern(double v) { return static_cast<uint64_t>(__double_as_longlong(v)); }
+};
+struct PrecF32 {
+	using value_t = float;
+	static constexpr int      kBits        = 32;
+	static constexpr int      kNumCombos   = 66;
+	static constexpr uint32_t kExcBits     = 32u;
+	static constexpr uint32_t kRdThreshold = 22u * 32u;
+	static constexpr int64_t  kEncMin = INT32_MIN, kEncMax = INT32_MAX;
+	struct Coef {
+		float    exp10, frac_f, frac_e;
+		uint32_t fact;
+	};
+	static __device__ __forceinline__ const ComboTable& combos() { return kCombos32; }
+	static __device__ __forceinline__ Coef coef(int e, int f) { return Coef {kExpArrF[e], kFracArrF[f], kFracArrF[e], kFactArrF[f]}; }
+	static __device__ __forceinline__ bool roundtrip(float v, const Coef& c, int64_t& enc) {
+		const int32_t q = encode_value_f32(v, c.exp10, c.frac_f); // the SAFE branch does not exist as built (alp_device_f32.hpp)
+		enc             = q;
+		return decode_value_f32(q, c.fact, c.frac_e) == v;
+	}
+	static __device__ __forceinline__ int      bits(int64_t mx, int64_t mn) { return count_bits32(static_cast<int32_t>(mx), static_cast<int32_t>(mn)); }
+	static __device__ __forceinline__ uint64_t pattern(float v) { return static_cast<uint64_t>(__float_as_uint(v)); }
+};
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
@@ -97,10 +142,10 @@ __device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, const uint64_t* 
 // find_top_k_combinations / find_best_dictionary receive): workgroup b reads n_vectors (= its sample count, <= 288)
 // doubles at in + 288*b.  Used by the per-rowgroup entry point behind include/alp.hpp, where the column may end in
 // a partial vector and the sampler's index rules (sampler.hpp:29-44) are applied on the host.
-template <bool FROM_SAMPLES>
-__global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __restrict__ in, uint64_t n_vectors,
+template <class P, bool FROM_SAMPLES>
+__global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
                                                                 alpgpu_rowgroup_state* __restrict__ rgs, int force_rd) {
-	__shared__ double   smp[kMaxSampledVectors * 32];
+	__shared__ typename P::value_t smp[kMaxSampledVectors * 32];
 	__shared__ uint32_t best_key[kMaxSampledVectors];
 	__shared__ uint64_t      s_key[kMaxSamples]; // samples sorted by bit pattern (ALP_RD)
 	__shared__ uint16_t      s_idx[kMaxSamples]; // original sample index of each sorted entry
@@ -140,31 +185,25 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 	if (wave < n_sv && !force_rd) {
 		uint32_t my_key = 0xFFFFFFFFu;
 #pragma unroll 1
-		for (int r = 0; r < 3; ++r) {
+		for (int r = 0; r < (P::kNumCombos + 63) / 64; ++r) {
 			const int c = lane + 64 * r;
-			if (c < kNumCombos) {
-				const int     e      = kCombos.e[c];
-				const int     f      = kCombos.f[c];
-				const double  exp10  = kExpArr[e];
-				const double  frac_f = kFracArr[f];
-				const int64_t fact   = kFactArr[f];
-				const double  frac_e = kFracArr[e];
-				int           non_exc = 0;
-				int64_t       mx = INT64_MIN, mn = INT64_MAX;
+			if (c < P::kNumCombos) {
+				const typename P::Coef k = P::coef(P::combos().e[c], P::combos().f[c]);
+				int                    non_exc = 0;
+				int64_t                mx = P::kEncMin, mn = P::kEncMax;
 #pragma unroll 4
 				for (int s = 0; s < samples_size; ++s) {
-					const double  v   = smp[wave * 32 + s];
-					const int64_t enc = encode_value_safe(v, exp10, frac_f);
-					const double  dec = decode_value(enc, fact, frac_e);
-					if (dec == v) {
+					const typename P::value_t v = smp[wave * 32 + s];
+					int64_t                   enc;
+					if (P::roundtrip(v, k, enc)) {
 						++non_exc;
 						mx = enc > mx ? enc : mx;
 						mn = enc < mn ? enc : mn;
 					}
 				}
 				if (non_exc >= 2) { // encoder.hpp:182
-					const uint32_t size = static_cast<uint32_t>(samples_size) * static_cast<uint32_t>(count_bits(mx, mn)) +
-					                      static_cast<uint32_t>(samples_size - non_exc) * 80u;
+					const uint32_t size = static_cast<uint32_t>(samples_size) * static_cast<uint32_t>(P::bits(mx, mn)) +
+					                      static_cast<uint32_t>(samples_size - non_exc) * (P::kExcBits + 16u);
 					const uint32_t key  = (size << 8) | static_cast<uint32_t>(c);
 					my_key              = key < my_key ? key : my_key;
 				}
@@ -177,7 +216,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 
 	// ---- vote, scheme decision, top-k (encoder.hpp:207-234) ----
 	if (tid == 0) {
-		uint32_t best_size = static_cast<uint32_t>(samples_size) * (64u + 16u) + static_cast<uint32_t>(samples_size) * 64u; // encoder.hpp:147-149
+		uint32_t best_size = static_cast<uint32_t>(samples_size) * (P::kExcBits + 16u) + static_cast<uint32_t>(samples_size) * P::kExcBits; // encoder.hpp:147-149
 		int      ce[kMaxSampledVectors], cf[kMaxSampledVectors], cn[kMaxSampledVectors];
 		int      n_c = 0;
 		for (int w = 0; w < n_sv; ++w) {
@@ -185,8 +224,8 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 			if (best_key[w] != 0xFFFFFFFFu) {
 				const int      c    = static_cast<int>(best_key[w] & 0xFFu);
 				const uint32_t size = best_key[w] >> 8;
-				e                   = kCombos.e[c];
-				f                   = kCombos.f[c];
+				e                   = P::combos().e[c];
+				f                   = P::combos().f[c];
 				best_size           = size < best_size ? size : best_size;
 			}
 			int hit = -1;
@@ -205,7 +244,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 		for (int i = 0; i < 10; ++i) { st.combos[i] = 0; }
 		st.rd_rbw = st.rd_lbw = st.rd_dict_size = st.pad = 0;
 		for (int i = 0; i < 8; ++i) { st.rd_dict[i] = 0; }
-		if (force_rd || best_size >= 48u * 32u) { // RD_SIZE_THRESHOLD_LIMIT, encoder.hpp:213-216
+		if (force_rd || best_size >= P::kRdThreshold) { // RD_SIZE_THRESHOLD_LIMIT, encoder.hpp:213-216
 			st.scheme = ALPGPU_SCHEME_ALP_RD;
 		} else {
 			st.scheme = ALPGPU_SCHEME_ALP;
@@ -242,10 +281,10 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 	// (sample t sits at smp[32 * (t / samples_size) + t % samples_size]; with 32-sample blocks that is smp[t])
 	auto smp_at = [&](int t) { return smp[32 * (t / samples_size) + (t % samples_size)]; };
 	if (tid < n_smp) {
-		const uint64_t key  = static_cast<uint64_t>(__double_as_longlong(smp_at(tid)));
+		const uint64_t key  = P::pattern(smp_at(tid));
 		int            rank = 0;
 		for (int j = 0; j < n_smp; ++j) {
-			const uint64_t kj = static_cast<uint64_t>(__double_as_longlong(smp_at(j)));
+			const uint64_t kj = P::pattern(smp_at(j));
 			rank += (kj < key || (kj == key && j < tid)) ? 1 : 0;
 		}
 		s_key[rank] = key;
@@ -255,7 +294,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 
 	RdWaveScratch& W = s_rd[wave];
 	for (int cut = wave + 1; cut <= 16; cut += kMaxSampledVectors) { // wave-uniform
-		const int rbw = 64 - cut;
+		const int rbw = P::kBits - cut;
 		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
 		// histogram of run lengths; number of distinct left parts
 		int distinct = 0;
@@ -311,7 +350,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 	__syncthreads();
 	if (wave == 0) { // the dictionary of the chosen cut: the (<= 8) best-ranked runs
 		const int best_cut = s_best_cut;
-		const int rbw      = 64 - best_cut;
+		const int rbw      = P::kBits - best_cut;
 		const int ds       = s_cut_ds[best_cut];
 		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
 		for (int b = 0; b < n_smp; b += 64) {
@@ -339,12 +378,26 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const double* __
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs) {
 	if (n_vectors == 0) { return ALPGPU_OK; }
 	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
-	hipLaunchKernelGGL(k_rowgroup_init<false>, dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0);
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
-	hipLaunchKernelGGL(k_rowgroup_init<true>, dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, true>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
+	                   force_rd);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// single precision: alp::encoder<float>::init / alp::rd_encoder<float>::init
+int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs) {
+	if (n_vectors == 0) { return ALPGPU_OK; }
+	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, true>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
 	                   force_rd);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

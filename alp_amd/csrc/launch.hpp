@@ -51,4 +51,27 @@ int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t*
                      const alpgpu_rowgroup_state* states, const uint32_t* idx, const uint16_t* exc, const uint16_t* pos, size_t stride,
                      const uint16_t* cnt, uint64_t n);
 
+
+// ---- single precision (decode_f32_kernels.hip, encode_f32_kernels.hip, init_kernels.hip, primitive_f32_kernels.hip) ----
+int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores);
+int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs);
+int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
+int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace);
+int launch_pad_tail_f32(hipStream_t stream, float* d_in, uint64_t n_values);
+int launch_ffor_i32(hipStream_t stream, int n_cus, const int32_t* in, int32_t* packed, size_t stride, const uint8_t* bw, const int32_t* base, uint64_t n);
+int launch_unffor_i32(hipStream_t stream, int n_cus, const int32_t* packed, size_t stride, int32_t* out, const uint8_t* bw, const int32_t* base, uint64_t n);
+int launch_falp_f32(hipStream_t stream, int n_cus, const int32_t* packed, size_t stride, float* out, const uint8_t* bw, const int32_t* base,
+                    const uint8_t* fac, const uint8_t* exp, uint64_t n);
+int launch_decode_values_f32(hipStream_t stream, int n_cus, const int32_t* enc, float* out, const uint8_t* fac, const uint8_t* exp, uint64_t n);
+int launch_patch_f32(hipStream_t stream, int n_cus, float* out, const float* exc, const uint16_t* pos, size_t stride, const uint16_t* cnt, uint64_t n);
+int launch_analyze_ffor_i32(hipStream_t stream, int n_cus, const int32_t* enc, uint8_t* bw, int32_t* base, uint64_t n);
+int launch_encode_simdized_f32(hipStream_t stream, int n_cus, const float* in, float* exc, uint16_t* pos, size_t stride, uint16_t* cnt, int32_t* enc,
+                               const uint8_t* fac, const uint8_t* exp, uint64_t n);
+int launch_encode_values_f32(hipStream_t stream, int n_cus, const float* in, const alpgpu_rowgroup_state* states, const uint32_t* idx, float* exc,
+                             uint16_t* pos, size_t stride, uint16_t* cnt, int32_t* enc, uint8_t* fac, uint8_t* exp, uint64_t n);
+int launch_rd_encode_f32(hipStream_t stream, int n_cus, const float* in, const alpgpu_rowgroup_state* states, const uint32_t* idx, uint16_t* exc,
+                         uint16_t* pos, size_t stride, uint16_t* cnt, uint32_t* right, uint16_t* left, uint64_t n);
+int launch_rd_decode_f32(hipStream_t stream, int n_cus, float* out, const uint32_t* right, const uint16_t* left, const alpgpu_rowgroup_state* states,
+                         const uint32_t* idx, const uint16_t* exc, const uint16_t* pos, size_t stride, const uint16_t* cnt, uint64_t n);
+
 } // namespace alpgpu

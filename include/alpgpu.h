@@ -210,7 +210,7 @@ typedef struct alpgpu_blob_header {
 	uint64_t n_rowgroups;
 	uint64_t packed_bytes;
 	uint64_t exc_bytes;
-	uint64_t reserved;
+	uint64_t reserved;       /* value type: 0 or 8 = double column, 4 = float column */
 } alpgpu_blob_header;
 uint64_t alpgpu_blob_size(uint64_t n_vectors, uint64_t packed_bytes, uint64_t exc_bytes);
 int      alpgpu_column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity,
@@ -264,6 +264,55 @@ int alpgpu_rd_decode_vectors_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t*
                                  const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
                                  const uint16_t* d_exc, const uint16_t* d_pos, size_t exc_stride,
                                  const uint16_t* d_cnt, uint64_t n_vectors);
+
+/* ==== single precision ====================================================================
+ * The float instantiation of the same API: alp::encoder<float> / decoder<float> / rd_encoder<float> (same files and
+ * lines as the double entries above), Constants<float> include/alp/constants.hpp:30-64 (66 (e,f) candidates, exception
+ * cost 32+16 bits, ALP_RD threshold 22*32), falp float include/alp/falp.hpp:28-44, 32-bit FFOR
+ * src/fastlanes_generated_ffor.cpp:1776-7378 (32 lanes x 32 rows).  The column records are the same structs with
+ *   packed stream : ALP 128*bw bytes (bw 0..32); ALP_RD 128*rbw (right, u32 lanes, rbw 16..31) then 128*lbw (left, u16 lanes)
+ *   exception rec.: ALP cnt*4 B values (f32 bits) then cnt*2 B positions; ALP_RD cnt*2 B left parts then cnt*2 B positions;
+ *                   rounded up to 8 bytes
+ *   vector_desc.base: the int32 frame-of-reference base, sign-extended.
+ * A column encoded by the _f32 functions must be decoded by alpgpu_decode_f32 (the records do not carry the value type;
+ * blobs do: alpgpu_blob_header.reserved = 4 for float columns).
+ * Behaviour where the reference's float code is undefined in C++ (out-of-range float->int32 casts, the SAFE branch of
+ * encode_value, FACT_ARR[10]) follows the reference AS BUILT with Clang, pinned by oracle/alp_oracle_f32.c (see its header). */
+uint64_t alpgpu_packed_capacity_f32(uint64_t n_vectors); /* worst case n_vectors * 4352 */
+uint64_t alpgpu_exc_capacity_f32(uint64_t n_vectors);    /* worst case n_vectors * 6144 */
+int alpgpu_rowgroup_init_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
+int alpgpu_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
+int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
+int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
+int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
+/* ALPGPU_OPT_DECODE_VECTORS_PER_WG applies with values 0 (auto), 1, 2 and, for float only, 4 */
+int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
+int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values);
+int alpgpu_column_to_blob_f32(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);
+int alpgpu_column_from_blob_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values);
+/* batch primitives, 32-bit lanes (same conventions as the 64-bit ones above) */
+int alpgpu_ffor_i32(alpgpu_ctx* ctx, const int32_t* d_in, int32_t* d_packed, size_t packed_stride, const uint8_t* d_bw,
+                    const int32_t* d_base, uint64_t n_vectors);
+int alpgpu_unffor_i32(alpgpu_ctx* ctx, const int32_t* d_packed, size_t packed_stride, int32_t* d_out, const uint8_t* d_bw,
+                      const int32_t* d_base, uint64_t n_vectors);
+int alpgpu_falp_f32(alpgpu_ctx* ctx, const int32_t* d_packed, size_t packed_stride, float* d_out, const uint8_t* d_bw,
+                    const int32_t* d_base, const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors);
+int alpgpu_decode_values_f32(alpgpu_ctx* ctx, const int32_t* d_enc, float* d_out, const uint8_t* d_fac, const uint8_t* d_exp,
+                             uint64_t n_vectors);
+int alpgpu_patch_f32(alpgpu_ctx* ctx, float* d_out, const float* d_exc, const uint16_t* d_pos, size_t exc_stride,
+                     const uint16_t* d_cnt, uint64_t n_vectors);
+int alpgpu_encode_simdized_f32(alpgpu_ctx* ctx, const float* d_in, float* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt,
+                               int32_t* d_enc, const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors);
+int alpgpu_encode_values_f32(alpgpu_ctx* ctx, const float* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
+                             float* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, int32_t* d_enc, uint8_t* d_fac,
+                             uint8_t* d_exp, uint64_t n_vectors);
+int alpgpu_analyze_ffor_i32(alpgpu_ctx* ctx, const int32_t* d_enc, uint8_t* d_bw, int32_t* d_base, uint64_t n_vectors);
+int alpgpu_rd_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
+                                 uint16_t* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, uint32_t* d_right,
+                                 uint16_t* d_left, uint64_t n_vectors);
+int alpgpu_rd_decode_vectors_f32(alpgpu_ctx* ctx, float* d_out, const uint32_t* d_right, const uint16_t* d_left,
+                                 const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx, const uint16_t* d_exc,
+                                 const uint16_t* d_pos, size_t exc_stride, const uint16_t* d_cnt, uint64_t n_vectors);
 
 #ifdef __cplusplus
 }
