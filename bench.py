@@ -330,6 +330,36 @@ def main():
                              "roofline_frac_algorithmic": round((ne * 8192 + pb + eb + 13 * ne) / med / 1e6 / HBM_PEAK_GBPS, 4),
                              "decode_GBps": round(ne * 8192 / dmed / 1e6, 1), "gpu_roundtrip_bit_exact": rt}
             del x, ecol
+        # single precision: alpgpu_encode_f32 / alpgpu_decode_f32 on 1 Mi float vectors (4 GiB decoded)
+        fl = {}
+        outf = out.view(torch.float32)[: n * VEC]
+        for kind in ("decimal_mixed", "rd"):
+            g = torch.Generator(device=dev)
+            g.manual_seed(43)
+            if kind == "rd":
+                xf = torch.rand(n * VEC, dtype=torch.float32, device=dev, generator=g)
+            else:  # one- and two-decimal values in +-1000 (cycling per rowgroup), 1 % full-precision values, 0.1 % specials
+                xd = (torch.rand(n * VEC, dtype=torch.float64, device=dev, generator=g) - 0.5) * 2e3
+                sc = torch.where((torch.arange((n + 99) // 100, device=dev) % 2 == 0), 10.0, 100.0).to(torch.float64).repeat_interleave(100 * VEC)[: n * VEC]
+                xf = (torch.round(xd * sc) / sc).to(torch.float32)
+                m = torch.rand(n * VEC, device=dev, generator=g) < 0.01
+                xf[m] = (xd[m] * 3.141592653589793).to(torch.float32)
+                sp = torch.rand(n * VEC, device=dev, generator=g) < 0.001
+                specials = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0], dtype=torch.float32, device=dev)
+                xf[sp] = specials[torch.randint(0, 4, (int(sp.sum()),), device=dev, generator=g)]
+                del xd, sc, m, sp
+            fcol = capi.DeviceColumn(n, local_rank, dtype="f32")
+            emed, _ = time_launches(lambda: ctx.encode(xf, fcol), 3, 1)
+            pb, eb, ov = ctx.column_totals(fcol)
+            dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 5, 2)
+            rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
+            fl[kind] = {"vectors": n, "encode_input_GBps": round(n * 4096 / emed / 1e6, 1), "encode_ms": round(emed, 3),
+                        "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
+                        "decode_GBps_decoded_floats": round(n * 4096 / dmed / 1e6, 1), "decode_ms": round(dmed, 3),
+                        "decode_roofline_frac_algorithmic": round((n * (4096 + 13) + pb + eb) / dmed / 1e6 / HBM_PEAK_GBPS, 4),
+                        "gpu_roundtrip_bit_exact": rt}
+            del xf, fcol
+        extras["float_path"] = fl
         result["extras"] = extras
         ctx.decode(col, out)
         torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-// alp/constants.hpp — public constants of the codec (reference include/alp/constants.hpp:10-25, :66-154 for double).
+// alp/constants.hpp — public constants of the codec (reference include/alp/constants.hpp:10-25, :30-64 float, :66-154 double).
 // Host code only needs them for sizing and bookkeeping; the arithmetic tables live in the device code
 // (alp_amd/csrc/alp_device.hpp) and are bit-identical.
 #ifndef ALP_CONSTANTS_HPP
@@ -35,6 +35,19 @@ struct Constants<double> {
 	static inline constexpr uint64_t POSITIVE_INF            = 0x7FF0000000000000ULL;
 	static inline constexpr uint64_t NEGATIVE_INF            = 0xFFF0000000000000ULL;
 	static inline constexpr uint64_t SIGN_BIT_MASK           = 0x7FFFFFFFFFFFFFFFULL;
+};
+
+template <>
+struct Constants<float> {
+	static inline constexpr size_t   RD_SIZE_THRESHOLD_LIMIT = 22 * config::SAMPLES_PER_VECTOR;
+	static inline constexpr float    MAGIC_NUMBER            = 12582912.0f; // 2^23 + 2^22
+	static inline constexpr uint8_t  EXCEPTION_SIZE          = 32;
+	static inline constexpr uint8_t  EXCEPTION_SIZE_BYTES    = EXCEPTION_SIZE / 8;
+	static inline constexpr uint8_t  MAX_EXPONENT            = 10;
+	static inline constexpr uint32_t NEGATIVE_ZERO           = 0x80000000u;
+	static inline constexpr uint32_t POSITIVE_INF            = 0x7F800000u;
+	static inline constexpr uint32_t NEGATIVE_INF            = 0xFF800000u;
+	static inline constexpr uint32_t SIGN_BIT_MASK           = 0x7FFFFFFFu;
 };
 
 } // namespace alp

@@ -15,21 +15,25 @@ struct inner_t<double> {
 	using ut = uint64_t;
 	using st = int64_t;
 };
+template <>
+struct inner_t<float> {
+	using ut = uint32_t;
+	using st = int32_t;
+};
 
 template <class PT>
 struct decoder {
-	static_assert(sizeof(PT) == 8, "this build provides the double-precision path (float is SURVEY.md §8(f) item 2)");
 	using UT = typename inner_t<PT>::ut;
 	using ST = typename inner_t<PT>::st;
 
-	//! decode of a whole vector: output[i] = double(encoded[i] * FACT[fac]) * FRAC[exp]   (decoder.hpp:134-138)
+	//! decode of a whole vector: output[i] = PT(encoded[i] * FACT[fac]) * FRAC[exp]   (decoder.hpp:134-138)
 	static inline void decode(const ST* encoded_integers, const uint8_t fac_idx, const uint8_t exp_idx, PT* output) {
 		auto& s = gpu::tls();
-		gpu::h2d(s.at<ST>(s.ENC), encoded_integers, 8192);
+		gpu::h2d(s.at<ST>(s.ENC), encoded_integers, gpu::abi<PT>::VEC_BYTES);
 		const uint8_t fe[2] = {fac_idx, exp_idx};
 		gpu::h2d(s.fac(), fe, 2);
-		gpu::check(alpgpu_decode_values_f64(gpu::context(), s.at<ST>(s.ENC), s.at<PT>(s.OUT), s.fac(), s.exp(), 1), "alpgpu_decode_values_f64");
-		gpu::d2h(output, s.at<PT>(s.OUT), 8192);
+		gpu::check(gpu::abi<PT>::decode_values(s.at<ST>(s.ENC), s.at<PT>(s.OUT), s.fac(), s.exp()), "alpgpu_decode_values");
+		gpu::d2h(output, s.at<PT>(s.OUT), gpu::abi<PT>::VEC_BYTES);
 	}
 
 	//! single value (decoder.hpp:128-131); goes through the vector kernel like everything else in this header
@@ -46,12 +50,12 @@ struct decoder {
 		const exp_c_t n = exceptions_count[0];
 		if (n == 0) { return; }
 		auto& s = gpu::tls();
-		gpu::h2d(s.at<PT>(s.OUT), out, 8192);
-		gpu::h2d(s.at<PT>(s.EXC), exceptions, static_cast<size_t>(n) * 8);
+		gpu::h2d(s.at<PT>(s.OUT), out, gpu::abi<PT>::VEC_BYTES);
+		gpu::h2d(s.at<PT>(s.EXC), exceptions, static_cast<size_t>(n) * sizeof(PT));
 		gpu::h2d(s.at<exp_p_t>(s.POS), exceptions_positions, static_cast<size_t>(n) * 2);
 		gpu::h2d(s.cnt(), &n, 2);
-		gpu::check(alpgpu_patch_f64(gpu::context(), s.at<PT>(s.OUT), s.at<PT>(s.EXC), s.at<exp_p_t>(s.POS), 1024, s.cnt(), 1), "alpgpu_patch_f64");
-		gpu::d2h(out, s.at<PT>(s.OUT), 8192);
+		gpu::check(gpu::abi<PT>::patch(s.at<PT>(s.OUT), s.at<PT>(s.EXC), s.at<exp_p_t>(s.POS), s.cnt()), "alpgpu_patch");
+		gpu::d2h(out, s.at<PT>(s.OUT), gpu::abi<PT>::VEC_BYTES);
 	}
 };
 

@@ -69,9 +69,8 @@ inline alpgpu_rowgroup_state state_from_samples(const PT* sample_arr, size_t n_s
 	const size_t n_block = (n_samples + config::SAMPLES_PER_VECTOR - 1) / config::SAMPLES_PER_VECTOR;
 	const size_t n_up    = n_samples < config::SAMPLES_PER_VECTOR ? n_samples : n_block * config::SAMPLES_PER_VECTOR;
 	h2d(s.template at<PT>(s.SAMPLES), sample_arr, n_up * sizeof(PT));
-	check(alpgpu_state_from_samples_f64(context(), s.template at<PT>(s.SAMPLES), static_cast<uint32_t>(n_samples),
-	                                    s.template at<alpgpu_rowgroup_state>(s.STATE)),
-	      "alpgpu_state_from_samples_f64");
+	check(abi<PT>::state_from_samples(s.template at<PT>(s.SAMPLES), static_cast<uint32_t>(n_samples), s.template at<alpgpu_rowgroup_state>(s.STATE)),
+	      "alpgpu_state_from_samples");
 	alpgpu_rowgroup_state d {};
 	d2h(&d, s.template at<alpgpu_rowgroup_state>(s.STATE), sizeof(d));
 	return d;
@@ -115,11 +114,11 @@ struct encoder {
 	                          state<PT>& stt) {
 		auto&                       s = gpu::tls();
 		const alpgpu_rowgroup_state d = gpu::to_device_state(stt);
-		gpu::h2d(s.at<PT>(s.IN), input_vector, 8192);
+		gpu::h2d(s.at<PT>(s.IN), input_vector, gpu::abi<PT>::VEC_BYTES);
 		gpu::h2d(s.at<alpgpu_rowgroup_state>(s.STATE), &d, sizeof(d));
-		gpu::check(alpgpu_encode_values_f64(gpu::context(), s.at<PT>(s.IN), s.at<alpgpu_rowgroup_state>(s.STATE), nullptr, s.at<PT>(s.EXC),
-		                                    s.at<uint16_t>(s.POS), 1024, s.cnt(), s.at<ST>(s.ENC), s.fac(), s.exp(), 1),
-		           "alpgpu_encode_values_f64");
+		gpu::check(gpu::abi<PT>::encode_values(s.at<PT>(s.IN), s.at<alpgpu_rowgroup_state>(s.STATE), s.at<PT>(s.EXC), s.at<uint16_t>(s.POS), s.cnt(),
+		                                       s.at<ST>(s.ENC), s.fac(), s.exp()),
+		           "alpgpu_encode_values");
 		fetch_encoded(s, exceptions, exceptions_positions, exceptions_count, encoded_integers);
 		uint8_t fe[2];
 		gpu::d2h(fe, s.fac(), 2);
@@ -137,33 +136,32 @@ struct encoder {
 	                                   const exponent_idx_t exponent_idx) {
 		auto&         s     = gpu::tls();
 		const uint8_t fe[2] = {factor_idx, exponent_idx};
-		gpu::h2d(s.at<PT>(s.IN), input_vector, 8192);
+		gpu::h2d(s.at<PT>(s.IN), input_vector, gpu::abi<PT>::VEC_BYTES);
 		gpu::h2d(s.fac(), fe, 2);
-		gpu::check(alpgpu_encode_simdized_f64(gpu::context(), s.at<PT>(s.IN), s.at<PT>(s.EXC), s.at<uint16_t>(s.POS), 1024, s.cnt(),
-		                                      s.at<ST>(s.ENC), s.fac(), s.exp(), 1),
-		           "alpgpu_encode_simdized_f64");
+		gpu::check(gpu::abi<PT>::encode_simdized(s.at<PT>(s.IN), s.at<PT>(s.EXC), s.at<uint16_t>(s.POS), s.cnt(), s.at<ST>(s.ENC), s.fac(), s.exp()),
+		           "alpgpu_encode_simdized");
 		fetch_encoded(s, exceptions, exceptions_positions, exceptions_count, encoded_integers);
 	}
 
 	// encode_value / is_impossible_to_encode / count_bits (encoder.hpp:75-106) are internals of the reference's encoder that no
-	// caller outside include/alp/ uses; their arithmetic lives only in the device code (alp_amd/csrc/alp_device.hpp).
+	// caller outside include/alp/ uses; their arithmetic lives only in the device code (alp_amd/csrc/alp_device.hpp, alp_device_f32.hpp).
 
 	//! min/max -> frame-of-reference base and bit width (encoder.hpp:109-120)
 	static inline void analyze_ffor(const ST* input_vector, bw_t& bit_width, ST* base_for) {
 		auto& s = gpu::tls();
-		gpu::h2d(s.at<ST>(s.ENC), input_vector, 8192);
-		gpu::check(alpgpu_analyze_ffor_i64(gpu::context(), s.at<ST>(s.ENC), s.bw(), s.ffor_base(), 1), "alpgpu_analyze_ffor_i64");
+		gpu::h2d(s.at<ST>(s.ENC), input_vector, gpu::abi<PT>::VEC_BYTES);
+		gpu::check(gpu::abi<PT>::analyze_ffor(s.at<ST>(s.ENC), s.bw(), s.at<ST>(s.META + 8)), "alpgpu_analyze_ffor");
 		gpu::d2h(&bit_width, s.bw(), 1);
-		gpu::d2h(base_for, s.ffor_base(), 8);
+		gpu::d2h(base_for, s.at<ST>(s.META + 8), sizeof(ST));
 	}
 
 private:
 	static inline void fetch_encoded(gpu::scratch& s, PT* exceptions, uint16_t* positions, uint16_t* count, ST* encoded) {
 		uint16_t n = 0;
 		gpu::d2h(&n, s.cnt(), 2);
-		gpu::d2h(encoded, s.at<ST>(s.ENC), 8192);
+		gpu::d2h(encoded, s.at<ST>(s.ENC), gpu::abi<PT>::VEC_BYTES);
 		if (n) {
-			gpu::d2h(exceptions, s.at<PT>(s.EXC), static_cast<size_t>(n) * 8);
+			gpu::d2h(exceptions, s.at<PT>(s.EXC), static_cast<size_t>(n) * sizeof(PT));
 			gpu::d2h(positions, s.at<uint16_t>(s.POS), static_cast<size_t>(n) * 2);
 		}
 		*count = n;

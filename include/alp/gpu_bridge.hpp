@@ -44,7 +44,7 @@ struct scratch {
 	T* at(size_t off) const {
 		return reinterpret_cast<T*>(base + off);
 	}
-	// META layout: [0] bw u8, [1] fac u8, [2] exp u8, [8..15] base i64, [16..17] cnt u16, [24..25] base16 u16
+	// META layout: [0] bw u8, [1] fac u8, [2] exp u8, [8..15] base i64 (or i32 in [8..11]), [16..17] cnt u16, [24..25] base16 u16
 	uint8_t*  bw() const { return base + META; }
 	uint8_t*  fac() const { return base + META + 1; }
 	uint8_t*  exp() const { return base + META + 2; }
@@ -57,6 +57,58 @@ inline scratch& tls() {
 	static thread_local scratch s;
 	return s;
 }
+
+// The C ABI has one entry point per precision (…_f64 / …_f32, include/alpgpu.h); the templates of this header pick theirs here.
+template <class PT>
+struct abi;
+template <>
+struct abi<double> {
+	using ST = int64_t;
+	using UT = uint64_t;
+	static constexpr size_t VEC_BYTES = 8192;
+	static int state_from_samples(const double* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_state_from_samples_f64(context(), smp, n, st); }
+	static int rd_state_from_samples(const double* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_rd_state_from_samples_f64(context(), smp, n, st); }
+	static int encode_values(const double* in, const alpgpu_rowgroup_state* st, double* exc, uint16_t* pos, uint16_t* cnt, ST* enc, uint8_t* fac, uint8_t* exp) {
+		return alpgpu_encode_values_f64(context(), in, st, nullptr, exc, pos, 1024, cnt, enc, fac, exp, 1);
+	}
+	static int encode_simdized(const double* in, double* exc, uint16_t* pos, uint16_t* cnt, ST* enc, const uint8_t* fac, const uint8_t* exp) {
+		return alpgpu_encode_simdized_f64(context(), in, exc, pos, 1024, cnt, enc, fac, exp, 1);
+	}
+	static int analyze_ffor(const ST* enc, uint8_t* bw, ST* base) { return alpgpu_analyze_ffor_i64(context(), enc, bw, base, 1); }
+	static int decode_values(const ST* enc, double* out, const uint8_t* fac, const uint8_t* exp) { return alpgpu_decode_values_f64(context(), enc, out, fac, exp, 1); }
+	static int patch(double* out, const double* exc, const uint16_t* pos, const uint16_t* cnt) { return alpgpu_patch_f64(context(), out, exc, pos, 1024, cnt, 1); }
+	static int rd_encode(const double* in, const alpgpu_rowgroup_state* st, uint16_t* exc, uint16_t* pos, uint16_t* cnt, UT* right, uint16_t* left) {
+		return alpgpu_rd_encode_vectors_f64(context(), in, st, nullptr, exc, pos, 1024, cnt, right, left, 1);
+	}
+	static int rd_decode(double* out, const UT* right, const uint16_t* left, const alpgpu_rowgroup_state* st, const uint16_t* exc, const uint16_t* pos,
+	                     const uint16_t* cnt) {
+		return alpgpu_rd_decode_vectors_f64(context(), out, right, left, st, nullptr, exc, pos, 1024, cnt, 1);
+	}
+};
+template <>
+struct abi<float> {
+	using ST = int32_t;
+	using UT = uint32_t;
+	static constexpr size_t VEC_BYTES = 4096;
+	static int state_from_samples(const float* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_state_from_samples_f32(context(), smp, n, st); }
+	static int rd_state_from_samples(const float* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_rd_state_from_samples_f32(context(), smp, n, st); }
+	static int encode_values(const float* in, const alpgpu_rowgroup_state* st, float* exc, uint16_t* pos, uint16_t* cnt, ST* enc, uint8_t* fac, uint8_t* exp) {
+		return alpgpu_encode_values_f32(context(), in, st, nullptr, exc, pos, 1024, cnt, enc, fac, exp, 1);
+	}
+	static int encode_simdized(const float* in, float* exc, uint16_t* pos, uint16_t* cnt, ST* enc, const uint8_t* fac, const uint8_t* exp) {
+		return alpgpu_encode_simdized_f32(context(), in, exc, pos, 1024, cnt, enc, fac, exp, 1);
+	}
+	static int analyze_ffor(const ST* enc, uint8_t* bw, ST* base) { return alpgpu_analyze_ffor_i32(context(), enc, bw, base, 1); }
+	static int decode_values(const ST* enc, float* out, const uint8_t* fac, const uint8_t* exp) { return alpgpu_decode_values_f32(context(), enc, out, fac, exp, 1); }
+	static int patch(float* out, const float* exc, const uint16_t* pos, const uint16_t* cnt) { return alpgpu_patch_f32(context(), out, exc, pos, 1024, cnt, 1); }
+	static int rd_encode(const float* in, const alpgpu_rowgroup_state* st, uint16_t* exc, uint16_t* pos, uint16_t* cnt, UT* right, uint16_t* left) {
+		return alpgpu_rd_encode_vectors_f32(context(), in, st, nullptr, exc, pos, 1024, cnt, right, left, 1);
+	}
+	static int rd_decode(float* out, const UT* right, const uint16_t* left, const alpgpu_rowgroup_state* st, const uint16_t* exc, const uint16_t* pos,
+	                     const uint16_t* cnt) {
+		return alpgpu_rd_decode_vectors_f32(context(), out, right, left, st, nullptr, exc, pos, 1024, cnt, 1);
+	}
+};
 
 inline void h2d(void* d, const void* h, size_t n) { check(alpgpu_memcpy_h2d(context(), d, h, n), "alpgpu_memcpy_h2d"); }
 inline void d2h(void* h, const void* d, size_t n) { check(alpgpu_memcpy_d2h(context(), h, d, n), "alpgpu_memcpy_d2h"); }

@@ -36,9 +36,8 @@ struct rd_encoder {
 		const size_t n_block = (n + config::SAMPLES_PER_VECTOR - 1) / config::SAMPLES_PER_VECTOR;
 		const size_t n_up    = n < config::SAMPLES_PER_VECTOR ? n : n_block * config::SAMPLES_PER_VECTOR;
 		gpu::h2d(s.at<PT>(s.SAMPLES), smp_arr, n_up * sizeof(PT));
-		gpu::check(alpgpu_rd_state_from_samples_f64(gpu::context(), s.at<PT>(s.SAMPLES), static_cast<uint32_t>(n),
-		                                            s.at<alpgpu_rowgroup_state>(s.STATE)),
-		           "alpgpu_rd_state_from_samples_f64");
+		gpu::check(gpu::abi<PT>::rd_state_from_samples(s.at<PT>(s.SAMPLES), static_cast<uint32_t>(n), s.at<alpgpu_rowgroup_state>(s.STATE)),
+		           "alpgpu_rd_state_from_samples");
 		alpgpu_rowgroup_state d {};
 		gpu::d2h(&d, s.at<alpgpu_rowgroup_state>(s.STATE), sizeof(d));
 		stt.right_bit_width              = d.rd_rbw;
@@ -62,15 +61,14 @@ struct rd_encoder {
 	                          state<PT>& stt) {
 		auto&                       s = gpu::tls();
 		const alpgpu_rowgroup_state d = gpu::to_device_state(stt);
-		gpu::h2d(s.at<PT>(s.IN), dbl_arr, 8192);
+		gpu::h2d(s.at<PT>(s.IN), dbl_arr, gpu::abi<PT>::VEC_BYTES);
 		gpu::h2d(s.at<alpgpu_rowgroup_state>(s.STATE), &d, sizeof(d));
-		gpu::check(alpgpu_rd_encode_vectors_f64(gpu::context(), s.at<PT>(s.IN), s.at<alpgpu_rowgroup_state>(s.STATE), nullptr,
-		                                        s.at<uint16_t>(s.EXC), s.at<uint16_t>(s.POS), 1024, s.cnt(), s.at<UT>(s.ENC),
-		                                        s.at<uint16_t>(s.LEFT), 1),
-		           "alpgpu_rd_encode_vectors_f64");
+		gpu::check(gpu::abi<PT>::rd_encode(s.at<PT>(s.IN), s.at<alpgpu_rowgroup_state>(s.STATE), s.at<uint16_t>(s.EXC), s.at<uint16_t>(s.POS), s.cnt(),
+		                                   s.at<UT>(s.ENC), s.at<uint16_t>(s.LEFT)),
+		           "alpgpu_rd_encode_vectors");
 		uint16_t n = 0;
 		gpu::d2h(&n, s.cnt(), 2);
-		gpu::d2h(right_parts, s.at<UT>(s.ENC), 8192);
+		gpu::d2h(right_parts, s.at<UT>(s.ENC), gpu::abi<PT>::VEC_BYTES);
 		gpu::d2h(left_parts, s.at<uint16_t>(s.LEFT), 2048);
 		if (n) {
 			gpu::d2h(exceptions, s.at<uint16_t>(s.EXC), static_cast<size_t>(n) * 2);
@@ -91,7 +89,7 @@ struct rd_encoder {
 		auto&                       s = gpu::tls();
 		const alpgpu_rowgroup_state d = gpu::to_device_state(stt);
 		const uint16_t              n = exceptions_count[0];
-		gpu::h2d(s.at<UT>(s.ENC), unffor_right_arr, 8192);
+		gpu::h2d(s.at<UT>(s.ENC), unffor_right_arr, gpu::abi<PT>::VEC_BYTES);
 		gpu::h2d(s.at<uint16_t>(s.LEFT), unffor_left_arr, 2048);
 		gpu::h2d(s.at<alpgpu_rowgroup_state>(s.STATE), &d, sizeof(d));
 		gpu::h2d(s.cnt(), &n, 2);
@@ -99,11 +97,10 @@ struct rd_encoder {
 			gpu::h2d(s.at<uint16_t>(s.EXC), exceptions, static_cast<size_t>(n) * 2);
 			gpu::h2d(s.at<uint16_t>(s.POS), exceptions_positions, static_cast<size_t>(n) * 2);
 		}
-		gpu::check(alpgpu_rd_decode_vectors_f64(gpu::context(), s.at<PT>(s.OUT), s.at<UT>(s.ENC), s.at<uint16_t>(s.LEFT),
-		                                        s.at<alpgpu_rowgroup_state>(s.STATE), nullptr, s.at<uint16_t>(s.EXC), s.at<uint16_t>(s.POS), 1024,
-		                                        s.cnt(), 1),
-		           "alpgpu_rd_decode_vectors_f64");
-		gpu::d2h(a_out, s.at<PT>(s.OUT), 8192);
+		gpu::check(gpu::abi<PT>::rd_decode(s.at<PT>(s.OUT), s.at<UT>(s.ENC), s.at<uint16_t>(s.LEFT), s.at<alpgpu_rowgroup_state>(s.STATE),
+		                                   s.at<uint16_t>(s.EXC), s.at<uint16_t>(s.POS), s.cnt()),
+		           "alpgpu_rd_decode_vectors");
+		gpu::d2h(a_out, s.at<PT>(s.OUT), gpu::abi<PT>::VEC_BYTES);
 	}
 };
 

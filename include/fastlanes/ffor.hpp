@@ -1,6 +1,6 @@
 // fastlanes/ffor.hpp — ffor::ffor with the reference's signatures (include/fastlanes/ffor.hpp:7-15) for the word sizes
-// the ALP path uses: 64-bit (ALP integers, ALP_RD right parts) and 16-bit (ALP_RD left parts).  GPU-backed.
-// 8- and 32-bit lanes are not part of the double-precision path and are not declared.
+// the ALP path uses: 64-bit (double: ALP integers, ALP_RD right parts), 32-bit (float: the same) and 16-bit (ALP_RD left
+// parts).  GPU-backed.  8-bit lanes are not used by the codec and are not declared.
 #ifndef FASTLANES_FFOR_HPP
 #define FASTLANES_FFOR_HPP
 #include "alp/gpu_bridge.hpp"
@@ -34,6 +34,20 @@ inline void ffor(const uint16_t* __restrict in, uint16_t* __restrict out, uint8_
 }
 inline void ffor(const int16_t* __restrict in, int16_t* __restrict out, uint8_t bw, const int16_t* __restrict a_base_p) {
 	ffor(reinterpret_cast<const uint16_t*>(in), reinterpret_cast<uint16_t*>(out), bw, reinterpret_cast<const uint16_t*>(a_base_p));
+}
+
+inline void ffor(const uint32_t* __restrict in, uint32_t* __restrict out, uint8_t bw, const uint32_t* __restrict a_base_p) {
+	if (bw == 0 || bw > 32) { return; }
+	auto& s = alp::gpu::tls();
+	alp::gpu::h2d(s.at<uint32_t>(s.ENC), in, 4096);
+	alp::gpu::h2d(s.bw(), &bw, 1);
+	alp::gpu::h2d(s.at<int32_t>(s.META + 8), a_base_p, 4);
+	alp::gpu::check(alpgpu_ffor_i32(alp::gpu::context(), s.at<int32_t>(s.ENC), s.at<int32_t>(s.PACKED), 1024, s.bw(), s.at<int32_t>(s.META + 8), 1),
+	                "alpgpu_ffor_i32");
+	alp::gpu::d2h(out, s.at<uint32_t>(s.PACKED), static_cast<size_t>(bw) * 128);
+}
+inline void ffor(const int32_t* __restrict in, int32_t* __restrict out, uint8_t bw, const int32_t* __restrict a_base_p) {
+	ffor(reinterpret_cast<const uint32_t*>(in), reinterpret_cast<uint32_t*>(out), bw, reinterpret_cast<const uint32_t*>(a_base_p));
 }
 
 } // namespace fastlanes::generated::ffor::fallback::scalar

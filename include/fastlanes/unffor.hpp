@@ -1,4 +1,4 @@
-// fastlanes/unffor.hpp — unffor::unffor with the reference's signatures (include/fastlanes/unffor.hpp:7-15), 64- and 16-bit lanes.
+// fastlanes/unffor.hpp — unffor::unffor with the reference's signatures (include/fastlanes/unffor.hpp:7-15), 64-, 32- and 16-bit lanes.
 #ifndef FASTLANES_UNFFOR_HPP
 #define FASTLANES_UNFFOR_HPP
 #include "alp/gpu_bridge.hpp"
@@ -32,6 +32,20 @@ inline void unffor(const uint16_t* __restrict in, uint16_t* __restrict out, uint
 }
 inline void unffor(const int16_t* __restrict in, int16_t* __restrict out, uint8_t bw, const int16_t* __restrict a_base_p) {
 	unffor(reinterpret_cast<const uint16_t*>(in), reinterpret_cast<uint16_t*>(out), bw, reinterpret_cast<const uint16_t*>(a_base_p));
+}
+
+inline void unffor(const uint32_t* __restrict in, uint32_t* __restrict out, uint8_t bw, const uint32_t* __restrict a_base_p) {
+	if (bw > 32) { return; }
+	auto& s = alp::gpu::tls();
+	if (bw) { alp::gpu::h2d(s.at<uint32_t>(s.PACKED), in, static_cast<size_t>(bw) * 128); }
+	alp::gpu::h2d(s.bw(), &bw, 1);
+	alp::gpu::h2d(s.at<int32_t>(s.META + 8), a_base_p, 4);
+	alp::gpu::check(alpgpu_unffor_i32(alp::gpu::context(), s.at<int32_t>(s.PACKED), 1024, s.at<int32_t>(s.ENC), s.bw(), s.at<int32_t>(s.META + 8), 1),
+	                "alpgpu_unffor_i32");
+	alp::gpu::d2h(out, s.at<uint32_t>(s.ENC), 4096);
+}
+inline void unffor(const int32_t* __restrict in, int32_t* __restrict out, uint8_t bw, const int32_t* __restrict a_base_p) {
+	unffor(reinterpret_cast<const uint32_t*>(in), reinterpret_cast<uint32_t*>(out), bw, reinterpret_cast<const uint32_t*>(a_base_p));
 }
 
 } // namespace fastlanes::generated::unffor::fallback::scalar

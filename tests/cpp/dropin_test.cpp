@@ -3,8 +3,9 @@
 // decode -> bit-pattern-aware equality, plus the (exceptions_count, bit_width) known answers.  Our own harness code; the
 // column data and expectations come from tests/golden (exported by tests/test_dropin_gpu.py as raw files).
 //
-// usage: dropin_test <dir>   where <dir>/columns.txt lists: name n_values expected_bw expected_exc expect_rd
-//        and <dir>/<name>.f64 holds the raw doubles.
+// usage: dropin_test <dir>   where <dir>/columns.txt lists: type name n_values expected_bw expected_exc expect_rd
+//        (type = f64 | f32) and <dir>/<name>.<type> holds the raw values.  Both precisions run through the same
+//        template, like the reference's test_column<PT>.
 #include "alp.hpp"
 
 #include <cmath>
@@ -14,29 +15,33 @@
 #include <string>
 #include <vector>
 
-static bool same_value(double original, double decoded) {
-	uint64_t a, b;
-	std::memcpy(&a, &original, 8);
-	std::memcpy(&b, &decoded, 8);
+template <class PT>
+static bool same_value(PT original, PT decoded) {
 	if (std::isnan(original)) { return std::isnan(decoded); }
-	return a == b; // covers -0.0 vs 0.0
+	return std::memcmp(&original, &decoded, sizeof(PT)) == 0; // covers -0.0 vs 0.0
 }
 
+template <class PT>
 struct Buffers {
-	std::vector<double>   input, exceptions, decoded, sample, glue;
+	using ST = typename alp::inner_t<PT>::st;
+	using UT = typename alp::inner_t<PT>::ut;
+	std::vector<PT>       input, exceptions, decoded, sample, glue;
 	std::vector<uint16_t> rd_exc, pos, exc_c, left, ffor_left, unffor_left;
-	std::vector<int64_t>  ffor_buf, base, encoded;
-	std::vector<uint64_t> right, ffor_right, unffor_right;
+	std::vector<ST>       ffor_buf, base, encoded;
+	std::vector<UT>       right, ffor_right, unffor_right;
 	Buffers()
 	    : input(1024), exceptions(1024), decoded(1024), sample(1024), glue(1024), rd_exc(1024), pos(1024), exc_c(1024), left(1024),
 	      ffor_left(1024), unffor_left(1024), ffor_buf(1024), base(1024), encoded(1024), right(1024), ffor_right(1024), unffor_right(1024) {}
 };
 
+template <class PT>
 static int test_column(const std::string& dir, const std::string& name, size_t n_values, int want_bw, int want_exc, int want_rd) {
-	Buffers B;
-	std::vector<double> column(n_values);
-	std::ifstream       f(dir + "/" + name + ".f64", std::ios::binary);
-	f.read(reinterpret_cast<char*>(column.data()), static_cast<std::streamsize>(n_values * 8));
+	using ST                 = typename alp::inner_t<PT>::st;
+	constexpr size_t VEC_BYTES = sizeof(PT) * 1024;
+	Buffers<PT>      B;
+	std::vector<PT>  column(n_values);
+	std::ifstream    f(dir + "/" + name + (sizeof(PT) == 8 ? ".f64" : ".f32"), std::ios::binary);
+	f.read(reinterpret_cast<char*>(column.data()), static_cast<std::streamsize>(n_values * sizeof(PT)));
 	if (!f) {
 		std::printf("FAIL %s: cannot read input\n", name.c_str());
 		return 1;
@@ -44,43 +49,43 @@ static int test_column(const std::string& dir, const std::string& name, size_t n
 	int failures = 0;
 	const size_t n_vectors = n_values / alp::config::VECTOR_SIZE;
 
-	alp::state<double> stt;
+	alp::state<PT> stt;
 	for (size_t v = 0; v < n_vectors; ++v) {
 		const size_t offset = v * alp::config::VECTOR_SIZE;
 		if (v % alp::config::N_VECTORS_PER_ROWGROUP == 0) {
-			stt = alp::state<double>();
-			alp::encoder<double>::init(column.data(), offset, n_values, B.sample.data(), stt);
-			if (stt.scheme == alp::Scheme::ALP_RD) { alp::rd_encoder<double>::init(column.data(), offset, n_values, B.sample.data(), stt); }
+			stt = alp::state<PT>();
+			alp::encoder<PT>::init(column.data(), offset, n_values, B.sample.data(), stt);
+			if (stt.scheme == alp::Scheme::ALP_RD) { alp::rd_encoder<PT>::init(column.data(), offset, n_values, B.sample.data(), stt); }
 			if (v == 0 && want_rd >= 0 && (stt.scheme == alp::Scheme::ALP_RD) != (want_rd == 1)) {
 				std::printf("FAIL %s: scheme %d, expected rd=%d\n", name.c_str(), static_cast<int>(stt.scheme), want_rd);
 				++failures;
 			}
 		}
-		std::memcpy(B.input.data(), column.data() + offset, 8192);
-		const double* out = nullptr;
+		std::memcpy(B.input.data(), column.data() + offset, VEC_BYTES);
+		const PT* out = nullptr;
 		if (stt.scheme == alp::Scheme::ALP_RD) {
-			alp::rd_encoder<double>::encode(B.input.data(), B.rd_exc.data(), B.pos.data(), B.exc_c.data(), B.right.data(), B.left.data(), stt);
+			alp::rd_encoder<PT>::encode(B.input.data(), B.rd_exc.data(), B.pos.data(), B.exc_c.data(), B.right.data(), B.left.data(), stt);
 			ffor::ffor(B.right.data(), B.ffor_right.data(), stt.right_bit_width, &stt.right_for_base);
 			ffor::ffor(B.left.data(), B.ffor_left.data(), stt.left_bit_width, &stt.left_for_base);
 			unffor::unffor(B.ffor_right.data(), B.unffor_right.data(), stt.right_bit_width, &stt.right_for_base);
 			unffor::unffor(B.ffor_left.data(), B.unffor_left.data(), stt.left_bit_width, &stt.left_for_base);
-			alp::rd_encoder<double>::decode(B.glue.data(), B.unffor_right.data(), B.unffor_left.data(), B.rd_exc.data(), B.pos.data(), B.exc_c.data(), stt);
+			alp::rd_encoder<PT>::decode(B.glue.data(), B.unffor_right.data(), B.unffor_left.data(), B.rd_exc.data(), B.pos.data(), B.exc_c.data(), stt);
 			out = B.glue.data();
 		} else {
 			alp::bw_t bit_width = 0;
-			alp::encoder<double>::encode(B.input.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data(), B.encoded.data(), stt);
-			alp::encoder<double>::analyze_ffor(B.encoded.data(), bit_width, B.base.data());
+			alp::encoder<PT>::encode(B.input.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data(), B.encoded.data(), stt);
+			alp::encoder<PT>::analyze_ffor(B.encoded.data(), bit_width, B.base.data());
 			ffor::ffor(B.encoded.data(), B.ffor_buf.data(), bit_width, B.base.data());
 			generated::falp::fallback::scalar::falp(B.ffor_buf.data(), B.decoded.data(), bit_width, B.base.data(), stt.fac, stt.exp);
-			alp::decoder<double>::patch_exceptions(B.decoded.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data());
+			alp::decoder<PT>::patch_exceptions(B.decoded.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data());
 			out = B.decoded.data();
 			// the unfused path must agree with the fused one (benchmarks/benchmark.cpp:129-131)
-			std::vector<int64_t> unpacked(1024);
-			std::vector<double>  dec2(1024);
+			std::vector<ST> unpacked(1024);
+			std::vector<PT> dec2(1024);
 			unffor::unffor(B.ffor_buf.data(), unpacked.data(), bit_width, B.base.data());
-			alp::decoder<double>::decode(unpacked.data(), stt.fac, stt.exp, dec2.data());
-			alp::decoder<double>::patch_exceptions(dec2.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data());
-			if (std::memcmp(dec2.data(), out, 8192) != 0) {
+			alp::decoder<PT>::decode(unpacked.data(), stt.fac, stt.exp, dec2.data());
+			alp::decoder<PT>::patch_exceptions(dec2.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data());
+			if (std::memcmp(dec2.data(), out, VEC_BYTES) != 0) {
 				std::printf("FAIL %s v%zu: unffor+decode differs from falp\n", name.c_str(), v);
 				++failures;
 			}
@@ -105,11 +110,11 @@ int main(int argc, char** argv) {
 	if (argc < 2) { return 2; }
 	const std::string dir = argv[1];
 	std::ifstream     list(dir + "/columns.txt");
-	std::string       name;
+	std::string       type, name;
 	size_t            n_values;
 	int               bw, exc, rd, failures = 0, n = 0;
-	while (list >> name >> n_values >> bw >> exc >> rd) {
-		failures += test_column(dir, name, n_values, bw, exc, rd);
+	while (list >> type >> name >> n_values >> bw >> exc >> rd) {
+		failures += type == "f32" ? test_column<float>(dir, name, n_values, bw, exc, rd) : test_column<double>(dir, name, n_values, bw, exc, rd);
 		++n;
 	}
 	std::printf("%d columns, %d failures\n", n, failures);

@@ -25,14 +25,21 @@ def test_cpp_dropin_header_against_reference_columns(tmp_path):
         col.tofile(tmp_path / f"{key}.f64")
         is_rd = int(gold["scheme"][0] == 1)
         bw, exc = (int(known[0]), int(known[1])) if (known[0] >= 0 and not is_rd) else (-1, -1)
-        lines.append(f"{key} 1024 {bw} {exc} {is_rd}")
+        lines.append(f"f64 {key} 1024 {bw} {exc} {is_rd}")
     for name, col, gold in golden_io.rowgroup_samples():  # 128 vectors: two rowgroups, k > 1 (second-level sampling)
         col.tofile(tmp_path / f"{name}.f64")
-        lines.append(f"{name} {col.size} {int(gold['bw'][0])} {int(gold['exc_cnt'][0])} {int(gold['scheme'][0] == 1)}")
+        lines.append(f"f64 {name} {col.size} {int(gold['bw'][0])} {int(gold['exc_cnt'][0])} {int(gold['scheme'][0] == 1)}")
     # a column that ends in a partial vector: the host-side sampler rules + whole vectors only
     tail = np.round(np.random.default_rng(1).uniform(0, 100, 3 * 1024 + 500), 2)
     tail.tofile(tmp_path / "partial_tail.f64")
-    lines.append(f"partial_tail {tail.size} -1 -1 0")
+    lines.append(f"f64 partial_tail {tail.size} -1 -1 0")
+    # single precision: the reference's float test columns (asserted bit widths / exception count) and synthetic rowgroups
+    for name, col, gold, known in golden_io.float_vectors():
+        col.tofile(tmp_path / f"f32_{name}.f32")
+        is_rd = int(gold["scheme"][0] == 1)
+        bw = int(known[0]) if known[0] >= 0 else (int(gold["bw"][0]) if not is_rd else -1)
+        exc = int(known[1]) if known[1] >= 0 else (int(gold["exc_cnt"][0]) if not is_rd else -1)
+        lines.append(f"f32 f32_{name} {col.size} {bw} {exc} {is_rd}")
     (tmp_path / "columns.txt").write_text("\n".join(lines) + "\n")
     p = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=600)
     tail_out = "\n".join(p.stdout.splitlines()[-15:])
