@@ -146,10 +146,20 @@ struct AlpEncoded {
 	int      bw;
 };
 
+// Arithmetic shortcut (decided per value step, wave-uniformly).  Let t = (v * 10^e) * 10^-f as the reference computes it,
+// u = t + M, r = u - M (M = 2^52 + 2^51).  If |t| < 2^51 then u lies in [2^52, 2^53], where consecutive doubles are
+// consecutive integers: the encoded integer static_cast<int64_t>(r) equals bits(u) - bits(M) (one 64-bit subtract instead of
+// a software double->int64 conversion and its x86 range check).  For the verification, (double)(int64)(enc * 10^f) is the
+// correctly rounded value of an integer product that does not wrap when |enc * 10^f| < 2^63, i.e. exactly the IEEE product
+// r * 10^f of two exactly representable doubles (one multiply instead of a 64-bit integer multiply and a software
+// int64->double conversion).  A step in which any lane leaves these ranges (|t| >= 2^51, which includes -0.0's stand-in
+// 9.2e18 and +-Inf, or |r * 10^f| >= 2^63) is redone for the whole wavefront with the literal arithmetic; NaN never asks
+// for that (its compares are false) and is an exception on both routes.  Results are bit-identical by construction.
 __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int f, int lane, AlpEncoded& R) {
-	const double  exp10 = kExpArr[e];
+	const double  exp10  = kExpArr[e];
 	const double  frac_f = kFracArr[f];
-	const int64_t fact  = kFactArr[f];
+	const int64_t fact   = kFactArr[f];
+	const double  fact_d = kExpArr[f]; // 10^f, exact in double for f <= 18
 	const double  frac_e = kFracArr[e];
 	R.flags = 0;
 	R.cnt   = 0;
@@ -161,12 +171,22 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(v));
 			// pass 1 (encoder.hpp:326-338): for doubles only -0.0 matches (the mask literal evaluates to
 			// 0xFFE0000000000000); NaN/Inf go through the arithmetic and fail the compare
-			const double  vv  = bits == 0x8000000000000000ull ? kUpperLimit : v;
-			const int64_t enc = encode_value_unsafe(vv, exp10, frac_f);
-			const double  dec = decode_value(enc, fact, frac_e);
-			const bool    exc = dec != vv; // IEEE compare: NaN is always an exception
-			R.enc[m][j]       = enc;
-			R.ballot[m][j]    = __ballot(exc);
+			const double vv = bits == 0x8000000000000000ull ? kUpperLimit : v;
+			double       t  = vv * exp10;
+			t               = t * frac_f;
+			const double u  = t + kMagic;
+			const double r  = u - kMagic;
+			int64_t      enc = static_cast<int64_t>(static_cast<uint64_t>(__double_as_longlong(u)) - 0x4338000000000000ull);
+			const double prod = r * fact_d;
+			double       dec  = prod * frac_e;
+			const bool   wide = __builtin_fabs(t) >= 0x1p51 || __builtin_fabs(prod) >= 0x1p63;
+			if (__ballot(wide) != 0) { // wave-uniform, rare: the literal path of alp_device.hpp
+				enc = cast64_x86(r);
+				dec = decode_value(enc, fact, frac_e);
+			}
+			const bool exc = dec != vv; // IEEE compare: NaN is always an exception
+			R.enc[m][j]    = enc;
+			R.ballot[m][j] = __ballot(exc);
 			R.flags |= exc ? (1u << (2 * m + j)) : 0u;
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
 		}
@@ -253,7 +273,7 @@ __device__ __forceinline__ void pack_u64_from_lds(const EncodeLds& L, int bw, ul
 struct RdEncoded {
 	uint64_t right[8][2];
 	uint16_t left[8][2];  // original left parts
-	uint8_t  idx[8][2];   // dictionary index; dict_size at exception slots (see DESIGN.md, H4)
+	uint8_t  idx[8][2];   // dictionary index; dict_size at exception slots (DESIGN.md §3.3)
 	uint64_t ballot[8][2];
 	uint32_t flags;
 	int      cnt;

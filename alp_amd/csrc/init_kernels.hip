@@ -15,6 +15,7 @@
 // minimum of (size, candidate index).
 #include "alp_device_f32.hpp"
 #include "launch.hpp"
+#include "rd_dictionary_order.hpp"
 
 namespace alpgpu {
 
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	__shared__ double        s_cut_est[17];
 	__shared__ uint8_t       s_cut_ds[17];
 	__shared__ int           s_best_cut;
-	__shared__ uint16_t      s_best_dict[8];
+	__shared__ RdOrderLds    s_order;
 	__shared__ int           s_scheme;
 
 	const int      lane    = lane_id();
@@ -275,9 +276,9 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	// The samples are sorted ONCE by their 64-bit pattern; for every cut position the equal left parts are then
 	// contiguous runs of the sorted order.  One wavefront evaluates one cut at a time with wave-level primitives
 	// only: run starts (max-scan), run lengths and first occurrences (LDS atomics), a histogram of run lengths and
-	// a descending scan of it for the mass of the 8 most frequent left parts.  Ties: distinct parts are ranked by
-	// (count desc, first occurrence in the sample asc) — the reference sorts by count only and leaves ties to
-	// libstdc++ internals; the size estimate does not depend on the tie order, the dictionary order does.
+	// a descending scan of it for the mass of the 8 most frequent left parts.  The size estimate does not depend on how
+	// equally frequent left parts are ordered; the dictionary does, and is built afterwards for the chosen cut only, in the
+	// reference's (libstdc++'s) order — rd_dictionary_order.hpp.
 	// (sample t sits at smp[32 * (t / samples_size) + t % samples_size]; with 32-sample blocks that is smp[t])
 	auto smp_at = [&](int t) { return smp[32 * (t / samples_size) + (t % samples_size)]; };
 	if (tid < n_smp) {
@@ -353,24 +354,32 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 		const int rbw      = P::kBits - best_cut;
 		const int ds       = s_cut_ds[best_cut];
 		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
+		// distinct left parts in order of first occurrence in the sample, with their counts
+		int distinct = 0;
 		for (int b = 0; b < n_smp; b += 64) {
-			const int      j  = b + lane;
-			const uint32_t L  = j < n_smp ? W.len[j] : 0u;
-			const uint32_t fo = j < n_smp ? W.first[j] : 0u;
-			int            rank = 0;
+			const int      j   = b + lane;
+			const uint32_t L   = j < n_smp ? W.len[j] : 0u;
+			const uint32_t fo  = j < n_smp ? W.first[j] : 0u;
+			int            ord = 0;
 			for (int g = 0; g < n_smp; ++g) { // broadcast reads
-				const uint32_t Lg = W.len[g];
-				rank += (Lg != 0 && (Lg > L || (Lg == L && W.first[g] < fo))) ? 1 : 0;
+				ord += (W.len[g] != 0 && W.first[g] < fo) ? 1 : 0;
 			}
-			if (L != 0 && rank < 8) { s_best_dict[rank] = static_cast<uint16_t>(s_key[j] >> rbw); }
+			if (L != 0) {
+				s_order.okey[ord] = static_cast<uint32_t>(s_key[j] >> rbw);
+				s_order.ocnt[ord] = L;
+			}
+			distinct += __builtin_popcountll(__ballot(L != 0));
 		}
+		wave_lds_sync();
+		// the reference's order of equally frequent left parts is libstdc++'s (rd_dictionary_order.hpp): replayed by one lane
+		if (lane == 0) { rd_reference_order(s_order, distinct); }
 		wave_lds_sync();
 		if (lane == 0) {
 			const int lbw        = ds <= 2 ? 1 : (ds <= 4 ? 2 : 3);
 			rgs[rg].rd_rbw       = static_cast<uint8_t>(rbw);
 			rgs[rg].rd_lbw       = static_cast<uint8_t>(lbw);
 			rgs[rg].rd_dict_size = static_cast<uint8_t>(ds);
-			for (int i = 0; i < 8; ++i) { rgs[rg].rd_dict[i] = i < ds ? s_best_dict[i] : 0; }
+			for (int i = 0; i < 8; ++i) { rgs[rg].rd_dict[i] = i < ds ? static_cast<uint16_t>(s_order.sorted[i] & 0xFFFFu) : 0; }
 		}
 	}
 }

@@ -1,11 +1,10 @@
 // alp/rd.hpp — alp::rd_encoder<PT> with the reference's signatures (include/alp/rd.hpp:109-185), computed on the GPU.
 //
 // Dictionary order.  The reference builds the left-part histogram in a std::unordered_map and std::sort()s it by count
-// only, so the order of equally frequent left parts is whatever libstdc++ produces.  The GPU builder
-// ranks by (count desc, first occurrence in the sample asc): same cut position, bit widths, dictionary size and — when
-// counts are untied — same dictionary.  Left parts outside the dictionary are packed as index = dictionary size (the
-// reference packs a map position there, which no decoder reads).  A state produced by the reference itself can be
-// passed to encode()/decode() unchanged.
+// only, so the order of equally frequent left parts is whatever libstdc++ produces.  The device builder
+// replays those container internals (alp_amd/csrc/rd_dictionary_order.hpp) and returns the reference's dictionary entry
+// by entry.  Left parts outside the dictionary are packed as index = dictionary size (the reference packs a map position
+// there, which no decoder reads).  A state produced by the reference itself can be passed to encode()/decode() unchanged.
 #ifndef ALP_RD_HPP
 #define ALP_RD_HPP
 #include "alp/common.hpp"

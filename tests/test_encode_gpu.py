@@ -96,7 +96,8 @@ def test_golden_first_vectors_encode(ctx):
                 assert int(got["bw"][0]) == int(known[0]) and int(got["exc_cnt"][0]) == int(known[1]), name
         else:
             assert got["bw"][0] == gold["bw"][0] and got["lbw"][0] == gold["lbw"][0], name
-            assert got["dict_size"][0] == gold["dict_size"][0], name
+            assert got["dict_size"][0] == gold["dict_size"][0] and np.array_equal(got["dict"][0], gold["dict"][0]), name
+            assert np.array_equal(got["packed"], gold["packed"]) and np.array_equal(got["exc_cnt"], gold["exc_cnt"]), name
         out = ctx.decode(dcol)
         ctx.synchronize()
         assert torch.equal(out.view(torch.int64), x.view(torch.int64)), name
@@ -135,7 +136,8 @@ def test_rd_vectors_with_reference_state_bit_exact(ctx, oracle, name):
 
 @pytest.mark.parametrize("name", list(RD_COLUMNS.keys()))
 def test_rd_rowgroup_init_matches_reference_decisions(ctx, oracle, name):
-    """Own rowgroup init: scheme, cut (right/left bit width) and dictionary size equal the oracle's; round trip exact."""
+    """Own rowgroup init: scheme, cut (right/left bit width), dictionary size AND the dictionary entries in order equal the
+    oracle's (== the reference's), so every ALP_RD stream byte except the left index at exception slots is the reference's."""
     col_np = RD_COLUMNS[name]()
     want = oracle.encode_column(col_np)
     dcol, x = gpu_encode(ctx, col_np)
@@ -145,10 +147,17 @@ def test_rd_rowgroup_init_matches_reference_decisions(ctx, oracle, name):
     rd = rg["scheme"] == 1
     assert np.array_equal(rg["rd_rbw"][rd], w_rg["rd_rbw"][rd]) and np.array_equal(rg["rd_lbw"][rd], w_rg["rd_lbw"][rd])
     assert np.array_equal(rg["rd_dict_size"][rd], w_rg["rd_dict_size"][rd])
-    for r in np.nonzero(rd)[0]:
-        ds = int(rg["rd_dict_size"][r])
-        if ds < 8:  # every distinct sampled left part is in the dictionary: same set regardless of tie order
-            assert sorted(rg["rd_dict"][r, :ds].tolist()) == sorted(w_rg["rd_dict"][r, :ds].tolist())
+    # the dictionary itself, entry by entry: the order of equally frequent left parts is libstdc++'s in the reference
+    #  and is replayed on the device (alp_amd/csrc/rd_dictionary_order.hpp)
+    assert np.array_equal(rg["rd_dict"][rd], w_rg["rd_dict"][rd]), name
+    got = layout.expand(rg, vec, packed, exc)
+    assert_parts_equal(got, want, name)
+    for v in np.nonzero(want["scheme"] == 1)[0]:
+        a = oracle.unffor_u16(got["packed_left"][v], int(want["lbw"][v]))
+        b = oracle.unffor_u16(want["packed_left"][v], int(want["lbw"][v]))
+        keep = np.ones(1024, bool)
+        keep[want["pos"][v, : int(want["exc_cnt"][v])]] = False
+        assert np.array_equal(a[keep], b[keep]), f"{name}: left dictionary indices differ in vector {v}"
     assert np.array_equal(rg["k"][~rd], w_rg["k"][~rd]) and np.array_equal(rg["combos"][~rd], w_rg["combos"][~rd])
     out = ctx.decode(dcol)
     ctx.synchronize()

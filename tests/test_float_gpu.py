@@ -71,7 +71,7 @@ def test_golden_float_columns_decode_bit_exact(ctx, case):
 @pytest.mark.parametrize("case", FLOATS, ids=lambda c: c[0])
 def test_golden_float_columns_encode_bit_exact(ctx, case):
     """GPU rowgroup init + encode against the reference's outputs; ALP_RD rowgroups are compared in their decisions
-    (cut, dictionary size) and round trip, the dictionary order follows DESIGN.md H4"""
+    (cut, dictionary size, dictionary entries, right parts, exception lists) and round trip"""
     name, col, gold, known = case
     dcol, x = gpu_encode(ctx, col)
     got = layout.expand(*dcol.to_host(), 4)
@@ -83,7 +83,8 @@ def test_golden_float_columns_encode_bit_exact(ctx, case):
     else:
         for k in ("bw", "lbw", "e", "f", "base"):
             assert np.array_equal(got[k], gold[k]), (name, k)
-        assert np.array_equal(got["dict_size"], gold["dict_size"])
+        assert np.array_equal(got["dict_size"], gold["dict_size"]) and np.array_equal(got["dict"], gold["dict"]), name
+        assert np.array_equal(got["exc_cnt"], gold["exc_cnt"]) and np.array_equal(got["packed"], gold["packed"]), name
         assert np.array_equal(got["exc_cnt"][alp], gold["exc_cnt"][alp]) and np.array_equal(got["packed"][alp], gold["packed"][alp])
     if known[0] >= 0:
         assert int(got["bw"][0]) == int(known[0])
@@ -144,6 +145,8 @@ def test_synthetic_float_columns_encode_bit_exact(ctx, of32, name):
     alp_rg = rg["scheme"] == 2
     assert np.array_equal(rg["k"][alp_rg], w_rg["k"][alp_rg]) and np.array_equal(rg["combos"][alp_rg], w_rg["combos"][alp_rg]), name
     assert np.array_equal(rg["rd_rbw"], w_rg["rd_rbw"]) and np.array_equal(rg["rd_lbw"], w_rg["rd_lbw"]) and np.array_equal(rg["rd_dict_size"], w_rg["rd_dict_size"])
+    assert np.array_equal(rg["rd_dict"], w_rg["rd_dict"]), "ALP_RD dictionaries must come out in the reference's order"
+    assert_parts_equal(got, want, name)
     if alp_rg.all():
         assert_parts_equal(got, want, name)
         assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
@@ -307,6 +310,7 @@ def test_state_from_samples_f32(ctx, of32):
             assert got["k"] == w_rg["k"][0] and np.array_equal(got["combos"], w_rg["combos"][0]), name
         else:
             assert got["rd_rbw"] == w_rg["rd_rbw"][0] and got["rd_lbw"] == w_rg["rd_lbw"][0] and got["rd_dict_size"] == w_rg["rd_dict_size"][0], name
+            assert np.array_equal(got["rd_dict"], w_rg["rd_dict"][0]), name
 
 
 def test_float_container_round_trip_and_tail(ctx):
