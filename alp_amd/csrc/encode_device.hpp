@@ -54,6 +54,48 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src_lane) {
 	return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
+// A wave-uniform lane mask (a ballot) as this lane's predicate: the SGPR pair is used directly as the select mask.
+__device__ __forceinline__ bool lane_in(uint64_t ballot) { return __builtin_amdgcn_inverse_ballot_w64(ballot); }
+
+// min / max of doubles that ignore a quiet NaN operand (IEEE minNum / maxNum, which is what the instructions compute)
+__device__ __forceinline__ double fmin_num(double a, double b) {
+	double d;
+	asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+__device__ __forceinline__ double fmax_num(double a, double b) {
+	double d;
+	asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+// cross-lane copy of a double by DPP (register to register); lanes without a valid source lane keep their own value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+	const uint64_t b  = static_cast<uint64_t>(__double_as_longlong(v));
+	int            lo = static_cast<int>(static_cast<uint32_t>(b)), hi = static_cast<int>(static_cast<uint32_t>(b >> 32));
+	lo                = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+	hi                = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
+}
+// wavefront-wide NaN-ignoring min and max; the result is returned wave-uniform (read from lane 63)
+__device__ __forceinline__ void wave_minmax_f64(double& mn, double& mx) {
+#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
+	mn = fmin_num(mn, dpp_f64<CTRL, ROWS>(mn));                                                                         \
+	mx = fmax_num(mx, dpp_f64<CTRL, ROWS>(mx));
+	ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
+	ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
+	ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
+	ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8   -> lane 15 of every 16-lane row holds the row's result
+	ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+	ALPGPU_MINMAX_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's result
+#undef ALPGPU_MINMAX_STEP
+	const uint64_t a = static_cast<uint64_t>(__double_as_longlong(mn)), b = static_cast<uint64_t>(__double_as_longlong(mx));
+	const uint32_t a0 = __builtin_amdgcn_readlane(static_cast<uint32_t>(a), 63), a1 = __builtin_amdgcn_readlane(static_cast<uint32_t>(a >> 32), 63);
+	const uint32_t b0 = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), 63), b1 = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), 63);
+	mn = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(a1) << 32) | a0));
+	mx = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(b1) << 32) | b0));
+}
+
 __device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint64_t v, int lane) {
 	const double2* p = reinterpret_cast<const double2*>(in + v * kVec);
 	VecIn          r;
@@ -135,12 +177,11 @@ __device__ __forceinline__ void second_level_select(const VecIn& in, const alpgp
 }
 
 // ---- encode_simdized + analyze_ffor for one vector held in registers -------------------------------------
-// Outputs: enc[m][j] with exception slots overwritten by the filler; exception flags as a 16-bit per-lane
-// mask (bit 2m+j); ballots per (m,j); count; FOR base and bit width.
+// Outputs: enc[m][j] with exception slots overwritten by the filler; the exceptions of every (m,j) step as a
+// wave-uniform lane mask (ballot); count; FOR base and bit width.
 struct AlpEncoded {
 	int64_t  enc[8][2];
 	uint64_t ballot[8][2];
-	uint32_t flags;
 	int      cnt;
 	int64_t  base;
 	int      bw;
@@ -161,8 +202,12 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 	const int64_t fact   = kFactArr[f];
 	const double  fact_d = kExpArr[f]; // 10^f, exact in double for f <= 18
 	const double  frac_e = kFracArr[e];
-	R.flags = 0;
 	R.cnt   = 0;
+	// FOR analysis (encoder.hpp:109-120) rides along: the encoded integer of a non-exception equals r (an integer-valued
+	// double, |r| <= 2^63) on both routes, so min / max are taken over r with exception lanes masked by a quiet NaN that
+	// v_min_f64 / v_max_f64 ignore; exception slots later hold the filler, which is itself a non-exception's value.
+	const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+	double       rmin = qnan, rmax = qnan;
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
 #pragma unroll
@@ -187,8 +232,10 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 			const bool exc = dec != vv; // IEEE compare: NaN is always an exception
 			R.enc[m][j]    = enc;
 			R.ballot[m][j] = __ballot(exc);
-			R.flags |= exc ? (1u << (2 * m + j)) : 0u;
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
+			const double rm = exc ? qnan : r;
+			rmin            = fmin_num(rmin, rm);
+			rmax            = fmax_num(rmax, rm);
 		}
 	}
 	// filler = encoded value at the first non-exception position p (encoder.hpp:382-388); 0 when there is
@@ -215,28 +262,42 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 			found = true;
 		}
 	}
-	int64_t mn = INT64_MAX, mx = INT64_MIN;
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
 #pragma unroll
-		for (int j = 0; j < 2; ++j) {
-			if (R.flags & (1u << (2 * m + j))) { R.enc[m][j] = filler; }
-			mn = R.enc[m][j] < mn ? R.enc[m][j] : mn;
-			mx = R.enc[m][j] > mx ? R.enc[m][j] : mx;
-		}
+		for (int j = 0; j < 2; ++j) { R.enc[m][j] = lane_in(R.ballot[m][j]) ? filler : R.enc[m][j]; }
 	}
-	mn     = wave_min_i64(mn);
-	mx     = wave_max_i64(mx);
+	wave_minmax_f64(rmin, rmax);
+	// the filler takes part wherever there is an exception: normally it is one of the non-exception values, but it is 0 when
+	// the only non-exception sits at position 1023 or when there is none
+	const bool none = R.cnt == kVec;
+	int64_t    mn   = none ? filler : cast64_x86(rmin);
+	int64_t    mx   = none ? filler : cast64_x86(rmax);
+	if (R.cnt > 0) {
+		mn = filler < mn ? filler : mn;
+		mx = filler > mx ? filler : mx;
+	}
 	R.base = mn;
 	R.bw   = count_bits(mx, mn);
 }
 
-// rank of this lane's (m, j) exception among the vector's exceptions in ascending position order
-__device__ __forceinline__ int exception_rank(const uint64_t (&ballot)[8][2], uint32_t flags, int m, int j, int lane, int step_offset) {
-	const uint64_t lt = lanemask_lt(lane);
-	int            r  = step_offset + __builtin_popcountll(ballot[m][0] & lt) + __builtin_popcountll(ballot[m][1] & lt);
-	if (j == 1 && (flags & (1u << (2 * m)))) { r += 1; }
-	return r;
+// Calls emit(rank, m, j) on every lane whose (m, j) slot is set in `ballot`; rank = number of set slots at smaller positions
+// (position = 128*m + 2*lane + j), i.e. the slot's index in the ascending exception list.  m and j are compile-time at the call.
+template <class F>
+__device__ __forceinline__ void for_each_exception(const uint64_t (&ballot)[8][2], int lane, F&& emit) {
+	const uint64_t lt   = lanemask_lt(lane);
+	int            soff = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		const uint64_t b0 = ballot[m][0], b1 = ballot[m][1];
+		if ((b0 | b1) != 0) { // wave-uniform
+			const int  before = soff + __builtin_popcountll(b0 & lt) + __builtin_popcountll(b1 & lt);
+			const bool e0 = lane_in(b0), e1 = lane_in(b1);
+			if (e0) { emit(before, m, 0); }
+			if (e1) { emit(before + (e0 ? 1 : 0), m, 1); }
+			soff += __builtin_popcountll(b0) + __builtin_popcountll(b1);
+		}
+	}
 }
 
 // ---- FFOR u64 pack from LDS (closed form of src/fastlanes_generated_ffor.cpp:7379-29749) -------------------
@@ -275,7 +336,6 @@ struct RdEncoded {
 	uint16_t left[8][2];  // original left parts
 	uint8_t  idx[8][2];   // dictionary index; dict_size at exception slots
 	uint64_t ballot[8][2];
-	uint32_t flags;
 	int      cnt;
 };
 
@@ -283,7 +343,6 @@ __device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgp
 	const int      rbw  = rg.rd_rbw;
 	const uint64_t mask = bw_mask(rbw);
 	const int      ds   = rg.rd_dict_size;
-	R.flags = 0;
 	R.cnt   = 0;
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
@@ -302,7 +361,6 @@ __device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgp
 			R.left[m][j]   = left;
 			R.idx[m][j]    = static_cast<uint8_t>(idx);
 			R.ballot[m][j] = __ballot(exc);
-			R.flags |= exc ? (1u << (2 * m + j)) : 0u;
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
 		}
 	}

@@ -198,21 +198,12 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 			encode_alp_registers(x, d.e, d.f, lane, R);
 			// exception record: cnt x f64 original bits, then cnt x u16 positions, ascending position order
 			if (R.cnt > 0) {
-				uint64_t* ev   = reinterpret_cast<uint64_t*>(rec);
-				uint16_t* ep   = reinterpret_cast<uint16_t*>(rec + 8ull * R.cnt);
-				int       soff = 0;
-#pragma unroll
-				for (int m = 0; m < 8; ++m) {
-#pragma unroll
-					for (int j = 0; j < 2; ++j) {
-						if (R.flags & (1u << (2 * m + j))) {
-							const int r = exception_rank(R.ballot, R.flags, m, j, lane, soff);
-							ev[r]       = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
-							ep[r]       = static_cast<uint16_t>(128 * m + 2 * lane + j);
-						}
-					}
-					soff += __builtin_popcountll(R.ballot[m][0]) + __builtin_popcountll(R.ballot[m][1]);
-				}
+				uint64_t* ev = reinterpret_cast<uint64_t*>(rec);
+				uint16_t* ep = reinterpret_cast<uint16_t*>(rec + 8ull * R.cnt);
+				for_each_exception(R.ballot, lane, [&](int r, int m, int j) {
+					ev[r] = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
+					ep[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
+				});
 			}
 			// (enc - base) -> LDS in natural order, then FFOR pack
 			ulonglong2*    lv   = reinterpret_cast<ulonglong2*>(L.vals);
@@ -227,21 +218,12 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 			RdEncoded R;
 			encode_rd_registers(x, *rgp, lane, R);
 			if (R.cnt > 0) {
-				uint16_t* ev   = reinterpret_cast<uint16_t*>(rec);
-				uint16_t* ep   = reinterpret_cast<uint16_t*>(rec + 2ull * R.cnt);
-				int       soff = 0;
-#pragma unroll
-				for (int m = 0; m < 8; ++m) {
-#pragma unroll
-					for (int j = 0; j < 2; ++j) {
-						if (R.flags & (1u << (2 * m + j))) {
-							const int r = exception_rank(R.ballot, R.flags, m, j, lane, soff);
-							ev[r]       = R.left[m][j];
-							ep[r]       = static_cast<uint16_t>(128 * m + 2 * lane + j);
-						}
-					}
-					soff += __builtin_popcountll(R.ballot[m][0]) + __builtin_popcountll(R.ballot[m][1]);
-				}
+				uint16_t* ev = reinterpret_cast<uint16_t*>(rec);
+				uint16_t* ep = reinterpret_cast<uint16_t*>(rec + 2ull * R.cnt);
+				for_each_exception(R.ballot, lane, [&](int r, int m, int j) {
+					ev[r] = R.left[m][j];
+					ep[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
+				});
 			}
 			ulonglong2* lv = reinterpret_cast<ulonglong2*>(L.vals);
 #pragma unroll
@@ -305,7 +287,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	// ---- 1. encode into registers / LDS ----
 	VecIn              x;
 	alpgpu_vector_desc d;
-	uint32_t           flags = 0;
 	uint64_t           acc0 = 0, acc1 = 0; // ALP_RD: packed left streams of this lane's two lane64 columns
 	uint64_t           ballots[8][2];
 	int                cnt = 0;
@@ -328,8 +309,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 			AlpEncoded R;
 			encode_alp_registers(x, e, f, lane, R);
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
-			cnt   = R.cnt;
-			flags = R.flags;
+			cnt = R.cnt;
 			ulonglong2*    lv   = reinterpret_cast<ulonglong2*>(L.vals);
 			const uint64_t base = static_cast<uint64_t>(R.base);
 #pragma unroll
@@ -342,8 +322,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 			RdEncoded R;
 			encode_rd_registers(x, *rgp, lane, R);
 			d.bw = rgp->rd_rbw, d.lbw = rgp->rd_lbw;
-			cnt   = R.cnt;
-			flags = R.flags;
+			cnt = R.cnt;
 			ulonglong2*    lv    = reinterpret_cast<ulonglong2*>(L.vals);
 			const int      lbw   = d.lbw;
 			const uint64_t lmask = (1ull << lbw) - 1ull;
@@ -405,28 +384,19 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
 	if (cnt > 0) {
-		const bool alp  = d.scheme == ALPGPU_SCHEME_ALP;
-		const int  rbw  = d.bw;
-		int        soff = 0;
-#pragma unroll
-		for (int m = 0; m < 8; ++m) {
-#pragma unroll
-			for (int j = 0; j < 2; ++j) {
-				if (flags & (1u << (2 * m + j))) {
-					const int      r    = exception_rank(ballots, flags, m, j, lane, soff);
-					const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
-					const uint16_t pos  = static_cast<uint16_t>(128 * m + 2 * lane + j);
-					if (alp) {
-						reinterpret_cast<uint64_t*>(rec)[r]                    = bits;
-						reinterpret_cast<uint16_t*>(rec + 8ull * cnt)[r] = pos;
-					} else {
-						reinterpret_cast<uint16_t*>(rec)[r]                    = static_cast<uint16_t>(bits >> rbw);
-						reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
-					}
-				}
+		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
+		const int  rbw = d.bw;
+		for_each_exception(ballots, lane, [&](int r, int m, int j) {
+			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
+			const uint16_t pos  = static_cast<uint16_t>(128 * m + 2 * lane + j);
+			if (alp) {
+				reinterpret_cast<uint64_t*>(rec)[r]              = bits;
+				reinterpret_cast<uint16_t*>(rec + 8ull * cnt)[r] = pos;
+			} else {
+				reinterpret_cast<uint16_t*>(rec)[r]              = static_cast<uint16_t>(bits >> rbw);
+				reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
 			}
-			soff += __builtin_popcountll(ballots[m][0]) + __builtin_popcountll(ballots[m][1]);
-		}
+		});
 	}
 	pack_u64_from_lds(L, d.bw, reinterpret_cast<ulonglong2*>(dst), lane);
 	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 32) {

@@ -254,24 +254,18 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_values(const double
 		}
 		AlpEncoded R;
 		encode_alp_registers(x, e, f, lane, R);
-		longlong2* dst  = reinterpret_cast<longlong2*>(enc + v * kVec);
-		int        soff = 0;
+		longlong2* dst = reinterpret_cast<longlong2*>(enc + v * kVec);
 #pragma unroll
 		for (int m = 0; m < 8; ++m) {
 			longlong2 o;
 			o.x = R.enc[m][0];
 			o.y = R.enc[m][1];
 			dst[64 * m + lane] = o;
-#pragma unroll
-			for (int j = 0; j < 2; ++j) {
-				if (R.flags & (1u << (2 * m + j))) {
-					const int r              = exception_rank(R.ballot, R.flags, m, j, lane, soff);
-					exc[v * exc_stride + r] = j == 0 ? x.x[m].x : x.x[m].y;
-					pos[v * exc_stride + r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
-				}
-			}
-			soff += __builtin_popcountll(R.ballot[m][0]) + __builtin_popcountll(R.ballot[m][1]);
 		}
+		for_each_exception(R.ballot, lane, [&](int r, int m, int j) {
+			exc[v * exc_stride + r] = j == 0 ? x.x[m].x : x.x[m].y;
+			pos[v * exc_stride + r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
+		});
 		if (lane == 0) { cnts[v] = static_cast<uint16_t>(R.cnt); }
 	}
 }
@@ -290,21 +284,15 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_rd_encode(const double* __
 		encode_rd_registers(x, *rgp, lane, R);
 		ulonglong2* rdst = reinterpret_cast<ulonglong2*>(right + v * kVec);
 		uint32_t*   ldst = reinterpret_cast<uint32_t*>(left + v * kVec);
-		int         soff = 0;
 #pragma unroll
 		for (int m = 0; m < 8; ++m) {
 			rdst[64 * m + lane] = make_ulonglong2(R.right[m][0], R.right[m][1]);
 			ldst[64 * m + lane] = static_cast<uint32_t>(R.idx[m][0]) | (static_cast<uint32_t>(R.idx[m][1]) << 16);
-#pragma unroll
-			for (int j = 0; j < 2; ++j) {
-				if (R.flags & (1u << (2 * m + j))) {
-					const int r              = exception_rank(R.ballot, R.flags, m, j, lane, soff);
-					exc[v * exc_stride + r] = R.left[m][j];
-					pos[v * exc_stride + r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
-				}
-			}
-			soff += __builtin_popcountll(R.ballot[m][0]) + __builtin_popcountll(R.ballot[m][1]);
 		}
+		for_each_exception(R.ballot, lane, [&](int r, int m, int j) {
+			exc[v * exc_stride + r] = R.left[m][j];
+			pos[v * exc_stride + r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
+		});
 		if (lane == 0) { cnts[v] = static_cast<uint16_t>(R.cnt); }
 	}
 }
