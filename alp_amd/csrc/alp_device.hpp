@@ -20,7 +20,10 @@ namespace alpgpu {
 
 constexpr int kVec        = 1024;
 constexpr int kRowgroup   = 100;
-constexpr int kWavesPerWg = 4;
+#ifndef ALPGPU_WAVES_PER_WG
+#define ALPGPU_WAVES_PER_WG 4
+#endif
+constexpr int kWavesPerWg = ALPGPU_WAVES_PER_WG; // wavefronts (= vectors) per workgroup of the wave-per-vector kernels
 
 // ---- constants (reference include/alp/constants.hpp:66-154): bit-identical tables --------------------
 __device__ __constant__ const double kFracArr[21] = {
