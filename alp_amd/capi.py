@@ -47,8 +47,11 @@ class CColumn(C.Structure):
     _fields_ = [
         ("n_vectors", C.c_uint64), ("n_rowgroups", C.c_uint64), ("d_rowgroups", C.c_void_p), ("d_vectors", C.c_void_p),
         ("d_packed", C.c_void_p), ("packed_capacity", C.c_uint64), ("d_exc", C.c_void_p), ("exc_capacity", C.c_uint64),
-        ("d_totals", C.c_void_p), ("packed_bytes_hint", C.c_uint64), ("exc_bytes_hint", C.c_uint64),
+        ("d_totals", C.c_void_p), ("packed_bytes_hint", C.c_uint64), ("exc_bytes_hint", C.c_uint64), ("d_rd_order", C.c_void_p),
     ]
+
+
+RD_ORDER_STRIDE = 296  # ALPGPU_RD_ORDER_STRIDE
 
 
 def _sig(name, restype, *argtypes):
@@ -342,7 +345,7 @@ class DeviceColumn:
     """A compressed column in HBM (struct alpgpu_column) whose buffers are torch uint8 tensors."""
 
     def __init__(self, n_vectors: int, device: int = 0, packed_capacity: int | None = None,
-                 exc_capacity: int | None = None, dtype: str = "f64"):
+                 exc_capacity: int | None = None, dtype: str = "f64", rd_order: bool = True):
         import torch
         assert dtype in ("f64", "f32")
         dev = f"cuda:{device}"
@@ -358,8 +361,11 @@ class DeviceColumn:
         self.packed = torch.zeros(pc, dtype=torch.uint8, device=dev)
         self.exc = torch.zeros(ec, dtype=torch.uint8, device=dev)
         self.totals = torch.zeros(8, dtype=torch.int64, device=dev)
+        # optional ALP_RD sorted-order table (exception-slot indices identical to the reference's); rd_order=False leaves it out
+        self.rd_order = torch.zeros(max(1, self.n_rowgroups) * RD_ORDER_STRIDE, dtype=torch.int16, device=dev) if rd_order else None
         self.c = CColumn(self.n_vectors, self.n_rowgroups, self.rowgroups.data_ptr(), self.vectors.data_ptr(),
-                         self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr(), 0, 0)
+                         self.packed.data_ptr(), pc, self.exc.data_ptr(), ec, self.totals.data_ptr(), 0, 0,
+                         self.rd_order.data_ptr() if rd_order else None)
 
     @classmethod
     def from_host(cls, rowgroups: np.ndarray, vectors: np.ndarray, packed: np.ndarray, exc: np.ndarray, device: int = 0, dtype: str = "f64"):

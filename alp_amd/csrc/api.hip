@@ -55,7 +55,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 extern "C" {
 
-int alpgpu_abi_version(void) { return 1; }
+int alpgpu_abi_version(void) { return 2; } // 2: alpgpu_column.d_rd_order
 
 const char* alpgpu_last_error(void) { return g_err; }
 
@@ -220,7 +220,7 @@ int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vec
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
-	if (alpgpu::launch_rowgroup_init(ctx->stream, d_in, n_vectors, col->d_rowgroups) != ALPGPU_OK) {
+	if (alpgpu::launch_rowgroup_init(ctx->stream, d_in, n_vectors, col->d_rowgroups, col->d_rd_order) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;
@@ -523,7 +523,7 @@ int alpgpu_rowgroup_init_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vect
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
-	if (alpgpu::launch_rowgroup_init_f32(ctx->stream, d_in, n_vectors, col->d_rowgroups) != ALPGPU_OK) {
+	if (alpgpu::launch_rowgroup_init_f32(ctx->stream, d_in, n_vectors, col->d_rowgroups, col->d_rd_order) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;

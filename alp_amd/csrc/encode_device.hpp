@@ -12,6 +12,7 @@
 //   ALP_RD split           alp::rd_encoder<double>::encode                                    include/alp/rd.hpp:109-147
 #pragma once
 #include "alp_device.hpp"
+#include "rd_exception_index.hpp"
 
 namespace alpgpu {
 
@@ -334,12 +335,14 @@ __device__ __forceinline__ void pack_u64_from_lds(const EncodeLds& L, int bw, ul
 struct RdEncoded {
 	uint64_t right[8][2];
 	uint16_t left[8][2];  // original left parts
-	uint8_t  idx[8][2];   // dictionary index; dict_size at exception slots
+	uint8_t  idx[8][2];   // dictionary index; at exception slots the reference's map position (low 8 bits) or dict_size
 	uint64_t ballot[8][2];
 	int      cnt;
 };
 
-__device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgpu_rowgroup_state& rg, int lane, RdEncoded& R) {
+__device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgpu_rowgroup_state& rg, int lane, RdEncoded& R,
+                                                    const uint16_t* __restrict__ order_rg = nullptr) {
+	const RdOrderView order = load_rd_order(order_rg, rg, lane);
 	const int      rbw  = rg.rd_rbw;
 	const uint64_t mask = bw_mask(rbw);
 	const int      ds   = rg.rd_dict_size;
@@ -359,8 +362,12 @@ __device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgp
 			}
 			const bool exc = idx == ds;
 			R.left[m][j]   = left;
-			R.idx[m][j]    = static_cast<uint8_t>(idx);
 			R.ballot[m][j] = __ballot(exc);
+			if (order.valid && R.ballot[m][j] != 0) { // rare, wave-uniform: the reference's index for a left part outside the dictionary
+				const int ridx = rd_exception_index(order, left);
+				idx            = exc ? ridx : idx;
+			}
+			R.idx[m][j] = static_cast<uint8_t>(idx); // only the low lbw (<= 3) bits are packed
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
 		}
 	}

@@ -13,6 +13,7 @@
 // row = 8*m + (L >> 3), unit column a = L & 7.
 #include "encode_f32_device.hpp"
 #include "encode_lookback.hpp"
+#include "rd_exception_index.hpp"
 #include "launch.hpp"
 
 namespace alpgpu {
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                        uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                        uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
-                                                                       uint64_t v_first, uint64_t n_vectors_launch) {
+                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order) {
 	__shared__ EncodeLdsF32 lds[kWavesPerWg];
 	__shared__ uint64_t     s_size[kWavesPerWg];
 	__shared__ uint64_t     s_excl;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 			const uint32_t rmask = bw_mask32(rbw);
 			const uint64_t lmask = (1ull << lbw) - 1ull;
 			d.bw = static_cast<uint8_t>(rbw), d.lbw = static_cast<uint8_t>(lbw);
+			const RdOrderView order = load_rd_order(rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, *rgp, lane);
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				u32x4     q;
@@ -114,6 +116,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 					}
 					const bool exc = idx == ds;
 					ballots[m][j]  = __ballot(exc);
+					if (order.valid && ballots[m][j] != 0) { // the reference's index for a left part outside the dictionary
+						const int ridx = rd_exception_index(order, left);
+						idx            = exc ? ridx : idx;
+					}
 					flags |= exc ? (1u << (4 * m + j)) : 0u;
 					cnt += __builtin_popcountll(ballots[m][j]);
 					lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
@@ -218,7 +224,7 @@ int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_ve
 		if (hipMemsetAsync(d_workspace, 0, n_tiles * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		hipLaunchKernelGGL(k_encode_fused_f32, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch);
+		                   n_launch, col->d_rd_order);
 		hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(1), 0, stream, col->d_totals);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
                                                                   alpgpu_vector_desc* __restrict__ descs,
                                                                   const uint64_t* __restrict__ tile_bases, uint8_t* __restrict__ packed,
                                                                   uint8_t* __restrict__ excs, const uint64_t* __restrict__ totals,
-                                                                  uint64_t n_vectors) {
+                                                                  uint64_t n_vectors, const uint16_t* __restrict__ rd_order) {
 	__shared__ EncodeLds lds[kWavesPerWg];
 	if (totals[2] != 0) { return; } // capacity overflow: write nothing (reported through alpgpu_column_totals)
 	const int      lane   = lane_id();
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 			pack_u64_from_lds(L, R.bw, reinterpret_cast<ulonglong2*>(dst), lane);
 		} else {
 			RdEncoded R;
-			encode_rd_registers(x, *rgp, lane, R);
+			encode_rd_registers(x, *rgp, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr);
 			if (R.cnt > 0) {
 				uint16_t* ev = reinterpret_cast<uint16_t*>(rec);
 				uint16_t* ep = reinterpret_cast<uint16_t*>(rec + 2ull * R.cnt);
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
                                                                    alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                    uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                    uint64_t* __restrict__ totals, uint64_t packed_capacity,
-                                                                   uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch) {
+                                                                   uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch,
+                                                                   const uint16_t* __restrict__ rd_order) {
 	__shared__ EncodeLds lds[kWavesPerWg];
 	__shared__ uint64_t  s_size[kWavesPerWg]; // per vector: (packed units << 31) | exception units
 	__shared__ uint64_t  s_excl;              // tile's exclusive prefix in the same packing, or ~0 on a stall
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 			}
 		} else {
 			RdEncoded R;
-			encode_rd_registers(x, *rgp, lane, R);
+			encode_rd_registers(x, *rgp, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr);
 			d.bw = rgp->rd_rbw, d.lbw = rgp->rd_lbw;
 			cnt = R.cnt;
 			ulonglong2*    lv    = reinterpret_cast<ulonglong2*>(L.vals);
@@ -440,7 +441,7 @@ int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vecto
 		if (hipMemsetAsync(d_workspace, 0, n_tiles * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch);
+		                   n_launch, col->d_rd_order);
 		hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, stream, col->d_totals);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
@@ -460,7 +461,7 @@ int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vec
 	hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream, d_workspace, n_tiles, col->packed_capacity, col->exc_capacity,
 	                   col->d_totals);
 	hipLaunchKernelGGL(k_encode_pack, dim3(grid_for(n_vectors, n_cus, 16)), block, 0, stream, d_in, col->d_rowgroups, col->d_vectors,
-	                   d_workspace, col->d_packed, col->d_exc, col->d_totals, n_vectors);
+	                   d_workspace, col->d_packed, col->d_exc, col->d_totals, n_vectors, col->d_rd_order);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

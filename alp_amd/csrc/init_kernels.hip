@@ -145,7 +145,8 @@ __device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, const uint64_t* 
 // a partial vector and the sampler's index rules (sampler.hpp:29-44) are applied on the host.
 template <class P, bool FROM_SAMPLES>
 __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
-                                                                alpgpu_rowgroup_state* __restrict__ rgs, int force_rd) {
+                                                                alpgpu_rowgroup_state* __restrict__ rgs, int force_rd,
+                                                                uint16_t* __restrict__ rd_order) {
 	__shared__ typename P::value_t smp[kMaxSampledVectors * 32];
 	__shared__ uint32_t best_key[kMaxSampledVectors];
 	__shared__ uint64_t      s_key[kMaxSamples]; // samples sorted by bit pattern (ALP_RD)
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 		}
 		rgs[rg]  = st;
 		s_scheme = st.scheme;
+		if (rd_order && st.scheme != ALPGPU_SCHEME_ALP_RD) { rd_order[rg * ALPGPU_RD_ORDER_STRIDE] = 0; } // no table for an ALP rowgroup
 	}
 	__syncthreads();
 	if (s_scheme != ALPGPU_SCHEME_ALP_RD) { return; }
@@ -374,6 +376,11 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 		// the reference's order of equally frequent left parts is libstdc++'s (rd_dictionary_order.hpp): replayed by one lane
 		if (lane == 0) { rd_reference_order(s_order, distinct); }
 		wave_lds_sync();
+		if (rd_order) { // the whole sorted order, for the encoders' exception-slot indices (alpgpu_column.d_rd_order)
+			uint16_t* o = rd_order + rg * ALPGPU_RD_ORDER_STRIDE;
+			for (int i = lane; i < distinct; i += 64) { o[1 + i] = static_cast<uint16_t>(s_order.sorted[i] & 0xFFFFu); }
+			if (lane == 0) { o[0] = static_cast<uint16_t>(distinct); }
+		}
 		if (lane == 0) {
 			const int lbw        = ds <= 2 ? 1 : (ds <= 4 ? 2 : 3);
 			rgs[rg].rd_rbw       = static_cast<uint8_t>(rbw);
@@ -384,30 +391,32 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	}
 }
 
-int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs) {
+int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order) {
 	if (n_vectors == 0) { return ALPGPU_OK; }
 	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
-	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0);
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
+	                   d_rd_order);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, true>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
-	                   force_rd);
+	                   force_rd, static_cast<uint16_t*>(nullptr));
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 // single precision: alp::encoder<float>::init / alp::rd_encoder<float>::init
-int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs) {
+int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order) {
 	if (n_vectors == 0) { return ALPGPU_OK; }
 	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
-	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0);
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
+	                   d_rd_order);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, true>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
-	                   force_rd);
+	                   force_rd, static_cast<uint16_t*>(nullptr));
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

@@ -12,7 +12,7 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int variant);
 
 // init_kernels.hip
-int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs);
+int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order);
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
 
@@ -54,7 +54,7 @@ int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t*
 
 // ---- single precision (decode_f32_kernels.hip, encode_f32_kernels.hip, init_kernels.hip, primitive_f32_kernels.hip) ----
 int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores);
-int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs);
+int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order);
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
 int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace);
 int launch_pad_tail_f32(hipStream_t stream, float* d_in, uint64_t n_values);

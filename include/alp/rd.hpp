@@ -3,8 +3,8 @@
 // Dictionary order.  The reference builds the left-part histogram in a std::unordered_map and std::sort()s it by count
 // only, so the order of equally frequent left parts is whatever libstdc++ produces.  The device builder
 // replays those container internals (alp_amd/csrc/rd_dictionary_order.hpp) and returns the reference's dictionary entry
-// by entry.  Left parts outside the dictionary are packed as index = dictionary size (the reference packs a map position
-// there, which no decoder reads).  A state produced by the reference itself can be passed to encode()/decode() unchanged.
+// by entry.  Through this per-vector header, left parts outside the dictionary get index = dictionary size (the reference
+// stores a map position there, which no decoder reads; the batch C ABI reproduces it, see alpgpu_column.d_rd_order).  A state produced by the reference itself can be passed to encode()/decode() unchanged.
 #ifndef ALP_RD_HPP
 #define ALP_RD_HPP
 #include "alp/common.hpp"

@@ -119,7 +119,15 @@ typedef struct alpgpu_column {
 	 * alpgpu_column_from_blob; decode uses them only to pick its launch shape (ALPGPU_OPT_DECODE_VECTORS_PER_WG = 0 "auto") */
 	uint64_t               packed_bytes_hint;
 	uint64_t               exc_bytes_hint;
+	/* optional (NULL = absent; ABI version 2), ALP_RD rowgroups only: ALPGPU_RD_ORDER_STRIDE u16 words per rowgroup =
+	 * { D, then the D distinct sampled left parts in the reference's sorted order (left_parts_sorted_repetitions,
+	 * include/alp/rd.hpp:47-60) }.  alpgpu_rowgroup_init_* writes it; alpgpu_encode_vectors_* reads it to pack, at exception
+	 * slots, the left index the reference packs there (its map position, rd.hpp:69-77, :130-135).  Without it those slots
+	 * carry the dictionary size.  No decoder reads these bits; a table that does not start with the rowgroup's dictionary
+	 * (e.g. states supplied by the caller) is ignored. */
+	uint16_t*              d_rd_order;
 } alpgpu_column;
+#define ALPGPU_RD_ORDER_STRIDE 296u
 
 /* ---- context / plumbing ------------------------------------------------------------------------- */
 int         alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx);

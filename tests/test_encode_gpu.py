@@ -137,7 +137,7 @@ def test_rd_vectors_with_reference_state_bit_exact(ctx, oracle, name):
 @pytest.mark.parametrize("name", list(RD_COLUMNS.keys()))
 def test_rd_rowgroup_init_matches_reference_decisions(ctx, oracle, name):
     """Own rowgroup init: scheme, cut (right/left bit width), dictionary size AND the dictionary entries in order equal the
-    oracle's (== the reference's), so every ALP_RD stream byte except the left index at exception slots is the reference's."""
+    oracle's (== the reference's), and with the rowgroup's sorted-order table every stream byte is the reference's."""
     col_np = RD_COLUMNS[name]()
     want = oracle.encode_column(col_np)
     dcol, x = gpu_encode(ctx, col_np)
@@ -152,12 +152,11 @@ def test_rd_rowgroup_init_matches_reference_decisions(ctx, oracle, name):
     assert np.array_equal(rg["rd_dict"][rd], w_rg["rd_dict"][rd]), name
     got = layout.expand(rg, vec, packed, exc)
     assert_parts_equal(got, want, name)
-    for v in np.nonzero(want["scheme"] == 1)[0]:
-        a = oracle.unffor_u16(got["packed_left"][v], int(want["lbw"][v]))
-        b = oracle.unffor_u16(want["packed_left"][v], int(want["lbw"][v]))
-        keep = np.ones(1024, bool)
-        keep[want["pos"][v, : int(want["exc_cnt"][v])]] = False
-        assert np.array_equal(a[keep], b[keep]), f"{name}: left dictionary indices differ in vector {v}"
+    # ... and the packed left streams in EVERY bit, exception slots included (alpgpu_column.d_rd_order), so whole streams match
+    assert np.array_equal(got["packed_left"], want["packed_left"]), f"{name}: packed left streams differ"
+    w_rg2, w_vec, w_packed, w_exc = layout.compact(want)
+    assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
+    assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc), f"{name}: whole streams must be byte-identical"
     assert np.array_equal(rg["k"][~rd], w_rg["k"][~rd]) and np.array_equal(rg["combos"][~rd], w_rg["combos"][~rd])
     out = ctx.decode(dcol)
     ctx.synchronize()

@@ -147,10 +147,9 @@ def test_synthetic_float_columns_encode_bit_exact(ctx, of32, name):
     assert np.array_equal(rg["rd_rbw"], w_rg["rd_rbw"]) and np.array_equal(rg["rd_lbw"], w_rg["rd_lbw"]) and np.array_equal(rg["rd_dict_size"], w_rg["rd_dict_size"])
     assert np.array_equal(rg["rd_dict"], w_rg["rd_dict"]), "ALP_RD dictionaries must come out in the reference's order"
     assert_parts_equal(got, want, name)
-    if alp_rg.all():
-        assert_parts_equal(got, want, name)
-        assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
-        assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc), "whole streams must be byte-identical"
+    # ALP and ALP_RD alike: offsets and whole streams are the oracle's bytes (exception-slot left indices included)
+    assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
+    assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc), "whole streams must be byte-identical"
     out = ctx.decode(dcol)
     ctx.synchronize()
     assert torch.equal(out.view(torch.int32), x.view(torch.int32))
