@@ -88,6 +88,8 @@ _sig("alpgpu_ffor_i64", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
 _sig("alpgpu_unffor_i64", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
 _sig("alpgpu_ffor_u16", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
 _sig("alpgpu_unffor_u16", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
+_sig("alpgpu_ffor_u8", _int, _vp, _vp, _vp, _sz, _vp, _vp, _u64)
+_sig("alpgpu_unffor_u8", _int, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
 _sig("alpgpu_falp_f64", _int, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _u64)
 _sig("alpgpu_decode_values_f64", _int, _vp, _vp, _vp, _vp, _vp, _u64)
 _sig("alpgpu_patch_f64", _int, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
@@ -257,6 +259,12 @@ class Context:
 
     def unffor_u16(self, packed, out, bw, base=None):
         _check(lib.alpgpu_unffor_u16(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), out.shape[0]), "alpgpu_unffor_u16")
+
+    def ffor_u8(self, vals, packed, bw, base=None):
+        _check(lib.alpgpu_ffor_u8(self.h, self._p(vals), self._p(packed), packed.shape[1], self._p(bw), self._p(base), vals.shape[0]), "alpgpu_ffor_u8")
+
+    def unffor_u8(self, packed, out, bw, base=None):
+        _check(lib.alpgpu_unffor_u8(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), out.shape[0]), "alpgpu_unffor_u8")
 
     def falp(self, packed, out, bw, base, fac, exp):
         _check(lib.alpgpu_falp_f64(self.h, self._p(packed), packed.shape[1], self._p(out), self._p(bw), self._p(base), self._p(fac), self._p(exp),

@@ -324,6 +324,14 @@ int alpgpu_unffor_u16(alpgpu_ctx* ctx, const uint16_t* d_packed, size_t packed_s
 	ALPGPU_PRIM(d_packed && d_out && d_bw,
 	            alpgpu::launch_unffor_u16(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, n_vectors));
 }
+int alpgpu_ffor_u8(alpgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_packed, size_t packed_stride, const uint8_t* d_bw, const uint8_t* d_base,
+                   uint64_t n_vectors) {
+	ALPGPU_PRIM(d_in && d_packed && d_bw, alpgpu::launch_ffor_u8(ctx->stream, ctx->n_cus, d_in, d_packed, packed_stride, d_bw, d_base, n_vectors));
+}
+int alpgpu_unffor_u8(alpgpu_ctx* ctx, const uint8_t* d_packed, size_t packed_stride, uint8_t* d_out, const uint8_t* d_bw, const uint8_t* d_base,
+                     uint64_t n_vectors) {
+	ALPGPU_PRIM(d_packed && d_out && d_bw, alpgpu::launch_unffor_u8(ctx->stream, ctx->n_cus, d_packed, packed_stride, d_out, d_bw, d_base, n_vectors));
+}
 int alpgpu_falp_f64(alpgpu_ctx* ctx, const int64_t* d_packed, size_t packed_stride, double* d_out, const uint8_t* d_bw,
                     const int64_t* d_base, const uint8_t* d_fac, const uint8_t* d_exp, uint64_t n_vectors) {
 	ALPGPU_PRIM(d_packed && d_out && d_bw && d_base && d_fac && d_exp,

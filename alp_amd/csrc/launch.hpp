@@ -36,6 +36,8 @@ int launch_ffor_u16(hipStream_t stream, int n_cus, const uint16_t* in, uint16_t*
                     const uint16_t* base, uint64_t n);
 int launch_unffor_u16(hipStream_t stream, int n_cus, const uint16_t* packed, size_t stride, uint16_t* out, const uint8_t* bw,
                       const uint16_t* base, uint64_t n);
+int launch_ffor_u8(hipStream_t stream, int n_cus, const uint8_t* in, uint8_t* packed, size_t stride, const uint8_t* bw, const uint8_t* base, uint64_t n);
+int launch_unffor_u8(hipStream_t stream, int n_cus, const uint8_t* packed, size_t stride, uint8_t* out, const uint8_t* bw, const uint8_t* base, uint64_t n);
 int launch_decode_values(hipStream_t stream, int n_cus, const int64_t* enc, double* out, const uint8_t* fac, const uint8_t* exp,
                          uint64_t n);
 int launch_patch(hipStream_t stream, int n_cus, double* out, const double* exc, const uint16_t* pos, size_t stride,

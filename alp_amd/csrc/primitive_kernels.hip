@@ -164,6 +164,57 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_unffor_u16(const uint16_t*
 	}
 }
 
+// ---- FFOR / unFFOR, 8-bit lanes (src/fastlanes_generated_ffor.cpp:4-356): 128 lane-streams x 8 rows, value i -> stream i & 127,
+// row i >> 7, stream word k at out[128*k + stream].  Lane L owns streams 2L and 2L+1: 16-bit accesses, 128 B per instruction.
+// A stream is 8*bw <= 64 bits: one u64 accumulator each.
+__global__ __launch_bounds__(64 * kWavesPerWg) void k_ffor_u8(const uint8_t* __restrict__ in, uint8_t* __restrict__ packed, size_t packed_stride,
+                                                              const uint8_t* __restrict__ bws, const uint8_t* __restrict__ bases, uint64_t n) {
+	const int lane = lane_id();
+	ALPGPU_VECTOR_LOOP(v, n) {
+		const int bw = bws[v];
+		if (bw < 1 || bw > 8) { continue; }
+		const uint32_t  base = bases ? bases[v] : 0;
+		const uint32_t  mask = (1u << bw) - 1u;
+		const uint16_t* src  = reinterpret_cast<const uint16_t*>(in + v * kVec);
+		uint16_t*       dst  = reinterpret_cast<uint16_t*>(packed + v * packed_stride);
+		uint64_t        a0 = 0, a1 = 0;
+#pragma unroll
+		for (int row = 0; row < 8; ++row) {
+			const uint32_t w = src[64 * row + lane];
+			a0 |= static_cast<uint64_t>(((w & 0xFFu) - base) & mask) << (row * bw);
+			a1 |= static_cast<uint64_t>(((w >> 8) - base) & mask) << (row * bw);
+		}
+		for (int k = 0; k < bw; ++k) {
+			dst[64 * k + lane] = static_cast<uint16_t>((static_cast<uint32_t>(a0 >> (8 * k)) & 0xFFu) | ((static_cast<uint32_t>(a1 >> (8 * k)) & 0xFFu) << 8));
+		}
+	}
+}
+
+__global__ __launch_bounds__(64 * kWavesPerWg) void k_unffor_u8(const uint8_t* __restrict__ packed, size_t packed_stride, uint8_t* __restrict__ out,
+                                                                const uint8_t* __restrict__ bws, const uint8_t* __restrict__ bases, uint64_t n) {
+	const int lane = lane_id();
+	ALPGPU_VECTOR_LOOP(v, n) {
+		const int bw = bws[v];
+		if (bw > 8) { continue; }
+		const uint32_t  base = bases ? bases[v] : 0;
+		const uint32_t  mask = (1u << bw) - 1u;
+		const uint16_t* src  = reinterpret_cast<const uint16_t*>(packed + v * packed_stride);
+		uint16_t*       dst  = reinterpret_cast<uint16_t*>(out + v * kVec);
+		uint64_t        a0 = 0, a1 = 0;
+		for (int k = 0; k < bw; ++k) {
+			const uint32_t w = src[64 * k + lane];
+			a0 |= static_cast<uint64_t>(w & 0xFFu) << (8 * k);
+			a1 |= static_cast<uint64_t>(w >> 8) << (8 * k);
+		}
+#pragma unroll
+		for (int row = 0; row < 8; ++row) {
+			const uint32_t x = (static_cast<uint32_t>(a0 >> (row * bw)) & mask) + base;
+			const uint32_t y = (static_cast<uint32_t>(a1 >> (row * bw)) & mask) + base;
+			dst[64 * row + lane] = static_cast<uint16_t>((x & 0xFFu) | ((y & 0xFFu) << 8));
+		}
+	}
+}
+
 // ---- decoder::decode, patch_exceptions, analyze_ffor ------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerWg) void k_decode_values(const int64_t* __restrict__ enc, double* __restrict__ out,
                                                                     const uint8_t* __restrict__ facs, const uint8_t* __restrict__ exps,
@@ -365,6 +416,12 @@ int launch_ffor_u16(hipStream_t stream, int n_cus, const uint16_t* in, uint16_t*
 int launch_unffor_u16(hipStream_t stream, int n_cus, const uint16_t* packed, size_t stride, uint16_t* out, const uint8_t* bw,
                       const uint16_t* base, uint64_t n) {
 	PRIM_LAUNCH(k_unffor_u16, packed, stride, out, bw, base, n);
+}
+int launch_ffor_u8(hipStream_t stream, int n_cus, const uint8_t* in, uint8_t* packed, size_t stride, const uint8_t* bw, const uint8_t* base, uint64_t n) {
+	PRIM_LAUNCH(k_ffor_u8, in, packed, stride, bw, base, n);
+}
+int launch_unffor_u8(hipStream_t stream, int n_cus, const uint8_t* packed, size_t stride, uint8_t* out, const uint8_t* bw, const uint8_t* base, uint64_t n) {
+	PRIM_LAUNCH(k_unffor_u8, packed, stride, out, bw, base, n);
 }
 int launch_decode_values(hipStream_t stream, int n_cus, const int64_t* enc, double* out, const uint8_t* fac, const uint8_t* exp,
                          uint64_t n) {

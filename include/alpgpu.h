@@ -25,7 +25,7 @@
  *                              unffor::unffor(uint64/uint16)          include/fastlanes/unffor.hpp:7-15
  *                              alp::rd_encoder<double>::decode        include/alp/rd.hpp:152-178
  *   alpgpu_decode_sum_f64      falp + patch_exceptions fused with a SUM consumer (bench_end_to_end .../queries/q1.cpp:63-104)
- *   alpgpu_ffor_i64 / alpgpu_unffor_i64 / alpgpu_ffor_u16 / alpgpu_unffor_u16
+ *   alpgpu_ffor_i64 / alpgpu_unffor_i64 / alpgpu_ffor_u16 / alpgpu_unffor_u16 / alpgpu_ffor_u8 / alpgpu_unffor_u8 (+ _i32, float section)
  *                              ffor::ffor / unffor::unffor            include/fastlanes/{ffor,unffor}.hpp:7-15
  *   alpgpu_falp_f64            falp (no exception patching)           include/alp/falp.hpp:10-26
  *   alpgpu_decode_values_f64   alp::decoder<double>::decode           include/alp/decoder.hpp:134-138
@@ -241,6 +241,12 @@ int alpgpu_ffor_u16(alpgpu_ctx* ctx, const uint16_t* d_in, uint16_t* d_packed, s
                     const uint8_t* d_bw, const uint16_t* d_base, uint64_t n_vectors);
 int alpgpu_unffor_u16(alpgpu_ctx* ctx, const uint16_t* d_packed, size_t packed_stride, uint16_t* d_out,
                       const uint8_t* d_bw, const uint16_t* d_base, uint64_t n_vectors);
+
+/* 8-bit lanes (128 lane-streams x 8 rows; not used by the codec, part of the reference's ffor/unffor API: include/fastlanes/ffor.hpp:10) */
+int alpgpu_ffor_u8(alpgpu_ctx* ctx, const uint8_t* d_in, uint8_t* d_packed, size_t packed_stride, const uint8_t* d_bw,
+                   const uint8_t* d_base, uint64_t n_vectors);
+int alpgpu_unffor_u8(alpgpu_ctx* ctx, const uint8_t* d_packed, size_t packed_stride, uint8_t* d_out, const uint8_t* d_bw,
+                     const uint8_t* d_base, uint64_t n_vectors);
 
 /* falp without exception patching: packed -> doubles */
 int alpgpu_falp_f64(alpgpu_ctx* ctx, const int64_t* d_packed, size_t packed_stride, double* d_out,

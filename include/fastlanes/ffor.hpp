@@ -1,6 +1,6 @@
 // fastlanes/ffor.hpp — ffor::ffor with the reference's signatures (include/fastlanes/ffor.hpp:7-15) for the word sizes
-// the ALP path uses: 64-bit (double: ALP integers, ALP_RD right parts), 32-bit (float: the same) and 16-bit (ALP_RD left
-// parts).  GPU-backed.  8-bit lanes are not used by the codec and are not declared.
+// of the reference: 64-bit (double: ALP integers, ALP_RD right parts), 32-bit (float: the same), 16-bit (ALP_RD left parts) and
+// 8-bit (unused by the codec, part of the API).  GPU-backed.
 #ifndef FASTLANES_FFOR_HPP
 #define FASTLANES_FFOR_HPP
 #include "alp/gpu_bridge.hpp"
@@ -48,6 +48,20 @@ inline void ffor(const uint32_t* __restrict in, uint32_t* __restrict out, uint8_
 }
 inline void ffor(const int32_t* __restrict in, int32_t* __restrict out, uint8_t bw, const int32_t* __restrict a_base_p) {
 	ffor(reinterpret_cast<const uint32_t*>(in), reinterpret_cast<uint32_t*>(out), bw, reinterpret_cast<const uint32_t*>(a_base_p));
+}
+
+inline void ffor(const uint8_t* __restrict in, uint8_t* __restrict out, uint8_t bw, const uint8_t* __restrict a_base_p) {
+	if (bw == 0 || bw > 8) { return; }
+	auto& s = alp::gpu::tls();
+	alp::gpu::h2d(s.at<uint8_t>(s.LEFT), in, 1024);
+	alp::gpu::h2d(s.bw(), &bw, 1);
+	alp::gpu::h2d(s.at<uint8_t>(s.META + 24), a_base_p, 1);
+	alp::gpu::check(alpgpu_ffor_u8(alp::gpu::context(), s.at<uint8_t>(s.LEFT), s.at<uint8_t>(s.PACKED_LEFT), 1024, s.bw(), s.at<uint8_t>(s.META + 24), 1),
+	                "alpgpu_ffor_u8");
+	alp::gpu::d2h(out, s.at<uint8_t>(s.PACKED_LEFT), static_cast<size_t>(bw) * 128);
+}
+inline void ffor(const int8_t* __restrict in, int8_t* __restrict out, uint8_t bw, const int8_t* __restrict a_base_p) {
+	ffor(reinterpret_cast<const uint8_t*>(in), reinterpret_cast<uint8_t*>(out), bw, reinterpret_cast<const uint8_t*>(a_base_p));
 }
 
 } // namespace fastlanes::generated::ffor::fallback::scalar

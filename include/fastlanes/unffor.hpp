@@ -1,4 +1,4 @@
-// fastlanes/unffor.hpp — unffor::unffor with the reference's signatures (include/fastlanes/unffor.hpp:7-15), 64-, 32- and 16-bit lanes.
+// fastlanes/unffor.hpp — unffor::unffor with the reference's signatures (include/fastlanes/unffor.hpp:7-15), 64-, 32-, 16- and 8-bit lanes.
 #ifndef FASTLANES_UNFFOR_HPP
 #define FASTLANES_UNFFOR_HPP
 #include "alp/gpu_bridge.hpp"
@@ -46,6 +46,20 @@ inline void unffor(const uint32_t* __restrict in, uint32_t* __restrict out, uint
 }
 inline void unffor(const int32_t* __restrict in, int32_t* __restrict out, uint8_t bw, const int32_t* __restrict a_base_p) {
 	unffor(reinterpret_cast<const uint32_t*>(in), reinterpret_cast<uint32_t*>(out), bw, reinterpret_cast<const uint32_t*>(a_base_p));
+}
+
+inline void unffor(const uint8_t* __restrict in, uint8_t* __restrict out, uint8_t bw, const uint8_t* __restrict a_base_p) {
+	if (bw > 8) { return; }
+	auto& s = alp::gpu::tls();
+	if (bw) { alp::gpu::h2d(s.at<uint8_t>(s.PACKED_LEFT), in, static_cast<size_t>(bw) * 128); }
+	alp::gpu::h2d(s.bw(), &bw, 1);
+	alp::gpu::h2d(s.at<uint8_t>(s.META + 24), a_base_p, 1);
+	alp::gpu::check(alpgpu_unffor_u8(alp::gpu::context(), s.at<uint8_t>(s.PACKED_LEFT), 1024, s.at<uint8_t>(s.LEFT), s.bw(), s.at<uint8_t>(s.META + 24), 1),
+	                "alpgpu_unffor_u8");
+	alp::gpu::d2h(out, s.at<uint8_t>(s.LEFT), 1024);
+}
+inline void unffor(const int8_t* __restrict in, int8_t* __restrict out, uint8_t bw, const int8_t* __restrict a_base_p) {
+	unffor(reinterpret_cast<const uint8_t*>(in), reinterpret_cast<uint8_t*>(out), bw, reinterpret_cast<const uint8_t*>(a_base_p));
 }
 
 } // namespace fastlanes::generated::unffor::fallback::scalar

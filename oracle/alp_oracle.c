@@ -479,6 +479,37 @@ void alpo_unffor_u16(const uint16_t* in, uint16_t* out, int bw, uint16_t base) {
 }
 
 /* ---- decode ------------------------------------------------------------------------------------------ */
+/* u8: src/fastlanes_generated_ffor.cpp:4-356 (dispatch :29749 ff.).  128 lane-streams x 8 rows; value i -> lane = i % 128,
+ * row = i / 128; stream word k lives at out[128*k + lane].  bw = 0 writes nothing; bw = 8 does not mask; bw > 8 is a no-op. */
+void alpo_ffor_u8(const uint8_t* in, uint8_t* out, int bw, uint8_t base) {
+	if (bw <= 0 || bw > 8) { return; }
+	const unsigned mask = (1u << bw) - 1u;
+	for (int w = 0; w < 128 * bw; w++) { out[w] = 0; }
+	for (int i = 0; i < VECTOR_SIZE; i++) {
+		const int      lane = i % 128, row = i / 128;
+		const unsigned v = ((unsigned)(uint8_t)(in[i] - base)) & mask;
+		const int      p = row * bw, k = p / 8, s = p % 8;
+		out[128 * k + lane] |= (uint8_t)(v << s);
+		if (s + bw > 8) { out[128 * (k + 1) + lane] |= (uint8_t)(v >> (8 - s)); }
+	}
+}
+
+void alpo_unffor_u8(const uint8_t* in, uint8_t* out, int bw, uint8_t base) {
+	if (bw < 0 || bw > 8) { return; }
+	if (bw == 0) {
+		for (int i = 0; i < VECTOR_SIZE; i++) { out[i] = base; }
+		return;
+	}
+	const unsigned mask = (1u << bw) - 1u;
+	for (int i = 0; i < VECTOR_SIZE; i++) {
+		const int lane = i % 128, row = i / 128;
+		const int p = row * bw, k = p / 8, s = p % 8;
+		unsigned  v = (unsigned)in[128 * k + lane] >> s;
+		if (s + bw > 8) { v |= (unsigned)in[128 * (k + 1) + lane] << (8 - s); }
+		out[i] = (uint8_t)((v & mask) + base);
+	}
+}
+
 /* include/alp/decoder.hpp:134-138 */
 void alpo_decode(const int64_t* enc, int fac, int exp, double* out) {
 	for (int i = 0; i < VECTOR_SIZE; i++) { out[i] = alpo_decode_value(enc[i], fac, exp); }

@@ -47,6 +47,10 @@ void alpo_unffor_u64(const uint64_t* in, uint64_t* out, int bw, uint64_t base);
 void alpo_ffor_u16(const uint16_t* in, uint16_t* out, int bw, uint16_t base);
 void alpo_unffor_u16(const uint16_t* in, uint16_t* out, int bw, uint16_t base);
 
+/* 8-bit lanes (not used by the codec; part of the reference's ffor/unffor API, include/fastlanes/ffor.hpp:10) */
+void alpo_ffor_u8(const uint8_t* in, uint8_t* out, int bw, uint8_t base);
+void alpo_unffor_u8(const uint8_t* in, uint8_t* out, int bw, uint8_t base);
+
 void alpo_decode(const int64_t* enc, int fac, int exp, double* out);
 void alpo_falp(const uint64_t* in, double* out, int bw, uint64_t base, int fac, int exp);
 void alpo_patch(double* out, const double* exc, const uint16_t* pos, uint16_t cnt);

@@ -111,6 +111,18 @@ class Oracle(_Base):
         self.fn("unffor_u16")(_p(packed), _p(out), C.c_int(bw), C.c_uint16(base))
         return out
 
+    def ffor_u8(self, vals, bw, base=0):
+        vals = np.ascontiguousarray(vals, np.uint8)
+        out = np.zeros(1024, np.uint8)
+        self.fn("ffor_u8")(_p(vals), _p(out), C.c_int(bw), C.c_uint8(base))
+        return out
+
+    def unffor_u8(self, packed, bw, base=0):
+        packed = np.ascontiguousarray(packed, np.uint8)
+        out = np.zeros(1024, np.uint8)
+        self.fn("unffor_u8")(_p(packed), _p(out), C.c_int(bw), C.c_uint8(base))
+        return out
+
     def falp(self, packed: np.ndarray, bw: int, base: int, fac: int, exp: int) -> np.ndarray:
         packed = np.ascontiguousarray(packed).view(np.uint64)
         out = np.zeros(1024, np.float64)
@@ -177,6 +189,20 @@ class Reference(_Base):
         out = np.zeros(1024, np.uint16)
         b = np.array([base], np.uint16)
         self.fn("unffor_u16")(_p(packed), _p(out), C.c_uint8(bw), _p(b))
+        return out
+
+    def ffor_u8(self, vals, bw, base=0):
+        vals = np.ascontiguousarray(vals, np.uint8)
+        out = np.zeros(1024, np.uint8)
+        b = np.array([base], np.uint8)
+        self.fn("ffor_u8")(_p(vals), _p(out), C.c_uint8(bw), _p(b))
+        return out
+
+    def unffor_u8(self, packed, bw, base=0):
+        packed = np.ascontiguousarray(packed, np.uint8)
+        out = np.zeros(1024, np.uint8)
+        b = np.array([base], np.uint8)
+        self.fn("unffor_u8")(_p(packed), _p(out), C.c_uint8(bw), _p(b))
         return out
 
     def falp(self, packed, bw, base, fac, exp):

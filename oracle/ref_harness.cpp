@@ -116,6 +116,8 @@ void ref_ffor_u16(const uint16_t* in, uint16_t* out, uint8_t bw, const uint16_t*
 void ref_unffor_u16(const uint16_t* in, uint16_t* out, uint8_t bw, const uint16_t* base) {
 	unffor::unffor(in, out, bw, base);
 }
+void ref_ffor_u8(const uint8_t* in, uint8_t* out, uint8_t bw, const uint8_t* base) { ffor::ffor(in, out, bw, base); }
+void ref_unffor_u8(const uint8_t* in, uint8_t* out, uint8_t bw, const uint8_t* base) { unffor::unffor(in, out, bw, base); }
 void ref_falp(const int64_t* in, double* out, uint8_t bw, const int64_t* base, uint8_t fac, uint8_t exp) {
 	generated::falp::fallback::scalar::falp(in, out, bw, base, fac, exp);
 }

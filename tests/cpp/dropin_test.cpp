@@ -106,6 +106,24 @@ static int test_column(const std::string& dir, const std::string& name, size_t n
 	return failures;
 }
 
+// 8-bit lanes of ffor / unffor (not used by the codec; part of the reference's API): pack, unpack, compare
+static int test_u8_lanes() {
+	int failures = 0;
+	for (int bw = 0; bw <= 8; ++bw) {
+		std::vector<uint8_t> in(1024), packed(1024, 0), out(1024, 0xAA);
+		const uint8_t        base = static_cast<uint8_t>(17 * bw + 3);
+		for (int i = 0; i < 1024; ++i) { in[i] = static_cast<uint8_t>(base + ((i * 37 + 11) & ((1 << bw) - 1))); }
+		ffor::ffor(in.data(), packed.data(), static_cast<uint8_t>(bw), &base);
+		unffor::unffor(packed.data(), out.data(), static_cast<uint8_t>(bw), &base);
+		if (in != out) {
+			std::printf("FAIL u8 lanes bw=%d\n", bw);
+			++failures;
+		}
+	}
+	if (!failures) { std::printf("ok   u8 ffor/unffor bw 0..8\n"); }
+	return failures;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 2) { return 2; }
 	const std::string dir = argv[1];
@@ -117,6 +135,7 @@ int main(int argc, char** argv) {
 		failures += type == "f32" ? test_column<float>(dir, name, n_values, bw, exc, rd) : test_column<double>(dir, name, n_values, bw, exc, rd);
 		++n;
 	}
+	failures += test_u8_lanes();
 	std::printf("%d columns, %d failures\n", n, failures);
 	return failures ? 1 : 0;
 }

@@ -35,6 +35,17 @@ def test_ffor_unffor_u16_all_bit_widths(oracle, ref, bw):
     assert np.array_equal(oracle.unffor_u16(b, bw), vals)
 
 
+@pytest.mark.parametrize("bw", list(range(0, 9)))
+def test_ffor_unffor_u8_all_bit_widths(oracle, ref, bw):
+    rng = np.random.default_rng(200 + bw)
+    base = int(rng.integers(0, 256))
+    vals = (((rng.integers(0, 256, 1024) & ((1 << bw) - 1)) + base) & 0xFF).astype(np.uint8)
+    a, b = oracle.ffor_u8(vals, bw, base), ref.ffor_u8(vals, bw, base)
+    assert np.array_equal(a[:128 * bw], b[:128 * bw])
+    assert np.array_equal(oracle.unffor_u8(b, bw, base), ref.unffor_u8(b, bw, base))
+    assert np.array_equal(oracle.unffor_u8(b, bw, base), vals)
+
+
 @pytest.mark.parametrize("name", list(datagen.adversarial_vectors().keys()))
 @pytest.mark.parametrize("ef", [(14, 12), (18, 18), (0, 0), (5, 2), (16, 0)])
 def test_encode_simdized_corner_cases(oracle, ref, name, ef):

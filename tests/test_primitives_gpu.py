@@ -68,6 +68,26 @@ def test_ffor_unffor_u16_every_bit_width(ctx, oracle):
     assert np.array_equal(d_out.cpu().numpy().view(np.uint16), vals)
 
 
+def test_ffor_unffor_u8_every_bit_width(ctx, oracle):
+    rng = np.random.default_rng(7)
+    bws = np.arange(0, 9, dtype=np.uint8)
+    n = bws.size
+    base = rng.integers(0, 256, n).astype(np.uint8)
+    vals = np.stack([(((rng.integers(0, 256, 1024) & ((1 << int(b)) - 1)) + int(base[i])) & 0xFF).astype(np.uint8) for i, b in enumerate(bws)])
+    want = np.stack([oracle.ffor_u8(vals[i], int(bws[i]), int(base[i])) for i in range(n)])
+    d_packed = torch.zeros((n, 1024), dtype=torch.uint8, device="cuda")
+    ctx.ffor_u8(cu(vals), d_packed, cu(bws), cu(base))
+    ctx.synchronize()
+    got = d_packed.cpu().numpy()
+    for i, bw in enumerate(bws):
+        assert np.array_equal(got[i, :128 * int(bw)], want[i, :128 * int(bw)]), f"ffor u8 bw={bw}"
+        assert not got[i, 128 * int(bw):].any()
+    d_out = torch.zeros((n, 1024), dtype=torch.uint8, device="cuda")
+    ctx.unffor_u8(cu(want), d_out, cu(bws), cu(base))
+    ctx.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), vals)
+
+
 def test_encode_simdized_analyze_patch(ctx, oracle):
     cases = datagen.adversarial_vectors()
     efs = [(14, 12), (18, 18), (0, 0), (5, 2), (16, 0)]
