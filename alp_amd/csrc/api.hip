@@ -256,6 +256,9 @@ int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	return ALPGPU_OK;
 }
 
+// Rowgroup init, then the vector encode, on the context's stream.  (Running the rowgroup search of the next chunk of the column
+// on a second stream while the vector encode of the current chunk runs was tried: 26 % SLOWER on MI355X — the single-pass
+// encode wants the whole device for its in-order tiles)
 int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
 	if (int rc = alpgpu_rowgroup_init_f64(ctx, d_in, n_vectors, col)) { return rc; }
 	return alpgpu_encode_vectors_f64(ctx, d_in, n_vectors, col);

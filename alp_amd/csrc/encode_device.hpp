@@ -304,6 +304,45 @@ __device__ __forceinline__ void for_each_exception(const uint64_t (&ballot)[8][2
 // ---- FFOR u64 pack from LDS (closed form of src/fastlanes_generated_ffor.cpp:7379-29749) -------------------
 // vals[i] hold (value - base) & mask in natural index order.  Output unit u = 8*k + a is the 16-byte pair of
 // stream word k for lane16 columns 2a, 2a+1; lane handles units lane, lane+64, ... -> 1-KiB contiguous stores.
+// The same packing, kept in registers: unit lane + 64*t goes to acc[t] (t < ceil(8*bw / 64) <= 8).  The single-pass encode
+// packs BEFORE it waits for its output offset, so that only the stores remain behind the wait (store_packed_units).
+typedef unsigned long long ull2v __attribute__((ext_vector_type(2)));
+struct PackedUnits {
+	ull2v acc[8];
+};
+__device__ __forceinline__ void pack_u64_units(const EncodeLds& L, int bw, int lane, PackedUnits& P) {
+	const ull2v* vals2   = reinterpret_cast<const ull2v*>(L.vals);
+	const int    n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		ull2v     acc = {0ull, 0ull};
+		const int u   = lane + 64 * t;
+		if (64 * t < n_units && u < n_units) { // first test is wave-uniform
+			const int k    = u >> 3;
+			const int a    = u & 7;
+			const int bit0 = 64 * k;
+			int       r    = bit0 / bw;
+			int       p    = r * bw;
+			while (p < bit0 + 64 && r < 64) {
+				const ull2v v  = vals2[8 * r + a];
+				const int   sh = p - bit0;
+				acc |= sh >= 0 ? (v << static_cast<unsigned long long>(sh)) : (v >> static_cast<unsigned long long>(-sh));
+				p += bw;
+				++r;
+			}
+		}
+		P.acc[t] = acc;
+	}
+}
+__device__ __forceinline__ void store_packed_units(const PackedUnits& P, int bw, ull2v* __restrict__ out, int lane) {
+	const int n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		const int u = lane + 64 * t;
+		if (64 * t < n_units && u < n_units) { out[u] = P.acc[t]; }
+	}
+}
+
 __device__ __forceinline__ void pack_u64_from_lds(const EncodeLds& L, int bw, ulonglong2* __restrict__ out, int lane) {
 	const ulonglong2* vals2   = reinterpret_cast<const ulonglong2*>(L.vals);
 	const int         n_units = 8 * bw;

@@ -139,13 +139,11 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	if (lane == 0) {
 		s_size[wave]           = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (arrived == kWavesPerWg - 1 && tile != 0) {
+		if (arrived == kWavesPerWg - 1) {
 			uint64_t aggregate = 0;
 #pragma unroll
 			for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
-			uint64_t expected = 0;
-			__hip_atomic_compare_exchange_strong(status + tile, &expected, kFlagAggregate | aggregate, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-			                                     __HIP_MEMORY_SCOPE_AGENT);
+			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
@@ -216,18 +214,23 @@ __global__ void k_fused_finish_f32(uint64_t* __restrict__ totals) {
 	totals[1] = totals[5];
 }
 
-int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
-	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-	for (uint64_t first = 0; first < n_vectors; first += kFusedMaxVectors) {
-		const uint64_t n_launch = n_vectors - first < kFusedMaxVectors ? n_vectors - first : kFusedMaxVectors;
+int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range) {
+	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
+		const uint64_t left     = v_first + n_range - first;
+		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kWavesPerWg - 1) / kWavesPerWg;
-		if (hipMemsetAsync(d_workspace, 0, n_tiles * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		hipLaunchKernelGGL(k_encode_fused_f32, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
 		                   n_launch, col->d_rd_order);
 		hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(1), 0, stream, col->d_totals);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors);
 }
 
 } // namespace alpgpu

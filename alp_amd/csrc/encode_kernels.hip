@@ -25,6 +25,18 @@ namespace alpgpu {
 
 constexpr int kScanTile = 1024;
 
+#ifdef ALPGPU_FUSED_TIMING // experiment builds only: where a wavefront of k_encode_fused spends its life (sums of s_memtime deltas)
+__device__ unsigned int* g_fused_phase; // [n_vectors][4] deltas, written by lane 0 of the vector's wavefront
+#define ALPGPU_PHASE_MARK(k)                                                                                           \
+	do {                                                                                                               \
+		const unsigned long long now_ = __builtin_readcyclecounter();                                                  \
+		if (lane == 0 && live && g_fused_phase) { g_fused_phase[4 * v + (k)] = static_cast<unsigned int>(now_ - t_prev_); } \
+		t_prev_ = now_;                                                                                                \
+	} while (0)
+#else
+#define ALPGPU_PHASE_MARK(k)
+#endif
+
 // ---- pass 1: analysis -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_analyze(const double* __restrict__ in,
                                                                      const alpgpu_rowgroup_state* __restrict__ rgs,
@@ -296,8 +308,15 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	d.bw = d.e = d.f = d.lbw = 0;
 	d.exc_cnt = d.scheme = 0;
 	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
+#ifdef ALPGPU_FUSED_TIMING
+	unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
 	if (live) {
 		x        = load_vector(in, v, lane);
+#ifdef ALPGPU_FUSED_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		ALPGPU_PHASE_MARK(0); // input load
 		d.scheme = rgp->scheme;
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
@@ -343,21 +362,25 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	}
 	uint64_t my_p = 0, my_e = 0; // bytes
 	if (live) { desc_sizes(d, my_p, my_e); }
+	ALPGPU_PHASE_MARK(1); // encode arithmetic + staging
 	// post this vector's size; the last worker to arrive publishes the tile's aggregate (so successors never wait for
 	// this tile's own look-back), then everybody waits — on LDS words only — for the scout's exclusive prefix
 	if (lane == 0) {
 		s_size[wave] = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (arrived == kWavesPerWg - 1 && tile != 0) {
+		if (arrived == kWavesPerWg - 1) {
 			uint64_t aggregate = 0;
 #pragma unroll
 			for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
-			// a scout that already finished may have written the prefix word; never overwrite a prefix with an aggregate
-			uint64_t expected = 0;
-			__hip_atomic_compare_exchange_strong(status + tile, &expected, kFlagAggregate | aggregate, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-			                                     __HIP_MEMORY_SCOPE_AGENT);
+			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
+	// The packed words do not depend on where they will be stored: build them now, in registers, while the ordered offset is
+	// still on its way (a wavefront otherwise idles ~40 % of its life here: profiles/r01_fused_phases.txt); wavefront 0 packs
+	// first as well, its look-back then finds more of its predecessors already posted.
+	PackedUnits packed_units;
+	wave_lds_sync(); // this wavefront's staged values
+	pack_u64_units(L, d.bw, lane, packed_units);
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
 	{
 		uint32_t spins = 0;
@@ -366,6 +389,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 			__builtin_amdgcn_s_sleep(2);
 		}
 	}
+	ALPGPU_PHASE_MARK(2); // ordered offset: look-back (wave 0) / wait for it (others)
 	uint64_t local = 0;
 #pragma unroll
 	for (int w = 0; w < kWavesPerWg; ++w) { local += w < wave ? s_size[w] : 0; }
@@ -399,7 +423,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 			}
 		});
 	}
-	pack_u64_from_lds(L, d.bw, reinterpret_cast<ulonglong2*>(dst), lane);
+	store_packed_units(packed_units, d.bw, reinterpret_cast<ull2v*>(dst), lane);
 	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 32) {
 		uint32_t* out32 = reinterpret_cast<uint32_t*>(dst + 128ull * d.bw);
 		for (int k = 0; k < d.lbw; ++k) {
@@ -407,7 +431,20 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 		}
 	}
 	if (lane == 0) { descs[v] = d; }
+#ifdef ALPGPU_FUSED_TIMING
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	ALPGPU_PHASE_MARK(3); // exception record + pack + stores
 }
+
+#ifdef ALPGPU_FUSED_TIMING
+extern "C" int alpgpu_debug_fused_phases(unsigned int* d_buffer) { // device buffer of n_vectors * 4 u32, or NULL to switch off
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_fused_phase), &d_buffer, sizeof(d_buffer)) == hipSuccess ? 0 : -1;
+}
+extern "C" int alpgpu_debug_lookback_phases(unsigned int* d_buffer) { // device buffer of n_tiles * 4 u32
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_lookback_phase), &d_buffer, sizeof(d_buffer)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // publishes the running totals after a fused launch (single thread; keeps totals[0..1] stable while the launch runs)
 __global__ void k_fused_finish(uint64_t* __restrict__ totals) {
@@ -428,23 +465,33 @@ static unsigned grid_for(uint64_t n_vectors, int n_cus, int wgs_per_cu) {
 uint64_t encode_workspace_bytes(uint64_t n_vectors) {
 	const uint64_t two_pass = ((n_vectors + kScanTile - 1) / kScanTile) * 16 + 16;
 	const uint64_t per_launch = n_vectors < kFusedMaxVectors ? n_vectors : kFusedMaxVectors;
-	const uint64_t fused    = ((per_launch + kWavesPerWg - 1) / kWavesPerWg) * 8 + 64;
+	const uint64_t fused    = lookback_words((per_launch + kWavesPerWg - 1) / kWavesPerWg) * 8 + 64;
 	return two_pass > fused ? two_pass : fused;
 }
 
-int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col) {
 	// d_totals: [0] packed bytes, [1] exception bytes, [2] overflow, [3] look-back stall, [4..5] running totals of the launch in flight
-	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-	for (uint64_t first = 0; first < n_vectors; first += kFusedMaxVectors) {
-		const uint64_t n_launch = n_vectors - first < kFusedMaxVectors ? n_vectors - first : kFusedMaxVectors;
+	return hipMemsetAsync(col->d_totals, 0, 64, stream) == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// vectors [v_first, v_first + n_range): continues the streams where d_totals[0..1] say the previous range ended
+int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range) {
+	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
+		const uint64_t left     = v_first + n_range - first;
+		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kWavesPerWg - 1) / kWavesPerWg;
-		if (hipMemsetAsync(d_workspace, 0, n_tiles * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
 		                   n_launch, col->d_rd_order);
 		hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, stream, col->d_totals);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+	if (launch_encode_reset_totals(stream, col) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
+	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors);
 }
 
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,

@@ -23,9 +23,159 @@ __device__ __forceinline__ uint64_t status_pack(uint64_t flag, uint64_t packed_u
 	return flag | (packed_units << 31) | exc_units;
 }
 
+// ---- two-level form (default) -------------------------------------------------------------------------------------------
+// Measured on MI355X (tools/fused_phases.py, profiles/r01_fused_phases.txt): with the flat look-back below a wavefront spends
+// ~37 % of its life waiting for its offset, and wider windows or faster polling make it worse — agent-scope loads of status
+// words are served on the far side of the fabric (the XCDs' L2s are not coherent with each other), so the polling traffic
+// itself (64 words x ~5 rounds per tile) is the cost.  Here tiles form blocks of kBlockTiles consecutive tiles:
+//   level 1  status[tile]   = AGGREGATE | size of the tile, written once by the tile's last-arriving wavefront;
+//            a tile reads its <= 63 predecessors INSIDE its block in one round (they were dispatched just before it);
+//   level 2  bstatus[block] = AGGREGATE | size of the block, written by the tile that closes the block as soon as it knows
+//            it, later replaced by PREFIX | inclusive prefix of the block; a tile finds its block's base with a decoupled
+//            look-back over the (few, 64x sparser) block words.
+// Exclusive prefix of a tile = base of its block + sizes of its predecessors in the block.  ~2 rounds and ~130 status loads
+// per tile instead of ~5 and ~320, and no positive feedback between look-back latency and look-back distance.
+constexpr int kBlockTiles = 64;
+#ifdef ALPGPU_FUSED_TIMING
+__device__ unsigned int* g_lookback_phase; // [n_tiles][4]: level-1 ticks, level-1 retries, level-2 ticks, level-2 retries
+#define ALPGPU_LB_NOTE(k, val)                                                                                          \
+	do {                                                                                                                \
+		if (lane == 0 && g_lookback_phase) { g_lookback_phase[4 * tile + (k)] = static_cast<unsigned int>(val); }        \
+	} while (0)
+#else
+#define ALPGPU_LB_NOTE(k, val)
+#endif
+
+__device__ __forceinline__ uint64_t status_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void     status_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+	for (int dd = 32; dd >= 1; dd >>= 1) { v += static_cast<uint64_t>(__shfl_xor(static_cast<long long>(v), dd)); }
+	return v;
+}
+
+// status: [gridDim.x] tile words followed by [ceil(gridDim.x / kBlockTiles)] block words, all zero at launch.
+__device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
+                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
+	uint64_t*      bstatus = status + gridDim.x;
+	const uint64_t block   = tile / kBlockTiles;
+	const int      i       = static_cast<int>(tile % kBlockTiles);
+	const bool     closes  = i == kBlockTiles - 1 || tile == gridDim.x - 1; // this tile completes its block
+	bool           stalled = false;
+	uint32_t       spins   = 0;
+	auto give_up = [&]() { return ++spins > kSpinLimit || status_load(totals + 3) != 0; };
+
+	// level 1: the sizes of the i predecessors inside this block
+	uint64_t local = 0;
+#ifdef ALPGPU_FUSED_TIMING
+	const unsigned long long lb_t0 = __builtin_readcyclecounter();
+	unsigned                 lb_r1 = 0, lb_r2 = 0;
+#endif
+	if (i != 0) {
+		for (;;) {
+#ifdef ALPGPU_FUSED_TIMING
+			++lb_r1;
+#endif
+			const uint64_t st = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
+			if (__ballot((st >> 62) == 0) == 0) {
+				local = wave_sum_u64(st & ~(3ull << 62));
+				break;
+			}
+			if (give_up()) {
+				stalled = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
+		}
+	}
+#ifdef ALPGPU_FUSED_TIMING
+	const unsigned long long lb_t1 = __builtin_readcyclecounter();
+	ALPGPU_LB_NOTE(0, lb_t1 - lb_t0);
+	ALPGPU_LB_NOTE(1, lb_r1);
+#endif
+	// a closing tile needs its own size as well (LDS only): it publishes the block's aggregate before looking further back
+	uint64_t aggregate = 0;
+	if (closes && !stalled) {
+		uint32_t lspins = 0;
+		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kWavesPerWg) {
+			if (++lspins > kSpinLimit) {
+				stalled = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+#pragma unroll
+		for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+		if (!stalled && lane == 0) { status_store(bstatus + block, (block == 0 ? kFlagPrefix : kFlagAggregate) | (local + aggregate)); }
+	}
+	// level 2: the base of this block = everything before it
+	uint64_t base = 0;
+	if (block != 0 && !stalled) {
+		int64_t look = static_cast<int64_t>(block) - 1; // nearest block not yet accounted for
+		while (look >= 0) {
+#ifdef ALPGPU_FUSED_TIMING
+			++lb_r2;
+#endif
+			const int64_t  idx        = look - lane;
+			const uint64_t st         = idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix;
+			const uint64_t fl         = st >> 62;
+			const uint64_t has_prefix = __ballot(fl == 2);
+			const uint64_t invalid    = __ballot(fl == 0);
+			const int      first_p    = has_prefix ? __builtin_ctzll(has_prefix) : 64;
+			const uint64_t upto       = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull); // lanes 0..first_p
+			if (invalid & upto) { // a nearer block has not published yet
+				if (give_up()) {
+					stalled = true;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
+				continue;
+			}
+			base += wave_sum_u64((first_p == 64 || lane <= first_p) ? (st & ~(3ull << 62)) : 0ull);
+			if (first_p != 64) { break; }
+			look -= 64;
+		}
+	}
+#ifdef ALPGPU_FUSED_TIMING
+	ALPGPU_LB_NOTE(2, __builtin_readcyclecounter() - lb_t1);
+	ALPGPU_LB_NOTE(3, lb_r2);
+#endif
+	// the other wavefronts add up the sizes posted before theirs once released: every one of them must have posted (LDS only)
+	if (!closes && !stalled) {
+		uint32_t lspins = 0;
+		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kWavesPerWg) {
+			if (++lspins > kSpinLimit) {
+				stalled = true;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+	}
+	if (lane == 0) {
+		if (stalled) {
+			status_store(totals + 3, 1ull);
+			*s_excl = ~0ull;
+		} else {
+			const uint64_t excl = base + local;
+			if (closes && block != 0) { status_store(bstatus + block, kFlagPrefix | (excl + aggregate)); }
+			*s_excl = excl;
+			if (tile == gridDim.x - 1) { // running totals of the column, published by the finish kernel
+				const uint64_t incl = excl + aggregate;
+				totals[4]           = totals[0] + ((incl >> 31) & 0x7FFFFFFFull) * 128ull;
+				totals[5]           = totals[1] + (incl & 0x7FFFFFFFull) * 8ull;
+			}
+		}
+		__hip_atomic_store(s_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+
+// words of status workspace one launch over n_tiles tiles needs (tile words + block words)
+__host__ __device__ inline uint64_t lookback_words(uint64_t n_tiles) { return n_tiles + (n_tiles + kBlockTiles - 1) / kBlockTiles; }
+
+// ---- flat form (kept for A/B runs: -DALPGPU_FLAT_LOOKBACK) ----------------------------------------------------------------
 // The look-back of one tile (run by wavefront 0 after it has posted its own size): finds the tile's exclusive prefix,
 // waits for the tile's aggregate, publishes the inclusive prefix and releases the workgroup through LDS.
-__device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
+__device__ __forceinline__ void tile_lookback_flat(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
                                               uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
 		uint64_t* my_status = status + tile;
 		uint64_t  excl      = 0;

@@ -146,7 +146,7 @@ __device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, const uint64_t* 
 template <class P, bool FROM_SAMPLES>
 __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
                                                                 alpgpu_rowgroup_state* __restrict__ rgs, int force_rd,
-                                                                uint16_t* __restrict__ rd_order) {
+                                                                uint16_t* __restrict__ rd_order, uint64_t rg_first) {
 	__shared__ typename P::value_t smp[kMaxSampledVectors * 32];
 	__shared__ uint32_t best_key[kMaxSampledVectors];
 	__shared__ uint64_t      s_key[kMaxSamples]; // samples sorted by bit pattern (ALP_RD)
@@ -161,14 +161,14 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	const int      lane    = lane_id();
 	const int      wave    = wave_in_wg();
 	const int      tid     = static_cast<int>(threadIdx.x);
-	const uint64_t rg      = blockIdx.x;
+	const uint64_t rg      = rg_first + blockIdx.x;
 	int n_sv, n_smp, samples_size;
 	if constexpr (FROM_SAMPLES) {
 		// encoder.hpp:140-143: ceil(n / 32) sampled "vectors" of min(n, 32) samples each
 		n_smp        = static_cast<int>(n_vectors);
 		n_sv         = (n_smp + 31) / 32;
 		samples_size = n_smp < 32 ? n_smp : 32;
-		if (wave < n_sv && lane < 32) { smp[wave * 32 + lane] = in[288ull * rg + wave * samples_size + (lane < samples_size ? lane : 0)]; }
+		if (wave < n_sv && lane < 32) { smp[wave * 32 + lane] = in[288ull * blockIdx.x + wave * samples_size + (lane < samples_size ? lane : 0)]; }
 	} else {
 		const uint64_t v_first = rg * kRowgroup;
 		const int      nv      = static_cast<int>((n_vectors - v_first) < kRowgroup ? (n_vectors - v_first) : kRowgroup);
@@ -391,32 +391,37 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	}
 }
 
-int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order) {
-	if (n_vectors == 0) { return ALPGPU_OK; }
+// rowgroups [rg_first, rg_first + rg_count) of a column of n_vectors vectors; rg_count = 0 means "to the end"
+int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
+                         uint64_t rg_count) {
 	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
-	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
-	                   d_rd_order);
+	if (rg_first >= n_rg) { return ALPGPU_OK; }
+	if (rg_count == 0 || rg_first + rg_count > n_rg) { rg_count = n_rg - rg_first; }
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false>), dim3(static_cast<unsigned>(rg_count)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
+	                   d_rd_order, rg_first);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, true>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
-	                   force_rd, static_cast<uint16_t*>(nullptr));
+	                   force_rd, static_cast<uint16_t*>(nullptr), 0ull);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 // single precision: alp::encoder<float>::init / alp::rd_encoder<float>::init
-int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order) {
-	if (n_vectors == 0) { return ALPGPU_OK; }
+int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
+                             uint64_t rg_first, uint64_t rg_count) {
 	const uint64_t n_rg = (n_vectors + kRowgroup - 1) / kRowgroup;
-	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false>), dim3(static_cast<unsigned>(n_rg)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
-	                   d_rd_order);
+	if (rg_first >= n_rg) { return ALPGPU_OK; }
+	if (rg_count == 0 || rg_first + rg_count > n_rg) { rg_count = n_rg - rg_first; }
+	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false>), dim3(static_cast<unsigned>(rg_count)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
+	                   d_rd_order, rg_first);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, true>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples), d_state,
-	                   force_rd, static_cast<uint16_t*>(nullptr));
+	                   force_rd, static_cast<uint16_t*>(nullptr), 0ull);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

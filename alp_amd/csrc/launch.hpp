@@ -12,13 +12,17 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int variant);
 
 // init_kernels.hip
-int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order);
+int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first = 0,
+                         uint64_t rg_count = 0);
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
 
 // encode_kernels.hip
 uint64_t encode_workspace_bytes(uint64_t n_vectors);
 int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace);
+// pieces of the above for a caller that interleaves other work: zero d_totals, then vector ranges in ascending order
+int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col);
+int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range);
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus);
 
@@ -56,9 +60,11 @@ int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t*
 
 // ---- single precision (decode_f32_kernels.hip, encode_f32_kernels.hip, init_kernels.hip, primitive_f32_kernels.hip) ----
 int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores);
-int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order);
+int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
+                             uint64_t rg_first = 0, uint64_t rg_count = 0);
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
 int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace);
+int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range);
 int launch_pad_tail_f32(hipStream_t stream, float* d_in, uint64_t n_values);
 int launch_ffor_i32(hipStream_t stream, int n_cus, const int32_t* in, int32_t* packed, size_t stride, const uint8_t* bw, const int32_t* base, uint64_t n);
 int launch_unffor_i32(hipStream_t stream, int n_cus, const int32_t* packed, size_t stride, int32_t* out, const uint8_t* bw, const int32_t* base, uint64_t n);

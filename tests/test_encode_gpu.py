@@ -187,3 +187,59 @@ def test_long_column_spans_several_fused_launches_worth_of_tiles(ctx, oracle):
     w_rg, w_vec, w_packed, w_exc = layout.compact(want)
     assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
     assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc)
+
+
+def _streams(dcol):
+    rg, vec, packed, exc = dcol.to_host()
+    return [rg.view(np.uint8), vec.view(np.uint8), packed, exc]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_large_column_every_encode_route_gives_the_same_bytes(ctx, dtype):
+    """300k vectors (75k tiles, > 1000 look-back blocks): alpgpu_encode_*, rowgroup init + vector encode called separately and
+    (double) the two-pass encode must produce byte-identical columns, twice in a row, and decode back to the input bits.
+    Guards the ordered-offset protocol against races that small columns do not expose (one such race was found this way)."""
+    from alp_amd import capi
+    n = 300_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    if dtype == "f64":
+        x = torch.round((torch.rand(n * 1024, dtype=torch.float64, device="cuda", generator=g) - 0.5) * 2e7) / 100.0
+        m = torch.rand(n * 1024, device="cuda", generator=g) < 0.01
+        x[m] = x[m] * 3.141592653589793
+        it = torch.int64
+    else:
+        x = (torch.round(torch.rand(n * 1024, dtype=torch.float64, device="cuda", generator=g) * 1e5) / 100).to(torch.float32)
+        it = torch.int32
+    # ALP_RD rowgroups in the middle
+    x[120_000 * 1024: 150_000 * 1024] = torch.rand(30_000 * 1024, dtype=x.dtype, device="cuda", generator=g)
+
+    def encode_all():
+        col = capi.DeviceColumn(n, dtype=dtype)
+        ctx.encode(x, col)
+        ctx.synchronize()
+        assert ctx.column_totals(col)[2] == 0
+        return col
+
+    ref = encode_all()
+    want = _streams(ref)
+    out = ctx.decode(ref)
+    ctx.synchronize()
+    assert torch.equal(out.view(it), x.view(it))
+    del out
+    for a, b in zip(_streams(encode_all()), want):  # run to run
+        assert np.array_equal(a, b)
+    plain = capi.DeviceColumn(n, dtype=dtype)  # the two halves called separately
+    ctx.rowgroup_init(x, plain)
+    ctx.encode_vectors(x, plain)
+    ctx.synchronize()
+    for a, b in zip(_streams(plain), want):
+        assert np.array_equal(a, b)
+    if dtype == "f64":
+        try:
+            ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 1)
+            two = encode_all()
+        finally:
+            ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
+        for a, b in zip(_streams(two), want):
+            assert np.array_equal(a, b)
