@@ -22,6 +22,9 @@ struct VecInF {
 	f32x4 x[4];
 };
 
+// a wave-uniform lane mask (ballot) as this lane's predicate
+__device__ __forceinline__ bool lane_in_f32(uint64_t ballot) { return __builtin_amdgcn_inverse_ballot_w64(ballot); }
+
 __device__ __forceinline__ uint64_t lanemask_lt64(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 
 __device__ __forceinline__ VecInF load_vector_f32(const float* __restrict__ in, uint64_t v, int lane) {
@@ -97,8 +100,7 @@ __device__ __forceinline__ void second_level_select_f32(const VecInF& in, const 
 // ---- encode_simdized + analyze_ffor for one vector held in registers --------------------------------------------------
 struct AlpEncodedF {
 	int32_t  enc[4][4];
-	uint64_t ballot[4][4];
-	uint32_t flags; // bit 4m + j
+	uint64_t ballot[4][4]; // exception slots of every (m, j) step as wave-uniform lane masks
 	int      cnt;
 	int32_t  base;
 	int      bw;
@@ -109,7 +111,6 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 	const float    frac_f = kFracArrF[f];
 	const uint32_t fact   = kFactArrF[f];
 	const float    frac_e = kFracArrF[e];
-	R.flags = 0;
 	R.cnt   = 0;
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
@@ -125,7 +126,6 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 			const bool    exc     = dec != vv;
 			R.enc[m][j]           = enc;
 			R.ballot[m][j]        = __ballot(exc);
-			R.flags |= exc ? (1u << (4 * m + j)) : 0u;
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
 		}
 	}
@@ -162,7 +162,7 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 	for (int m = 0; m < 4; ++m) {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			if (R.flags & (1u << (4 * m + j))) { R.enc[m][j] = filler; }
+			R.enc[m][j] = lane_in_f32(R.ballot[m][j]) ? filler : R.enc[m][j];
 			mn = R.enc[m][j] < mn ? R.enc[m][j] : mn;
 			mx = R.enc[m][j] > mx ? R.enc[m][j] : mx;
 		}
@@ -178,18 +178,72 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 	R.bw   = count_bits32(mx, mn);
 }
 
-// rank of this lane's (m, j) exception among the vector's exceptions in ascending position order
-__device__ __forceinline__ int exception_rank_f32(const uint64_t (&ballot)[4][4], uint32_t flags, int m, int j, int lane, int step_offset) {
-	const uint64_t lt = lanemask_lt64(lane);
-	int            r  = step_offset;
+// Calls emit(rank, m, j) on every lane whose (m, j) slot is set in `ballot`; rank = number of set slots at smaller positions
+// (position = 256*m + 4*lane + j).  Steps without exceptions are skipped wave-uniformly; m and j are compile-time at the call.
+template <class F>
+__device__ __forceinline__ void for_each_exception_f32(const uint64_t (&ballot)[4][4], int lane, F&& emit) {
+	const uint64_t lt   = lanemask_lt64(lane);
+	int            soff = 0;
 #pragma unroll
-	for (int jj = 0; jj < 4; ++jj) { r += __builtin_popcountll(ballot[m][jj] & lt); }
-	r += __builtin_popcount((flags >> (4 * m)) & ((1u << j) - 1u));
-	return r;
+	for (int m = 0; m < 4; ++m) {
+		const uint64_t any = ballot[m][0] | ballot[m][1] | ballot[m][2] | ballot[m][3];
+		if (any != 0) {
+			int rank = soff;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { rank += __builtin_popcountll(ballot[m][j] & lt); }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (lane_in_f32(ballot[m][j])) {
+					emit(rank, m, j);
+					++rank;
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { soff += __builtin_popcountll(ballot[m][j]); }
+		}
+	}
 }
 
 // ---- FFOR u32 pack from LDS: vals[i] = value - base (< 2^bw), natural order.  Output unit u = 8*k + a is the 16-byte group
 // of stream word k for lane32 columns 4a..4a+3; lane handles units lane, lane + 64, ... -> 1-KiB contiguous stores.
+// The same packing kept in registers (unit lane + 64*t in acc[t], t < ceil(8*bw / 64) <= 4): the single-pass encode packs
+// before it waits for its output offset and only stores afterwards.
+struct PackedUnitsF32 {
+	u32x4 acc[4];
+};
+__device__ __forceinline__ void pack_u32_units(const EncodeLdsF32& L, int bw, int lane, PackedUnitsF32& P) {
+	const u32x4* vals4   = reinterpret_cast<const u32x4*>(L.vals);
+	const int    n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		u32x4     acc = {0u, 0u, 0u, 0u};
+		const int u   = lane + 64 * t;
+		if (64 * t < n_units && u < n_units) {
+			const int k    = u >> 3;
+			const int a    = u & 7;
+			const int bit0 = 32 * k;
+			int       r    = bit0 / bw;
+			int       p    = r * bw;
+			while (p < bit0 + 32 && r < 32) {
+				const u32x4 v  = vals4[8 * r + a];
+				const int   sh = p - bit0;
+				acc |= sh >= 0 ? (v << static_cast<uint32_t>(sh)) : (v >> static_cast<uint32_t>(-sh));
+				p += bw;
+				++r;
+			}
+		}
+		P.acc[t] = acc;
+	}
+}
+__device__ __forceinline__ void store_packed_units_f32(const PackedUnitsF32& P, int bw, u32x4* __restrict__ out, int lane) {
+	const int n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const int u = lane + 64 * t;
+		if (64 * t < n_units && u < n_units) { out[u] = P.acc[t]; }
+	}
+}
+
 __device__ __forceinline__ void pack_u32_from_lds(const EncodeLdsF32& L, int bw, u32x4* __restrict__ out, int lane) {
 	const u32x4* vals4   = reinterpret_cast<const u32x4*>(L.vals);
 	const int    n_units = 8 * bw;

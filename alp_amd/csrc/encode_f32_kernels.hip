@@ -53,7 +53,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	const uint64_t v    = v_first + vl;
 	VecInF             x;
 	alpgpu_vector_desc d;
-	uint32_t           flags = 0;
 	uint64_t           lacc[4] = {0, 0, 0, 0}; // ALP_RD: packed left streams of this lane's four lane64 columns
 	uint64_t           ballots[4][4];
 	int                cnt = 0;
@@ -77,8 +76,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 			AlpEncodedF R;
 			encode_alp_registers_f32(x, e, f, lane, R);
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
-			cnt   = R.cnt;
-			flags = R.flags;
+			cnt = R.cnt;
 			const uint32_t base = static_cast<uint32_t>(R.base);
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
@@ -120,7 +118,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 						const int ridx = rd_exception_index(order, left);
 						idx            = exc ? ridx : idx;
 					}
-					flags |= exc ? (1u << (4 * m + j)) : 0u;
 					cnt += __builtin_popcountll(ballots[m][j]);
 					lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
 				}
@@ -146,6 +143,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
+	// pack into registers while the ordered offset is on its way (see k_encode_fused)
+	PackedUnitsF32 packed_units;
+	wave_lds_sync();
+	pack_u32_units(L, d.bw, lane, packed_units);
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
 	{
 		uint32_t spins = 0;
@@ -172,31 +173,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
 	if (cnt > 0) {
-		const bool alp  = d.scheme == ALPGPU_SCHEME_ALP;
-		const int  rbw  = d.bw;
-		int        soff = 0;
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				if (flags & (1u << (4 * m + j))) {
-					const int      r    = exception_rank_f32(ballots, flags, m, j, lane, soff);
-					const uint32_t bits = __float_as_uint(x.x[m][j]);
-					const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
-					if (alp) {
-						reinterpret_cast<uint32_t*>(rec)[r]              = bits;
-						reinterpret_cast<uint16_t*>(rec + 4ull * cnt)[r] = pos;
-					} else {
-						reinterpret_cast<uint16_t*>(rec)[r]              = static_cast<uint16_t>(bits >> rbw);
-						reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
-					}
-				}
+		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
+		const int  rbw = d.bw;
+		for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
+			const uint32_t bits = __float_as_uint(x.x[m][j]);
+			const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
+			if (alp) {
+				reinterpret_cast<uint32_t*>(rec)[r]              = bits;
+				reinterpret_cast<uint16_t*>(rec + 4ull * cnt)[r] = pos;
+			} else {
+				reinterpret_cast<uint16_t*>(rec)[r]              = static_cast<uint16_t>(bits >> rbw);
+				reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
 			}
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { soff += __builtin_popcountll(ballots[m][j]); }
-		}
+		});
 	}
-	pack_u32_from_lds(L, d.bw, reinterpret_cast<u32x4*>(dst), lane);
+	store_packed_units_f32(packed_units, d.bw, reinterpret_cast<u32x4*>(dst), lane);
 	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 16) {
 		uint64_t* out64 = reinterpret_cast<uint64_t*>(dst + 128ull * d.bw);
 		for (int k = 0; k < d.lbw; ++k) { // word k of lane64 columns 4*lane .. 4*lane+3

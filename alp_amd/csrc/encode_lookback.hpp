@@ -32,7 +32,8 @@ __device__ __forceinline__ uint64_t status_pack(uint64_t flag, uint64_t packed_u
 //            a tile reads its <= 63 predecessors INSIDE its block in one round (they were dispatched just before it);
 //   level 2  bstatus[block] = AGGREGATE | size of the block, written by the tile that closes the block as soon as it knows
 //            it, later replaced by PREFIX | inclusive prefix of the block; a tile finds its block's base with a decoupled
-//            look-back over the (few, 64x sparser) block words.
+//            look-back over the (few, 64x sparser) block words, reading the tile words of a block directly while that block's
+//            word is still missing (so nobody waits for another tile's look-back, only for tiles to finish encoding).
 // Exclusive prefix of a tile = base of its block + sizes of its predecessors in the block.  ~2 rounds and ~130 status loads
 // per tile instead of ~5 and ~320, and no positive feedback between look-back latency and look-back distance.
 constexpr int kBlockTiles = 64;
@@ -71,12 +72,17 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	const unsigned long long lb_t0 = __builtin_readcyclecounter();
 	unsigned                 lb_r1 = 0, lb_r2 = 0;
 #endif
+	// both levels' first rounds are issued together: one trip across the fabric instead of two when nothing is late
+	uint64_t first1 = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
+	uint64_t first2 = (block != 0 && static_cast<int64_t>(block) - 1 - lane >= 0) ? status_load(bstatus + (block - 1 - lane)) : kFlagPrefix;
+	bool     fresh1 = true, fresh2 = true;
 	if (i != 0) {
 		for (;;) {
 #ifdef ALPGPU_FUSED_TIMING
 			++lb_r1;
 #endif
-			const uint64_t st = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
+			const uint64_t st = fresh1 ? first1 : (lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate);
+			fresh1            = false;
 			if (__ballot((st >> 62) == 0) == 0) {
 				local = wave_sum_u64(st & ~(3ull << 62));
 				break;
@@ -117,21 +123,34 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 			++lb_r2;
 #endif
 			const int64_t  idx        = look - lane;
-			const uint64_t st         = idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix;
+			const uint64_t st         = fresh2 ? first2 : (idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix);
+			fresh2                    = false;
 			const uint64_t fl         = st >> 62;
 			const uint64_t has_prefix = __ballot(fl == 2);
 			const uint64_t invalid    = __ballot(fl == 0);
 			const int      first_p    = has_prefix ? __builtin_ctzll(has_prefix) : 64;
 			const uint64_t upto       = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull); // lanes 0..first_p
-			if (invalid & upto) { // a nearer block has not published yet
-				if (give_up()) {
-					stalled = true;
-					break;
+			uint64_t late = 0; // sizes of nearer blocks whose word is not there yet, summed from their 64 tile words
+			if (invalid & upto) {
+				// The closing tile of such a block is still waiting for the block's slowest tile or has not run its look-back yet;
+				// the tile words themselves appear as soon as each tile has encoded, so read those instead of waiting a round.
+				bool ready = true;
+				for (uint64_t inv = invalid & upto; inv != 0 && ready; inv &= inv - 1) { // wave-uniform
+					const uint64_t blk = static_cast<uint64_t>(look - __builtin_ctzll(inv));
+					const uint64_t w   = status_load(status + blk * kBlockTiles + lane);
+					ready              = __ballot((w >> 62) == 0) == 0;
+					late += wave_sum_u64(w & ~(3ull << 62));
 				}
-				__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
-				continue;
+				if (!ready) {
+					if (give_up()) {
+						stalled = true;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
+					continue;
+				}
 			}
-			base += wave_sum_u64((first_p == 64 || lane <= first_p) ? (st & ~(3ull << 62)) : 0ull);
+			base += late + wave_sum_u64(((first_p == 64 || lane <= first_p) && fl != 0) ? (st & ~(3ull << 62)) : 0ull);
 			if (first_p != 64) { break; }
 			look -= 64;
 		}

@@ -170,24 +170,18 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_values_f32(const fl
 		}
 		AlpEncodedF R;
 		encode_alp_registers_f32(x, e, f, lane, R);
-		u32x4* dst  = reinterpret_cast<u32x4*>(enc + v * kVec);
-		int    soff = 0;
+		u32x4* dst = reinterpret_cast<u32x4*>(enc + v * kVec);
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
 			u32x4 o;
 #pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				o[j] = static_cast<uint32_t>(R.enc[m][j]);
-				if (R.flags & (1u << (4 * m + j))) {
-					const int r             = exception_rank_f32(R.ballot, R.flags, m, j, lane, soff);
-					exc[v * exc_stride + r] = x.x[m][j];
-					pos[v * exc_stride + r] = static_cast<uint16_t>(256 * m + 4 * lane + j);
-				}
-			}
+			for (int j = 0; j < 4; ++j) { o[j] = static_cast<uint32_t>(R.enc[m][j]); }
 			dst[64 * m + lane] = o;
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { soff += __builtin_popcountll(R.ballot[m][j]); }
 		}
+		for_each_exception_f32(R.ballot, lane, [&](int r, int m, int j) {
+			exc[v * exc_stride + r] = x.x[m][j];
+			pos[v * exc_stride + r] = static_cast<uint16_t>(256 * m + 4 * lane + j);
+		});
 		if (lane == 0) { cnts[v] = static_cast<uint16_t>(R.cnt); }
 	}
 }
