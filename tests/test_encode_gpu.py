@@ -243,3 +243,29 @@ def test_large_column_every_encode_route_gives_the_same_bytes(ctx, dtype):
             ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
         for a, b in zip(_streams(two), want):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_column_longer_than_one_fused_launch(ctx, dtype):
+    """more than 2^20 vectors: the single-pass encode chains several launches through d_totals; offsets must continue across
+    the seam, the round trip must be exact and the descriptors' extents must tile the streams without gaps"""
+    from alp_amd import capi
+    n = (1 << 20) + 4100
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    x = (torch.round(torch.rand(n * 1024, dtype=torch.float64, device="cuda", generator=g) * 1e5) / 100)
+    x = x.to(torch.float32) if dtype == "f32" else x
+    col = capi.DeviceColumn(n, dtype=dtype)
+    ctx.encode(x, col)
+    ctx.synchronize()
+    pb, eb, ov = ctx.column_totals(col)
+    assert ov == 0
+    out = ctx.decode(col)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int32 if dtype == "f32" else torch.int64), x.view(torch.int32 if dtype == "f32" else torch.int64))
+    vec = col.vectors.cpu().numpy().view(capi.VECTOR_DTYPE)[:n]
+    W = 4 if dtype == "f32" else 8
+    psz, esz = layout.record_sizes(vec["scheme"], vec["bw"], vec["lbw"], vec["exc_cnt"], W)
+    assert np.array_equal(vec["packed_off"], np.concatenate([[0], np.cumsum(psz)[:-1]]).astype(np.uint64))
+    assert np.array_equal(vec["exc_off"], np.concatenate([[0], np.cumsum(esz)[:-1]]).astype(np.uint64))
+    assert int(psz.sum()) == pb and int(esz.sum()) == eb
