@@ -318,7 +318,7 @@ def main():
         del sums
         # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
         for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
-            ne = min(n, 1 << 18)
+            ne = n  # BASELINE.json configs[2] / [3]: 1 Mi vectors
             x = synthetic_input(kind, ne, dev, seed=42)
             ecol = capi.DeviceColumn(ne, local_rank)
             med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
