@@ -25,11 +25,6 @@ struct VecIn {
 	double2 x[8];
 };
 
-struct AlpVectorResult {
-	int      e, f, bw, cnt;
-	int64_t  base;
-};
-
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 
 __device__ __forceinline__ int64_t wave_min_i64(int64_t v) {

@@ -7,14 +7,17 @@
 //   alp::rd_encoder<double>::encode       include/alp/rd.hpp:109-147
 // and the caller's per-column loop (publication/source_code/bench_compression_ratio/alp.cpp:198-229).
 //
-// Variable-size output needs each vector's byte offsets.  Round-1 structure:
-//   k_encode_analyze : one wave per vector; picks (e,f), counts exceptions, finds base/bw -> descriptor sizes
-//   k_scan_tiles     : exclusive scan of the sizes inside tiles of 1024 vectors, tile totals to a workspace
-//   k_scan_totals    : one workgroup scans the tile totals, writes the stream totals / overflow flag
-//   k_encode_pack    : one wave per vector; re-encodes with the chosen (e,f) and writes packed words,
-//                      exception record and the final descriptor at the now-known offsets
-// Offsets are therefore in vector order and the output is byte-reproducible.  The input is read twice
-// (analysis + pack); fusing the two passes with a decoupled look-back scan is the planned next step.
+// Variable-size output needs each vector's byte offsets.  Two forms, byte-identical output:
+//   default  k_encode_fused (+ k_fused_finish): one pass; offsets from the in-kernel two-level look-back of
+//            encode_lookback.hpp (description above the kernel)
+//   fallback (ALPGPU_OPT_ENCODE_TWO_PASS):
+//     k_encode_analyze : one wave per vector; picks (e,f), counts exceptions, finds base/bw -> descriptor sizes
+//     k_scan_tiles     : exclusive scan of the sizes inside tiles of 1024 vectors, tile totals to a workspace
+//     k_scan_totals    : one workgroup scans the tile totals, writes the stream totals / overflow flag
+//     k_encode_pack    : one wave per vector; re-encodes with the chosen (e,f) and writes packed words,
+//                        exception record and the final descriptor at the now-known offsets
+//     (no communication between workgroups; reads the input twice and repeats the arithmetic)
+// Offsets are the exclusive scan of the record sizes in vector order, so the output is byte-reproducible.
 #include "encode_device.hpp"
 #include "encode_lookback.hpp"
 #include "launch.hpp"
@@ -25,7 +28,7 @@ namespace alpgpu {
 
 constexpr int kScanTile = 1024;
 
-#ifdef ALPGPU_FUSED_TIMING // experiment builds only: where a wavefront of k_encode_fused spends its life (sums of s_memtime deltas)
+#ifdef ALPGPU_FUSED_TIMING // experiment builds only (tools/fused_phases.py): where a wavefront of k_encode_fused spends its life
 __device__ unsigned int* g_fused_phase; // [n_vectors][4] deltas, written by lane 0 of the vector's wavefront
 #define ALPGPU_PHASE_MARK(k)                                                                                           \
 	do {                                                                                                               \
@@ -256,21 +259,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 }
 
 // ---- single pass: analysis, ordered offsets (decoupled look-back) and pack in ONE kernel -------------------------------
-// The two-pass form above reads the input twice and does the encode arithmetic twice (the kernels are VALU-bound:
-// profiles/r01_pmc_sq_encode.txt).  Here a workgroup (tile) of kWavesPerWg wavefronts = kWavesPerWg consecutive vectors
+// The two-pass form above reads the input twice and does the encode arithmetic twice.  Here a workgroup (tile) of kWavesPerWg
+// wavefronts = kWavesPerWg consecutive vectors
 //   1. encodes its vectors (registers -> LDS), knows their sizes,
 //   2. publishes the tile's size as ONE 64-bit status word {flag | packed 128-B units | exception 8-B units},
-//   3. wavefront 0 looks back over the preceding tiles' status words (kLookWindow per round) until it meets a tile that
-//      already knows its inclusive prefix, adds up the aggregates in between, publishes its own inclusive prefix and
-//      hands the tile's exclusive prefix to the other wavefronts through LDS words (no workgroup barrier is involved),
-//   4. every wavefront writes its packed words / exception record / descriptor at the now-known offsets.
+//   3. packs every vector into registers (the packed words do not depend on where they go),
+//   4. wavefront 0 finds the tile's exclusive prefix with the two-level look-back of encode_lookback.hpp and hands it to the
+//      other wavefronts through LDS words (no workgroup barrier is involved),
+//   5. every wavefront stores its packed words / exception record / descriptor at the now-known offsets.
 // Offsets are therefore the same vector-order exclusive scan as in the two-pass form: the output is byte-identical.
 // Status words are written with one agent-scope relaxed atomic store (the data IS the flag) and polled with agent-scope
 // relaxed atomic loads (cdna_hip_programming.md §6 G16, recipe R2).  Forward progress needs the predecessor tiles to be
 // resident or finished, which the in-order dispatch of a 1-D grid provides in practice but HIP does not promise:
 // every spin is bounded, and a stall sets totals[3] (reported as ALPGPU_ERR_HIP by alpgpu_column_totals; the two-pass
 // form is selectable with ALPGPU_OPT_ENCODE_TWO_PASS).  The field widths bound one launch to kFusedMaxVectors vectors;
-// longer columns are chained launch by launch through totals[0..1].
+// longer columns are chained launch by launch through totals[0..1].  Where a wavefront's time goes: profiles/r01_fused_phases.txt.
 __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double* __restrict__ in,
                                                                    const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                    alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
