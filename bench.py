@@ -206,7 +206,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ALPGPU_BENCH_FORCE_DIST"):  # (the env var lets a 1-GPU box exercise the N > 1 code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
