@@ -281,7 +281,7 @@ int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_s
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	if (alpgpu::launch_decode_sum(ctx->stream, col, d_sums, decode_variant_for(ctx, col)) != ALPGPU_OK) {
+	if (alpgpu::launch_decode_sum(ctx->stream, col, d_sums, ctx->decode_vpw ? ctx->decode_vpw : 2) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;

@@ -350,9 +350,11 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int variant) {
+// vectors_per_wg in {1, 2}.  There is no output stream to compete with, so two vectors in flight per workgroup is the default
+// (measured on the benchmark column: 1.39 / 1.16 / 1.43 ms for 1 / 2 / 4 vectors per workgroup).
+int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg) {
 	const uint64_t n        = col->n_vectors;
-	const int      V        = (variant & 1) ? 1 : 2;
+	const int      V        = vectors_per_wg == 1 ? 1 : 2;
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30;
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
