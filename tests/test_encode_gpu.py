@@ -269,3 +269,16 @@ def test_column_longer_than_one_fused_launch(ctx, dtype):
     assert np.array_equal(vec["packed_off"], np.concatenate([[0], np.cumsum(psz)[:-1]]).astype(np.uint64))
     assert np.array_equal(vec["exc_off"], np.concatenate([[0], np.cumsum(esz)[:-1]]).astype(np.uint64))
     assert int(psz.sum()) == pb and int(esz.sum()) == eb
+
+
+@pytest.mark.parametrize("n_vectors", [4, 5, 252, 255, 256, 257, 260, 511, 512, 513, 16383, 16384, 16385, 16388])
+def test_look_back_block_boundaries(ctx, oracle, n_vectors):
+    """column lengths around the look-back's block (64 tiles = 256 vectors) and tile (4 vectors) boundaries: offsets and
+    whole streams against the oracle"""
+    col_np = datagen.mixed_column(n_vectors, seed=1000 + n_vectors, exc_rate=0.02)
+    want = oracle.encode_column(col_np)
+    dcol, x = gpu_encode(ctx, col_np)
+    rg, vec, packed, exc = dcol.to_host()
+    w_rg, w_vec, w_packed, w_exc = layout.compact(want)
+    assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
+    assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc)
