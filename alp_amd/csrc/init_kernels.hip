@@ -282,16 +282,25 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	// equally frequent left parts are ordered; the dictionary does, and is built afterwards for the chosen cut only, in the
 	// reference's (libstdc++'s) order — rd_dictionary_order.hpp.
 	// (sample t sits at smp[32 * (t / samples_size) + t % samples_size]; with 32-sample blocks that is smp[t])
-	auto smp_at = [&](int t) { return smp[32 * (t / samples_size) + (t % samples_size)]; };
+	// The bit patterns go to LDS in sample order first (W.* of the waves is free until the cut search), so that the rank loop is
+	// one broadcast read + compare per step instead of an index division per step.
+	uint64_t* s_unsorted = reinterpret_cast<uint64_t*>(&s_rd[0]); // 288 * 8 B <= sizeof(RdWaveScratch)
+	static_assert(sizeof(RdWaveScratch) >= kMaxSamples * sizeof(uint64_t), "scratch reuse");
+	if (tid < n_smp) { s_unsorted[tid] = P::pattern(smp[32 * (tid / samples_size) + (tid % samples_size)]); }
+	__syncthreads();
+	uint64_t my_key  = 0;
+	int      my_rank = 0;
 	if (tid < n_smp) {
-		const uint64_t key  = P::pattern(smp_at(tid));
-		int            rank = 0;
+		my_key = s_unsorted[tid];
 		for (int j = 0; j < n_smp; ++j) {
-			const uint64_t kj = P::pattern(smp_at(j));
-			rank += (kj < key || (kj == key && j < tid)) ? 1 : 0;
+			const uint64_t kj = s_unsorted[j];
+			my_rank += (kj < my_key || (kj == my_key && j < tid)) ? 1 : 0;
 		}
-		s_key[rank] = key;
-		s_idx[rank] = static_cast<uint16_t>(tid);
+	}
+	__syncthreads(); // everybody is done reading s_unsorted (it aliases wave 0's scratch)
+	if (tid < n_smp) {
+		s_key[my_rank] = my_key;
+		s_idx[my_rank] = static_cast<uint16_t>(tid);
 	}
 	__syncthreads();
 
@@ -357,24 +366,32 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 		const int ds       = s_cut_ds[best_cut];
 		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
 		// distinct left parts in order of first occurrence in the sample, with their counts
+		// (run starts are compacted into s_order.sorted[] = first occurrence, so the order loop walks D runs, not 288 samples)
 		int distinct = 0;
+		for (int b = 0; b < n_smp; b += 64) {
+			const int      j    = b + lane;
+			const bool     head = j < n_smp && W.len[j] != 0;
+			const uint64_t hb   = __ballot(head);
+			if (head) { s_order.sorted[distinct + __builtin_popcountll(hb & ((1ull << lane) - 1ull))] = W.first[j]; }
+			distinct += __builtin_popcountll(hb);
+		}
+		wave_lds_sync();
 		for (int b = 0; b < n_smp; b += 64) {
 			const int      j   = b + lane;
 			const uint32_t L   = j < n_smp ? W.len[j] : 0u;
 			const uint32_t fo  = j < n_smp ? W.first[j] : 0u;
 			int            ord = 0;
-			for (int g = 0; g < n_smp; ++g) { // broadcast reads
-				ord += (W.len[g] != 0 && W.first[g] < fo) ? 1 : 0;
-			}
+			for (int g = 0; g < distinct; ++g) { ord += s_order.sorted[g] < fo ? 1 : 0; } // broadcast reads
 			if (L != 0) {
 				s_order.okey[ord] = static_cast<uint32_t>(s_key[j] >> rbw);
 				s_order.ocnt[ord] = L;
 			}
-			distinct += __builtin_popcountll(__ballot(L != 0));
 		}
 		wave_lds_sync();
 		// the reference's order of equally frequent left parts is libstdc++'s (rd_dictionary_order.hpp): replayed by one lane
+#ifndef ALPGPU_EXPERIMENT_SKIP_RD_ORDER
 		if (lane == 0) { rd_reference_order(s_order, distinct); }
+#endif
 		wave_lds_sync();
 		if (rd_order) { // the whole sorted order, for the encoders' exception-slot indices (alpgpu_column.d_rd_order)
 			uint16_t* o = rd_order + rg * ALPGPU_RD_ORDER_STRIDE;
