@@ -56,6 +56,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 // status: [gridDim.x] tile words followed by [ceil(gridDim.x / kBlockTiles)] block words, all zero at launch.
+// N_SIZES = vectors per tile (entries of s_size); s_count counts the tile's kWavesPerWg wavefronts.
+template <int N_SIZES = kWavesPerWg>
 __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
                                               uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
 	uint64_t*      bstatus = status + gridDim.x;
@@ -111,7 +113,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 			__builtin_amdgcn_s_sleep(2);
 		}
 #pragma unroll
-		for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+		for (int w = 0; w < N_SIZES; ++w) { aggregate += s_size[w]; }
 		if (!stalled && lane == 0) { status_store(bstatus + block, (block == 0 ? kFlagPrefix : kFlagAggregate) | (local + aggregate)); }
 	}
 	// level 2: the base of this block = everything before it
