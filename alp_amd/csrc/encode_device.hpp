@@ -193,6 +193,7 @@ struct AlpEncoded {
 // 9.2e18 and +-Inf, or |r * 10^f| >= 2^63) is redone for the whole wavefront with the literal arithmetic; NaN never asks
 // for that (its compares are false) and is an exception on both routes.  Results are bit-identical by construction.
 __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int f, int lane, AlpEncoded& R) {
+	(void)lane; // every cross-lane step below is a ballot, a DPP move or a readlane
 	const double  exp10  = kExpArr[e];
 	const double  frac_f = kFracArr[f];
 	const int64_t fact   = kFactArr[f];

@@ -107,6 +107,7 @@ struct AlpEncodedF {
 };
 
 __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e, int f, int lane, AlpEncodedF& R) {
+	(void)lane; // every cross-lane step below is a ballot, a DPP move or a readlane
 	const float    exp10  = kExpArrF[e];
 	const float    frac_f = kFracArrF[f];
 	const uint32_t fact   = kFactArrF[f];
