@@ -309,6 +309,9 @@ struct PackedUnits {
 __device__ __forceinline__ void pack_u64_units(const EncodeLds& L, int bw, int lane, PackedUnits& P) {
 	const ull2v* vals2   = reinterpret_cast<const ull2v*>(L.vals);
 	const int    n_units = 8 * bw;
+	// bit0 / bw without a per-lane division: bit0 <= 4032 and bw <= 64, so with M = floor(2^20 / bw) + 1 the error term
+	// bit0 * (M * bw - 2^20) stays below 2^20 and (bit0 * M) >> 20 is the exact quotient (and fits 32 bits)
+	const uint32_t inv_bw = bw > 0 ? (1u << 20) / static_cast<uint32_t>(bw) + 1u : 0u;
 #pragma unroll
 	for (int t = 0; t < 8; ++t) {
 		ull2v     acc = {0ull, 0ull};
@@ -317,7 +320,7 @@ __device__ __forceinline__ void pack_u64_units(const EncodeLds& L, int bw, int l
 			const int k    = u >> 3;
 			const int a    = u & 7;
 			const int bit0 = 64 * k;
-			int       r    = bit0 / bw;
+			int       r    = static_cast<int>((static_cast<uint32_t>(bit0) * inv_bw) >> 20); // = bit0 / bw
 			int       p    = r * bw;
 			while (p < bit0 + 64 && r < 64) {
 				const ull2v v  = vals2[8 * r + a];
@@ -342,11 +345,14 @@ __device__ __forceinline__ void store_packed_units(const PackedUnits& P, int bw,
 __device__ __forceinline__ void pack_u64_from_lds(const EncodeLds& L, int bw, ulonglong2* __restrict__ out, int lane) {
 	const ulonglong2* vals2   = reinterpret_cast<const ulonglong2*>(L.vals);
 	const int         n_units = 8 * bw;
+	// bit0 / bw without a per-lane division: bit0 <= 4032 and bw <= 64, so with M = floor(2^20 / bw) + 1 the error term
+	// bit0 * (M * bw - 2^20) stays below 2^20 and (bit0 * M) >> 20 is the exact quotient (and fits 32 bits)
+	const uint32_t inv_bw = bw > 0 ? (1u << 20) / static_cast<uint32_t>(bw) + 1u : 0u;
 	for (int u = lane; u < n_units; u += 64) {
 		const int  k    = u >> 3;
 		const int  a    = u & 7;
 		const int  bit0 = 64 * k;
-		int        r    = bit0 / bw;
+		int        r    = static_cast<int>((static_cast<uint32_t>(bit0) * inv_bw) >> 20); // = bit0 / bw
 		int        p    = r * bw;
 		ulonglong2 acc  = make_ulonglong2(0, 0);
 		while (p < bit0 + 64 && r < 64) {

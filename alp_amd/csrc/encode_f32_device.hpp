@@ -215,6 +215,9 @@ struct PackedUnitsF32 {
 __device__ __forceinline__ void pack_u32_units(const EncodeLdsF32& L, int bw, int lane, PackedUnitsF32& P) {
 	const u32x4* vals4   = reinterpret_cast<const u32x4*>(L.vals);
 	const int    n_units = 8 * bw;
+	// bit0 / bw without a per-lane division: bit0 <= 4032 and bw <= 64, so with M = floor(2^20 / bw) + 1 the error term
+	// bit0 * (M * bw - 2^20) stays below 2^20 and (bit0 * M) >> 20 is the exact quotient (and fits 32 bits)
+	const uint32_t inv_bw = bw > 0 ? (1u << 20) / static_cast<uint32_t>(bw) + 1u : 0u;
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
 		u32x4     acc = {0u, 0u, 0u, 0u};
@@ -223,7 +226,7 @@ __device__ __forceinline__ void pack_u32_units(const EncodeLdsF32& L, int bw, in
 			const int k    = u >> 3;
 			const int a    = u & 7;
 			const int bit0 = 32 * k;
-			int       r    = bit0 / bw;
+			int       r    = static_cast<int>((static_cast<uint32_t>(bit0) * inv_bw) >> 20); // = bit0 / bw
 			int       p    = r * bw;
 			while (p < bit0 + 32 && r < 32) {
 				const u32x4 v  = vals4[8 * r + a];
@@ -248,11 +251,14 @@ __device__ __forceinline__ void store_packed_units_f32(const PackedUnitsF32& P, 
 __device__ __forceinline__ void pack_u32_from_lds(const EncodeLdsF32& L, int bw, u32x4* __restrict__ out, int lane) {
 	const u32x4* vals4   = reinterpret_cast<const u32x4*>(L.vals);
 	const int    n_units = 8 * bw;
+	// bit0 / bw without a per-lane division: bit0 <= 4032 and bw <= 64, so with M = floor(2^20 / bw) + 1 the error term
+	// bit0 * (M * bw - 2^20) stays below 2^20 and (bit0 * M) >> 20 is the exact quotient (and fits 32 bits)
+	const uint32_t inv_bw = bw > 0 ? (1u << 20) / static_cast<uint32_t>(bw) + 1u : 0u;
 	for (int u = lane; u < n_units; u += 64) {
 		const int k    = u >> 3;
 		const int a    = u & 7;
 		const int bit0 = 32 * k;
-		int       r    = bit0 / bw;
+		int       r    = static_cast<int>((static_cast<uint32_t>(bit0) * inv_bw) >> 20); // = bit0 / bw
 		int       p    = r * bw;
 		u32x4     acc  = {0u, 0u, 0u, 0u};
 		while (p < bit0 + 32 && r < 32) {
