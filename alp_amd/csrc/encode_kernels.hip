@@ -411,6 +411,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	}
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
+#ifdef ALPGPU_ABLATE_STORES // timing experiment: everything but the output stores
+	if (packed_capacity == 1) {
+#endif
 	if (cnt > 0) {
 		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
 		const int  rbw = d.bw;
@@ -433,6 +436,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 			out32[32 * k + lane] = (static_cast<uint32_t>(acc0 >> (16 * k)) & 0xFFFFu) | ((static_cast<uint32_t>(acc1 >> (16 * k)) & 0xFFFFu) << 16);
 		}
 	}
+#ifdef ALPGPU_ABLATE_STORES
+	}
+#endif
 	if (lane == 0) { descs[v] = d; }
 #ifdef ALPGPU_FUSED_TIMING
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -67,6 +67,13 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	bool           stalled = false;
 	uint32_t       spins   = 0;
 	auto give_up = [&]() { return ++spins > kSpinLimit || status_load(totals + 3) != 0; };
+#ifdef ALPGPU_ABLATE_LOOKBACK // timing experiment: worst-case strides instead of the scan (the output is NOT compact)
+	if (lane == 0) {
+		*s_excl = status_pack(0, tile * N_SIZES * 66, tile * N_SIZES * 1280);
+		__hip_atomic_store(s_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	return;
+#endif
 
 	// level 1: the sizes of the i predecessors inside this block
 	uint64_t local = 0;
