@@ -99,6 +99,8 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	return ALPGPU_OK;
 }
 
+int alpgpu_init(int device, alpgpu_ctx** out_ctx) { return alpgpu_ctx_create(device, out_ctx); }
+
 void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 	if (!ctx) { return; }
 	(void)hipSetDevice(ctx->device);
@@ -376,6 +378,16 @@ int alpgpu_rd_decode_vectors_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t*
 	ALPGPU_PRIM(d_out && d_right && d_left && d_states && d_exc && d_pos && d_cnt,
 	            alpgpu::launch_rd_decode(ctx->stream, ctx->n_cus, d_out, d_right, d_left, d_states, d_state_idx, d_exc, d_pos, exc_stride,
 	                                     d_cnt, n_vectors));
+}
+
+int alpgpu_rd_encode_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx, uint16_t* d_exc,
+                         uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, uint64_t* d_right, uint16_t* d_left, uint64_t n_vectors) {
+	return alpgpu_rd_encode_vectors_f64(ctx, d_in, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, d_right, d_left, n_vectors);
+}
+int alpgpu_rd_decode_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t* d_right, const uint16_t* d_left, const alpgpu_rowgroup_state* d_states,
+                         const uint32_t* d_state_idx, const uint16_t* d_exc, const uint16_t* d_pos, size_t exc_stride, const uint16_t* d_cnt,
+                         uint64_t n_vectors) {
+	return alpgpu_rd_decode_vectors_f64(ctx, d_out, d_right, d_left, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, n_vectors);
 }
 
 // ---- tail padding + blob container ---------------------------------------------------------------------------------

@@ -131,6 +131,7 @@ typedef struct alpgpu_column {
 
 /* ---- context / plumbing ------------------------------------------------------------------------- */
 int         alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx);
+int         alpgpu_init(int device, alpgpu_ctx** out_ctx); /* the name SURVEY.md §8(b) uses for the same call */
 void        alpgpu_ctx_destroy(alpgpu_ctx* ctx);
 const char* alpgpu_last_error(void);
 int         alpgpu_abi_version(void);
@@ -278,6 +279,13 @@ int alpgpu_rd_decode_vectors_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t*
                                  const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
                                  const uint16_t* d_exc, const uint16_t* d_pos, size_t exc_stride,
                                  const uint16_t* d_cnt, uint64_t n_vectors);
+/* the same two under the names SURVEY.md §8(b) lists (alpgpu_rd_encode_f64 / alpgpu_rd_decode_f64) */
+int alpgpu_rd_encode_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx,
+                         uint16_t* d_exc, uint16_t* d_pos, size_t exc_stride, uint16_t* d_cnt, uint64_t* d_right, uint16_t* d_left,
+                         uint64_t n_vectors);
+int alpgpu_rd_decode_f64(alpgpu_ctx* ctx, double* d_out, const uint64_t* d_right, const uint16_t* d_left,
+                         const alpgpu_rowgroup_state* d_states, const uint32_t* d_state_idx, const uint16_t* d_exc,
+                         const uint16_t* d_pos, size_t exc_stride, const uint16_t* d_cnt, uint64_t n_vectors);
 
 /* ==== single precision ====================================================================
  * The float instantiation of the same API: alp::encoder<float> / decoder<float> / rd_encoder<float> (same files and
