@@ -80,3 +80,20 @@ def test_whole_column_matches_reference(oracle, ref, name):
     golden_io.assert_same_encoding(a, b, name)
     dec = oracle.decode_column(a)
     assert np.array_equal(dec.view(np.uint64), col.view(np.uint64))
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_fuzz_columns_oracle_equals_reference(oracle, ref, seed):
+    """the boundary-hunting random columns of tests/test_fuzz_gpu.py, restatement against the real reference (both precisions)"""
+    from oracle.pyoracle import OracleF32, ReferenceF32
+    from test_fuzz_gpu import fuzz_column
+    c = fuzz_column(np.random.default_rng(7000 + seed), np.float64)
+    a, b = oracle.encode_column(c), ref.encode_column(c)
+    golden_io.assert_same_encoding(a, b, f"f64 seed {seed}")
+    assert np.array_equal(oracle.decode_column(a).view(np.uint64), c.view(np.uint64))
+    if ReferenceF32.available():
+        of, rf = OracleF32(), ReferenceF32()
+        c = fuzz_column(np.random.default_rng(9000 + seed), np.float32)
+        a, b = of.encode_column(c), rf.encode_column(c)
+        golden_io.assert_same_encoding(a, b, f"f32 seed {seed}", word=np.uint32)
+        assert np.array_equal(of.decode_column(a).view(np.uint32), c.view(np.uint32))
