@@ -76,6 +76,9 @@ def test_fuzz_double(ctx, oracle, seed):
     out = ctx.decode(dcol)
     ctx.synchronize()
     assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+    out2 = ctx.decode(capi.DeviceColumn.from_host(*want))  # the decoder on the oracle's own encoding
+    ctx.synchronize()
+    assert torch.equal(out2.view(torch.int64), x.view(torch.int64))
 
 
 @pytest.mark.parametrize("seed", list(range(ROUNDS)))
@@ -94,3 +97,6 @@ def test_fuzz_float(ctx, seed):
     out = ctx.decode(dcol)
     ctx.synchronize()
     assert torch.equal(out.view(torch.int32), x.view(torch.int32))
+    out2 = ctx.decode(capi.DeviceColumn.from_host(*want, dtype="f32"))
+    ctx.synchronize()
+    assert torch.equal(out2.view(torch.int32), x.view(torch.int32))
