@@ -196,8 +196,8 @@ def cpu_baseline_leg(col, vec, gpu_out, sample_vectors: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps first (the first ~10 launches after an idle gap run 3-30 %% slower: tools/launch_trend.py)")
     ap.add_argument("--vectors", type=int, default=1 << 20, help="vectors per GPU (default 1 Mi = 8 GiB decoded)")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-bit-width sweep, the encode legs and the CPU baseline")
     args = ap.parse_args()
@@ -288,7 +288,7 @@ def main():
         sweep = {}
         for bw in (1, 2, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 53):
             c, _, ab = build_decode_column(ns, local_rank, seed=7, bw_of_rowgroup=bw)
-            med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+            med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
             sweep[str(bw)] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
             del c
         extras["decode_sweep_by_bit_width"] = sweep
@@ -300,17 +300,17 @@ def main():
             row = {}
             for vpw in (1, 2):
                 ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
-                med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+                med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
                 row[f"vectors_per_wg_{vpw}"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
             ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
-            med, _ = time_launches(lambda: ctx.decode(c, out), 5, 2)
+            med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
             row["auto"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
             exc_cases[label] = row
             del c
         extras["decode_exceptions_and_tuning"] = exc_cases
         # decode fused into a SUM consumer: the 8 KiB per vector of decoded doubles never reach HBM
         sums = torch.empty(n, dtype=torch.float64, device=dev)
-        med, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 2)
+        med, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 10)
         read_bytes = alg_bytes - n * 8192 + n * 8
         extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
                                       "roofline_frac_algorithmic": round(read_bytes / med / 1e6 / HBM_PEAK_GBPS, 4),
@@ -323,7 +323,7 @@ def main():
             ecol = capi.DeviceColumn(ne, local_rank)
             med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
             pb, eb, ov = ctx.column_totals(ecol)
-            dmed, _ = time_launches(lambda: ctx.decode(ecol, out), 5, 2)
+            dmed, _ = time_launches(lambda: ctx.decode(ecol, out), 7, 10)
             rt = bool(torch.equal(out[: ne * VEC].view(torch.int64), x.view(torch.int64)))
             extras[label] = {"input_GBps": round(ne * 8192 / med / 1e6, 1), "ms": round(med, 3), "vectors": ne,
                              "compressed_bits_per_value": round((pb + eb + 32 * ne) * 8 / (ne * VEC), 2),
@@ -351,7 +351,7 @@ def main():
             fcol = capi.DeviceColumn(n, local_rank, dtype="f32")
             emed, _ = time_launches(lambda: ctx.encode(xf, fcol), 3, 1)
             pb, eb, ov = ctx.column_totals(fcol)
-            dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 5, 2)
+            dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
             rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
             fl[kind] = {"vectors": n, "encode_input_GBps": round(n * 4096 / emed / 1e6, 1), "encode_ms": round(emed, 3),
                         "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
