@@ -76,6 +76,7 @@ _sig("alpgpu_exc_capacity", _u64, _u64)
 _sig("alpgpu_use_own_stream", _int, _vp)
 _sig("alpgpu_decode_f64", _int, _vp, C.POINTER(CColumn), _vp)
 _sig("alpgpu_decode_sum_f64", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_decode_count_range_f64", _int, _vp, C.POINTER(CColumn), C.c_double, C.c_double, _vp)
 _sig("alpgpu_rowgroup_init_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_vectors_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
@@ -294,6 +295,14 @@ class Context:
     def rd_decode_vectors(self, out, right, left, states, state_idx, exc, pos, cnt):
         _check(lib.alpgpu_rd_decode_vectors_f64(self.h, self._p(out), self._p(right), self._p(left), self._p(states), self._p(state_idx),
                                                 self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_rd_decode_vectors_f64")
+
+    def decode_count_range(self, col: "DeviceColumn", lo: float, hi: float, out=None):
+        """per-vector count of decoded values in [lo, hi] without materialising them (alpgpu_decode_count_range_f64)"""
+        import torch
+        if out is None:
+            out = torch.empty(col.n_vectors, dtype=torch.int32, device=f"cuda:{self.device}")
+        _check(lib.alpgpu_decode_count_range_f64(self.h, C.byref(col.c), lo, hi, _vp(out.data_ptr())), "alpgpu_decode_count_range_f64")
+        return out
 
     def decode_sum(self, col: "DeviceColumn", out=None):
         """per-vector sums of the decoded values without materialising them (alpgpu_decode_sum_f64)"""

@@ -289,6 +289,17 @@ int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_s
 	return ALPGPU_OK;
 }
 
+int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_counts && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	if (alpgpu::launch_decode_count_range(ctx->stream, col, lo, hi, d_counts) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
 int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }

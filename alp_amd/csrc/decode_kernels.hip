@@ -109,13 +109,27 @@ __device__ __forceinline__ void store_pair(double2* __restrict__ p, double x, do
 }
 
 // ---- one vector, after its packed words / exception mask are visible in L --------------------------------------
-// SUM = false: the decoded pair is stored (dst).  SUM = true: it is added to `acc` instead, x then y, in step order —
+// SINK = kSinkStore: the decoded pair is stored (dst).  kSinkSum: it is added to `acc` instead, x then y, in step order —
 // the fixed order tests/test_decode_sum_gpu.py reproduces on the host (decode fused into its
 // consumer, the shape of publication/source_code/bench_end_to_end/src/benchmarks/alp/queries/q1.cpp:63-104, without the
 // 8 KiB per vector of decoded doubles ever reaching HBM).
-template <bool NT_STORE, bool SUM = false>
+// kSinkCount: `acc` counts the values v with lo <= v <= hi (a predicate pushed into the decode; NaN never qualifies).
+constexpr int kSinkStore = 0, kSinkSum = 1, kSinkCount = 2;
+template <int SINK>
+__device__ __forceinline__ void consume_pair(double ox, double oy, double* acc, double lo, double hi) {
+	if constexpr (SINK == kSinkSum) {
+		*acc += ox;
+		*acc += oy;
+	} else {
+		*acc += (ox >= lo && ox <= hi) ? 1.0 : 0.0; // small integers: exact in double
+		*acc += (oy >= lo && oy <= hi) ? 1.0 : 0.0;
+	}
+}
+
+template <bool NT_STORE, int SINK = kSinkStore>
 __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
-                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr) {
+                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
+                                                     double range_lo = 0.0, double range_hi = 0.0) {
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
 	ExcMask        em {0u, 0};
@@ -162,9 +176,8 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 				}
 				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank))); }
 			}
-			if constexpr (SUM) {
-				*acc += ox;
-				*acc += oy;
+			if constexpr (SINK != kSinkStore) {
+				consume_pair<SINK>(ox, oy, acc, range_lo, range_hi);
 			} else {
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
 			}
@@ -207,9 +220,8 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 			}
 			const double ox = __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x));
 			const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
-			if constexpr (SUM) {
-				*acc += ox;
-				*acc += oy;
+			if constexpr (SINK != kSinkStore) {
+				consume_pair<SINK>(ox, oy, acc, range_lo, range_hi);
 			} else {
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
 			}
@@ -265,12 +277,12 @@ __device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vecto
 
 // V consecutive vectors per workgroup: all of their loads are in flight together, then they are unpacked one after the
 // other by the same 4 wavefronts.  V = 2 doubles the bytes in flight per CU for the same residency (8 workgroups per CU).
-template <int V, bool NT_STORE, bool SUM = false>
+template <int V, bool NT_STORE, int SINK = kSinkStore>
 __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_vector_desc* __restrict__ descs,
                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                   const uint8_t* __restrict__ packed,
                                                                   const uint8_t* __restrict__ excs, double* __restrict__ out,
-                                                                  uint64_t n_vectors, uint64_t wg_offset) {
+                                                                  uint64_t n_vectors, uint64_t wg_offset, double lo, double hi) {
 	__shared__ DecodeLds L[V];
 	static_assert(kDecWaves >= 2, "exception staging assumes at least kExcStage threads");
 	const int      tid  = static_cast<int>(threadIdx.x);
@@ -298,14 +310,15 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
 	__syncthreads();
 
-	if constexpr (SUM) {
+	if constexpr (SINK != kSinkStore) {
 		// per-vector sums: lane partial (step order) -> wavefront butterfly (xor 32,16,..,1) -> (w0 + w1) + (w2 + w3)
+		// (counts take the same route; they are small integers, so the order does not matter)
 		__shared__ double s_part[V][kDecWaves];
 #pragma unroll
 		for (int i = 0; i < V; ++i) {
 			double acc = 0.0;
 			if (v0 + i < n_vectors) {
-				decode_staged_vector<NT_STORE, true>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, nullptr, wave, lane, &acc);
+				decode_staged_vector<NT_STORE, SINK>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
 			}
 #pragma unroll
 			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
@@ -314,7 +327,12 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		__syncthreads();
 		if (tid < V && v0 + tid < n_vectors) {
 			static_assert(kDecWaves == 4, "the documented summation order is for 4 wavefronts per vector");
-			out[v0 + tid] = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+			const double total = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+			if constexpr (SINK == kSinkCount) {
+				reinterpret_cast<uint32_t*>(out)[v0 + tid] = static_cast<uint32_t>(total);
+			} else {
+				out[v0 + tid] = total;
+			}
 		}
 		return;
 	}
@@ -338,13 +356,13 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 2 && nt) {
-			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (nt) {
-			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
@@ -360,10 +378,23 @@ int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_su
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off);
+			hipLaunchKernelGGL((k_decode_column<2, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off);
+			hipLaunchKernelGGL((k_decode_column<1, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
 		}
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// per-vector number of values in [lo, hi]: the same kernel with the predicate as its consumer (two vectors per workgroup)
+int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts) {
+	const uint64_t n        = col->n_vectors;
+	const uint64_t n_wg     = (n + 1) / 2;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
+		hipLaunchKernelGGL((k_decode_column<2, false, kSinkCount>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc,
+		                   reinterpret_cast<double*>(d_counts), n, off, lo, hi);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

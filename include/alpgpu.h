@@ -198,6 +198,9 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
  * 256q+2L, +1, 256q+128+2L, +1 in that order starting from 0; lanes combine by a butterfly (partner L^32, ^16, .., ^1);
  * the four wavefront sums combine as (w0 + w1) + (w2 + w3). */
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
+/* The other consumer named there, a predicate pushed into the scan: d_counts[v] = number of decoded values x of vector v with
+ * lo <= x <= hi (exceptions patched in; NaN never qualifies; -0.0 == 0.0 as in C).  Nothing but 4 bytes per vector is written. */
+int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
 
 /* host copy of d_totals after the stream has drained: packed bytes, exception bytes, overflow flag */
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow);

@@ -56,3 +56,21 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name, vectors_per_wg):
     assert same.all(), f"{name}: {np.nonzero(~same)[0][:5]} {got[~same][:3]} {want[~same][:3]}"
     finite = np.isfinite(want)
     assert np.allclose(got[finite], col.reshape(-1, 1024)[finite].sum(axis=1), rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name", list(COLUMNS.keys()))
+def test_decode_count_range_matches_numpy(ctx, oracle, name):
+    """the predicate consumer: per-vector counts of lo <= x <= hi on the decoded values (exceptions, NaN, Inf, -0.0 included)"""
+    from alp_amd import capi
+    col = COLUMNS[name]()
+    enc = oracle.encode_column(col)
+    dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
+    v = col.reshape(-1, 1024)
+    finite = col[np.isfinite(col)]
+    for lo, hi in ((float(np.quantile(finite, 0.25)), float(np.quantile(finite, 0.75))), (0.0, 0.0), (-np.inf, np.inf), (1.0, -1.0),
+                   (float(finite.max()), float(finite.max()))):
+        got = ctx.decode_count_range(dcol, lo, hi)
+        ctx.synchronize()
+        with np.errstate(invalid="ignore"):
+            want = ((v >= lo) & (v <= hi)).sum(axis=1)
+        assert np.array_equal(got.cpu().numpy().astype(np.int64), want), (name, lo, hi)
