@@ -40,6 +40,9 @@ def test_cpp_dropin_header_against_reference_columns(tmp_path):
         bw = int(known[0]) if known[0] >= 0 else (int(gold["bw"][0]) if not is_rd else -1)
         exc = int(known[1]) if known[1] >= 0 else (int(gold["exc_cnt"][0]) if not is_rd else -1)
         lines.append(f"f32 f32_{name} {col.size} {bw} {exc} {is_rd}")
+    tailf = np.round(np.random.default_rng(2).uniform(0, 100, 2 * 1024 + 333), 1).astype(np.float32)
+    tailf.tofile(tmp_path / "partial_tail_f32.f32")
+    lines.append(f"f32 partial_tail_f32 {tailf.size} -1 -1 0")
     (tmp_path / "columns.txt").write_text("\n".join(lines) + "\n")
     p = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=600)
     tail_out = "\n".join(p.stdout.splitlines()[-15:])
