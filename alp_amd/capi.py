@@ -103,6 +103,8 @@ _sig("alpgpu_rd_decode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _v
 _sig("alpgpu_packed_capacity_f32", _u64, _u64)
 _sig("alpgpu_exc_capacity_f32", _u64, _u64)
 _sig("alpgpu_decode_f32", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_decode_sum_f32", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_decode_count_range_f32", _int, _vp, C.POINTER(CColumn), C.c_float, C.c_float, _vp)
 _sig("alpgpu_rowgroup_init_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_vectors_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn))
@@ -297,19 +299,21 @@ class Context:
                                                 self._p(exc), self._p(pos), exc.shape[1], self._p(cnt), out.shape[0]), "alpgpu_rd_decode_vectors_f64")
 
     def decode_count_range(self, col: "DeviceColumn", lo: float, hi: float, out=None):
-        """per-vector count of decoded values in [lo, hi] without materialising them (alpgpu_decode_count_range_f64)"""
+        """per-vector count of decoded values in [lo, hi] without materialising them (alpgpu_decode_count_range_f64 / _f32)"""
         import torch
         if out is None:
             out = torch.empty(col.n_vectors, dtype=torch.int32, device=f"cuda:{self.device}")
-        _check(lib.alpgpu_decode_count_range_f64(self.h, C.byref(col.c), lo, hi, _vp(out.data_ptr())), "alpgpu_decode_count_range_f64")
+        fn = lib.alpgpu_decode_count_range_f64 if col.dtype == "f64" else lib.alpgpu_decode_count_range_f32
+        _check(fn(self.h, C.byref(col.c), lo, hi, _vp(out.data_ptr())), "alpgpu_decode_count_range")
         return out
 
     def decode_sum(self, col: "DeviceColumn", out=None):
-        """per-vector sums of the decoded values without materialising them (alpgpu_decode_sum_f64)"""
+        """per-vector sums (float64) of the decoded values without materialising them (alpgpu_decode_sum_f64 / _f32)"""
         import torch
         if out is None:
             out = torch.empty(col.n_vectors, dtype=torch.float64, device=f"cuda:{self.device}")
-        _check(lib.alpgpu_decode_sum_f64(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_decode_sum_f64")
+        fn = lib.alpgpu_decode_sum_f64 if col.dtype == "f64" else lib.alpgpu_decode_sum_f32
+        _check(fn(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_decode_sum")
         return out
 
     def decode(self, col: "DeviceColumn", out=None):

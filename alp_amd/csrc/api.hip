@@ -607,6 +607,26 @@ int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out) {
 	return ALPGPU_OK;
 }
 
+int alpgpu_decode_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	if (alpgpu::launch_decode_sum_f32(ctx->stream, col, d_sums) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+
+int alpgpu_decode_count_range_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_counts && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	if (alpgpu::launch_decode_count_range_f32(ctx->stream, col, lo, hi, d_counts) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
 int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_values) { return fail(ALPGPU_ERR_INVALID, "null input"); }

@@ -107,9 +107,13 @@ __device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgp
 }
 
 // one vector, after its packed words / exception mask are visible in L; thread tid owns values 4*tid .. 4*tid+3
-template <bool NT_STORE>
+// SINK (as in decode_kernels.hip) = kSinkStoreF: the quad is stored.  kSinkSumF: its four values are widened to double
+// (exact) and added to `acc` in index order.  kSinkCountF: `acc` counts the values v with lo <= v <= hi (NaN never does).
+constexpr int kSinkStoreF = 0, kSinkSumF = 1, kSinkCountF = 2;
+template <bool NT_STORE, int SINK = kSinkStoreF>
 __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
-                                                         const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane) {
+                                                         const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane,
+                                                         double* acc = nullptr, float range_lo = 0.0f, float range_hi = 0.0f) {
 	const int    bw    = d.bw;
 	const int    cnt   = d.exc_cnt;
 	const int    a     = tid & 7;
@@ -174,14 +178,26 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 			out[c] = (l << rbw) | q[c];
 		}
 	}
-	store_quad<NT_STORE>(dst + 4 * tid, out);
+	if constexpr (SINK == kSinkSumF) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { *acc += static_cast<double>(__uint_as_float(out[c])); }
+	} else if constexpr (SINK == kSinkCountF) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const float v = __uint_as_float(out[c]);
+			*acc += (v >= range_lo && v <= range_hi) ? 1.0 : 0.0;
+		}
+	} else {
+		store_quad<NT_STORE>(dst + 4 * tid, out);
+	}
 }
 
-template <int V, bool NT_STORE>
+// SINK != kSinkStoreF: `out` is the per-vector result array instead (double sums / uint32 counts)
+template <int V, bool NT_STORE, int SINK = kSinkStoreF>
 __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu_vector_desc* __restrict__ descs,
                                                                     const alpgpu_rowgroup_state* __restrict__ rgs, const uint8_t* __restrict__ packed,
                                                                     const uint8_t* __restrict__ excs, float* __restrict__ out, uint64_t n_vectors,
-                                                                    uint64_t wg_offset) {
+                                                                    uint64_t wg_offset, float range_lo, float range_hi) {
 	__shared__ DecodeLdsF32 L[V];
 	const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
@@ -204,6 +220,33 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 	for (int i = 0; i < V; ++i) { land_exceptions_f32(L[i], d[i], excs + d[i].exc_off, e[i], tid); }
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
+	if constexpr (SINK != kSinkStoreF) {
+		// per-vector result: thread partial over its quad (index order, in double) -> wavefront butterfly (xor 32,16,..,1)
+		// -> (w0 + w1) + (w2 + w3); tests/test_decode_sum_gpu.py replays this order on the host
+		__shared__ double s_part[V][kDecThreadsF / 64];
+#pragma unroll
+		for (int i = 0; i < V; ++i) {
+			double acc = 0.0;
+			if (v0 + i < n_vectors) {
+				decode_staged_vector_f32<NT_STORE, SINK>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, nullptr, tid, wave, lane, &acc, range_lo,
+				                                         range_hi);
+			}
+#pragma unroll
+			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
+			if (lane == 0) { s_part[i][wave] = acc; }
+		}
+		__syncthreads();
+		if (tid < V && v0 + tid < n_vectors) {
+			static_assert(kDecThreadsF == 256, "the documented summation order is for 4 wavefronts per vector");
+			const double total = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+			if constexpr (SINK == kSinkCountF) {
+				reinterpret_cast<uint32_t*>(out)[v0 + tid] = static_cast<uint32_t>(total);
+			} else {
+				reinterpret_cast<double*>(out)[v0 + tid] = total;
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {
@@ -220,9 +263,9 @@ static void launch_v(hipStream_t stream, const alpgpu_column* col, float* d_out,
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
 		if (nt) {
-			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
 		} else {
-			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off);
+			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
 		}
 	}
 }
@@ -238,6 +281,27 @@ int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float
 		launch_v<4>(stream, col, d_out, !plain_stores);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+template <int SINK, int V>
+static int launch_sink_f32(hipStream_t stream, const alpgpu_column* col, void* d_result, float lo, float hi) {
+	const uint64_t n = col->n_vectors;
+	if (n == 0) { return ALPGPU_OK; }
+	const uint64_t n_wg     = (n + V - 1) / V;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
+		hipLaunchKernelGGL((k_decode_column_f32<V, false, SINK>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc,
+		                   static_cast<float*>(d_result), n, off, lo, hi);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// two vectors per workgroup: measured 1.57 / 1.30 / 1.37 ms per 1 Mi vectors for 1 / 2 / 4
+int launch_decode_sum_f32(hipStream_t stream, const alpgpu_column* col, double* d_sums) { return launch_sink_f32<kSinkSumF, 2>(stream, col, d_sums, 0.0f, 0.0f); }
+
+int launch_decode_count_range_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts) {
+	return launch_sink_f32<kSinkCountF, 2>(stream, col, d_counts, lo, hi);
 }
 
 } // namespace alpgpu

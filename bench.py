@@ -362,11 +362,14 @@ def main():
             pb, eb, ov = ctx.column_totals(fcol)
             dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
             rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
+            fsums = torch.empty(n, dtype=torch.float64, device=dev)
+            smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)
+            del fsums
             fl[kind] = {"vectors": n, "encode_input_GBps": round(n * 4096 / emed / 1e6, 1), "encode_ms": round(emed, 3),
                         "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
                         "decode_GBps_decoded_floats": round(n * 4096 / dmed / 1e6, 1), "decode_ms": round(dmed, 3),
                         "decode_roofline_frac_algorithmic": round((n * (4096 + 13) + pb + eb) / dmed / 1e6 / HBM_PEAK_GBPS, 4),
-                        "gpu_roundtrip_bit_exact": rt}
+                        "decode_sum_fused_ms": round(smed, 3), "gpu_roundtrip_bit_exact": rt}
             del xf, fcol
         extras["float_path"] = fl
         result["extras"] = extras
