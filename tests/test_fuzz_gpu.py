@@ -1,7 +1,8 @@
 """GPU differential fuzzing against the oracle: random columns built to sit on the decision boundaries of the codec — magnitudes
 around 2^51 / 2^53 / 2^63 scaled by powers of ten (the ranges where the encode kernel switches between its shortcut and the
 literal arithmetic), mixed precisions inside a rowgroup, runs of constants, specials, exception bursts, ALP_RD stretches — whole
-streams compared byte for byte, then decoded back.  Seeds are fixed; ALPGPU_FUZZ_ROUNDS=n runs more rounds."""
+streams compared byte for byte, then decoded back.  Seeds are fixed; ALPGPU_FUZZ_ROUNDS=n runs more rounds, ALPGPU_FUZZ_SEED_BASE=k
+shifts them to fresh seeds.  The last test does the same against the REAL reference (oracle/_ref), a quarter as many rounds."""
 import os
 
 import numpy as np
@@ -12,6 +13,7 @@ import layout
 
 pytestmark = pytest.mark.gpu
 ROUNDS = int(os.environ.get("ALPGPU_FUZZ_ROUNDS", "24"))
+SEED_BASE = int(os.environ.get("ALPGPU_FUZZ_SEED_BASE", "0"))
 
 
 def fuzz_column(rng, dtype):
@@ -64,7 +66,7 @@ def fuzz_column(rng, dtype):
 @pytest.mark.parametrize("seed", list(range(ROUNDS)))
 def test_fuzz_double(ctx, oracle, seed):
     from alp_amd import capi
-    col_np = fuzz_column(np.random.default_rng(7000 + seed), np.float64)
+    col_np = fuzz_column(np.random.default_rng(7000 + SEED_BASE + seed), np.float64)
     want = layout.compact(oracle.encode_column(col_np))
     x = torch.from_numpy(col_np).cuda()
     dcol = capi.DeviceColumn(col_np.size // 1024)
@@ -85,7 +87,7 @@ def test_fuzz_double(ctx, oracle, seed):
 def test_fuzz_float(ctx, seed):
     from alp_amd import capi
     from oracle.pyoracle import OracleF32
-    col_np = fuzz_column(np.random.default_rng(9000 + seed), np.float32)
+    col_np = fuzz_column(np.random.default_rng(9000 + SEED_BASE + seed), np.float32)
     want = layout.compact(OracleF32().encode_column(col_np), 4)
     x = torch.from_numpy(col_np).cuda()
     dcol = capi.DeviceColumn(col_np.size // 1024, dtype="f32")
@@ -100,3 +102,27 @@ def test_fuzz_float(ctx, seed):
     out2 = ctx.decode(capi.DeviceColumn.from_host(*want, dtype="f32"))
     ctx.synchronize()
     assert torch.equal(out2.view(torch.int32), x.view(torch.int32))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("seed", list(range(max(1, ROUNDS // 4))))
+def test_fuzz_against_the_reference(ctx, ref, seed, dtype):
+    """no restatement in between: the GPU streams against the streams of the reference compiled in place (oracle/_ref)"""
+    from alp_amd import capi
+    from oracle.pyoracle import ReferenceF32
+    if dtype == "f32" and not ReferenceF32.available():
+        pytest.skip("oracle/_ref without float entry points")
+    f64 = dtype == "f64"
+    col_np = fuzz_column(np.random.default_rng(11000 + SEED_BASE + seed), np.float64 if f64 else np.float32)
+    want = layout.compact(ref.encode_column(col_np)) if f64 else layout.compact(ReferenceF32().encode_column(col_np), 4)
+    x = torch.from_numpy(col_np).cuda()
+    dcol = capi.DeviceColumn(col_np.size // 1024, dtype=dtype)
+    ctx.encode(x, dcol)
+    ctx.synchronize()
+    assert ctx.column_totals(dcol)[2] == 0
+    for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"seed {seed} {dtype}: {what} differ from the reference"
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    it = torch.int64 if f64 else torch.int32
+    assert torch.equal(out.view(it), x.view(it))
