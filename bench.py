@@ -339,6 +339,11 @@ def main():
                                            "decode_achieved_vs_copy": round(achieved / copy_gbps, 4),
                                            "note": "torch tensor.copy_ of 8 GiB device to device, median of 7 after 10 warm-up copies"}
         del src
+        # and a write-only one: the narrow bit widths of the sweep are almost pure output traffic
+        fmed, _ = time_launches(lambda: out.fill_(1.0), 7, 10)
+        fill_gbps = out.numel() * 8 / fmed / 1e6
+        extras["measured_fill_ceiling"] = {"GBps_write": round(fill_gbps, 1), "frac_of_nominal_peak": round(fill_gbps / HBM_PEAK_GBPS, 4),
+                                           "note": "torch tensor.fill_ of 8 GiB, median of 7 after 10 warm-up fills"}
         # single precision: alpgpu_encode_f32 / alpgpu_decode_f32 on 1 Mi float vectors (4 GiB decoded)
         fl = {}
         outf = out.view(torch.float32)[: n * VEC]
