@@ -95,22 +95,53 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 	return v;
 }
 
+// Inclusive scans over the 64 lanes as DPP row shifts + row broadcasts (register to register).  The cut search below is a
+// chain of dependent scans per 64-sample chunk; as __shfl_up steps (ds_bpermute, one LDS-crossbar round trip each) that chain
+// was the latency that bounded ALP_RD rowgroups.
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
+	int v = static_cast<int>(x);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+	return static_cast<uint32_t>(v);
+}
+// values >= -1
+__device__ __forceinline__ int wave_scan_max_i32(int v) {
+	int t;
+	t = __builtin_amdgcn_update_dpp(-1, v, 0x111, 0xf, 0xf, false), v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(-1, v, 0x112, 0xf, 0xf, false), v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(-1, v, 0x114, 0xf, 0xf, false), v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(-1, v, 0x118, 0xf, 0xf, false), v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(-1, v, 0x142, 0xa, 0xf, false), v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(-1, v, 0x143, 0xc, 0xf, false), v = t > v ? t : v;
+	return v;
+}
+
 constexpr int kMaxSamples = kMaxSampledVectors * 32; // 288
 
 // per-wavefront scratch of the ALP_RD cut search
-struct RdWaveScratch {
+struct __attribute__((aligned(16))) RdWaveScratch {
 	uint32_t len[kMaxSamples];      // run length, stored at the run's first sorted position (0 elsewhere)
-	uint32_t first[kMaxSamples];    // smallest original sample index inside the run (its first occurrence)
 	uint32_t hist[kMaxSamples + 8]; // hist[L] = number of runs of length L
 };
 
-// Runs of equal left parts (bits >> rbw) in the sorted samples: fills W.len / W.first, zeroes W.hist.  One wavefront.
-__device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, const uint64_t* s_key, const uint16_t* s_idx, int n_smp, int rbw, int lane) {
+// The ALP_RD cut search only ever looks at the top 16 bits of a sample (cuts of 1..16 bits, rd.hpp:92), so the samples are
+// sorted by a 32-bit composite key = (top 16 bits << 16) | sample index: unique, one compare per pair, and the sample index
+// of every sorted entry comes along for free.
+__device__ __forceinline__ uint32_t rd_left_of(uint32_t composite, int cut) { return (composite >> 16) >> (16 - cut); }
+
+// Runs of equal left parts (the top `cut` bits) in the sorted samples: fills W.len, zeroes W.hist.  One wavefront.
+// first != nullptr (the chosen cut only): first[p] = smallest original sample index inside the run that starts at sorted
+// position p, i.e. the left part's first occurrence in the sample.
+__device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, uint32_t* first, const uint32_t* s_key, int n_smp, int cut, int lane) {
 	for (int b = 0; b < kMaxSamples + 8; b += 64) {
 		const int j = b + lane;
 		if (j < kMaxSamples) {
-			W.len[j]   = 0u;
-			W.first[j] = 0xFFFFFFFFu;
+			W.len[j] = 0u;
+			if (first) { first[j] = 0xFFFFFFFFu; }
 		}
 		if (j < kMaxSamples + 8) { W.hist[j] = 0u; }
 	}
@@ -119,21 +150,16 @@ __device__ __forceinline__ void rd_build_runs(RdWaveScratch& W, const uint64_t* 
 	for (int b = 0; b < n_smp; b += 64) {
 		const int      j     = b + lane;
 		const bool     valid = j < n_smp;
-		const uint64_t left  = valid ? (s_key[j] >> rbw) : 0ull;
-		const uint64_t prev  = (valid && j > 0) ? (s_key[j - 1] >> rbw) : ~left;
+		const uint32_t left  = valid ? rd_left_of(s_key[j], cut) : 0u;
+		const uint32_t prev  = (valid && j > 0) ? rd_left_of(s_key[j - 1], cut) : ~left;
 		const bool     head  = valid && (j == 0 || left != prev);
-		int            st    = head ? j : -1;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const int t = __shfl_up(st, d);
-			if (lane >= d) { st = t > st ? t : st; }
-		}
-		st = st < 0 ? carry : st;
+		int            st    = wave_scan_max_i32(head ? j : -1); // start of the run this sample belongs to
+		st                   = st < 0 ? carry : st;
 		if (valid) {
 			atomicAdd(&W.len[st], 1u);
-			atomicMin(&W.first[st], static_cast<uint32_t>(s_idx[j]));
+			if (first) { atomicMin(&first[st], s_key[j] & 0xFFFFu); }
 		}
-		carry = __shfl(st, 63);
+		carry = __builtin_amdgcn_readlane(st, 63);
 	}
 	wave_lds_sync();
 }
@@ -149,13 +175,12 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
                                                                 uint16_t* __restrict__ rd_order, uint64_t rg_first) {
 	__shared__ typename P::value_t smp[kMaxSampledVectors * 32];
 	__shared__ uint32_t best_key[kMaxSampledVectors];
-	__shared__ uint64_t      s_key[kMaxSamples]; // samples sorted by bit pattern (ALP_RD)
-	__shared__ uint16_t      s_idx[kMaxSamples]; // original sample index of each sorted entry
+	__shared__ uint32_t      s_key[kMaxSamples]; // (top 16 bits << 16 | sample index) of the samples, sorted (ALP_RD)
 	__shared__ RdWaveScratch s_rd[kMaxSampledVectors];
+	__shared__ uint32_t      s_first[kMaxSamples];
 	__shared__ double        s_cut_est[17];
 	__shared__ uint8_t       s_cut_ds[17];
 	__shared__ int           s_best_cut;
-	__shared__ RdOrderLds    s_order;
 	__shared__ int           s_scheme;
 
 	const int      lane    = lane_id();
@@ -262,9 +287,10 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 			}
 			const int k = n_c < 5 ? n_c : 5;
 			st.k        = static_cast<uint8_t>(k);
-			for (int i = 0; i < k; ++i) {
-				st.combos[2 * i]     = static_cast<uint8_t>(ce[i]);
-				st.combos[2 * i + 1] = static_cast<uint8_t>(cf[i]);
+#pragma unroll
+			for (int i = 0; i < 5; ++i) { // constant indices: `st` stays in registers (a dynamically indexed local is promoted to 18 KiB of LDS)
+				st.combos[2 * i]     = i < k ? static_cast<uint8_t>(ce[i]) : 0;
+				st.combos[2 * i + 1] = i < k ? static_cast<uint8_t>(cf[i]) : 0;
 			}
 		}
 		rgs[rg]  = st;
@@ -275,39 +301,45 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	if (s_scheme != ALPGPU_SCHEME_ALP_RD) { return; }
 
 	// ---- ALP_RD: find the cut and the dictionary (rd.hpp:89-104, :33-87) ----
-	// The samples are sorted ONCE by their 64-bit pattern; for every cut position the equal left parts are then
+	// The samples are sorted ONCE (by their top 16 bits, see rd_left_of); for every cut position the equal left parts are then
 	// contiguous runs of the sorted order.  One wavefront evaluates one cut at a time with wave-level primitives
 	// only: run starts (max-scan), run lengths and first occurrences (LDS atomics), a histogram of run lengths and
 	// a descending scan of it for the mass of the 8 most frequent left parts.  The size estimate does not depend on how
 	// equally frequent left parts are ordered; the dictionary does, and is built afterwards for the chosen cut only, in the
 	// reference's (libstdc++'s) order — rd_dictionary_order.hpp.
 	// (sample t sits at smp[32 * (t / samples_size) + t % samples_size]; with 32-sample blocks that is smp[t])
-	// The bit patterns go to LDS in sample order first (W.* of the waves is free until the cut search), so that the rank loop is
-	// one broadcast read + compare per step instead of an index division per step.
-	uint64_t* s_unsorted = reinterpret_cast<uint64_t*>(&s_rd[0]); // 288 * 8 B <= sizeof(RdWaveScratch)
-	static_assert(sizeof(RdWaveScratch) >= kMaxSamples * sizeof(uint64_t), "scratch reuse");
-	if (tid < n_smp) { s_unsorted[tid] = P::pattern(smp[32 * (tid / samples_size) + (tid % samples_size)]); }
+	// Rank sort: the composite keys go to LDS in sample order first (W.* of the waves is free until the cut search); every
+	// thread then counts the smaller keys, four broadcast keys per LDS read.
+	uint32_t* s_unsorted = reinterpret_cast<uint32_t*>(&s_rd[0]); // 288 * 4 B <= sizeof(RdWaveScratch)
+	static_assert(sizeof(RdWaveScratch) >= kMaxSamples * sizeof(uint32_t), "scratch reuse");
+	static_assert(kMaxSamples % 4 == 0, "the rank loop reads four keys at a time");
+	if (tid < kMaxSamples) {
+		uint32_t c = 0xFFFFFFFFu; // padding sorts behind every sample
+		if (tid < n_smp) {
+			c = (static_cast<uint32_t>(P::pattern(smp[32 * (tid / samples_size) + (tid % samples_size)]) >> (P::kBits - 16)) << 16) | static_cast<uint32_t>(tid);
+		}
+		s_unsorted[tid] = c;
+	}
 	__syncthreads();
-	uint64_t my_key  = 0;
+	uint32_t my_key  = 0;
 	int      my_rank = 0;
 	if (tid < n_smp) {
-		my_key = s_unsorted[tid];
-		for (int j = 0; j < n_smp; ++j) {
-			const uint64_t kj = s_unsorted[j];
-			my_rank += (kj < my_key || (kj == my_key && j < tid)) ? 1 : 0;
+		my_key             = s_unsorted[tid];
+		const u32x4* quads = reinterpret_cast<const u32x4*>(s_unsorted);
+		const int    n_q   = (n_smp + 3) / 4;
+		for (int q = 0; q < n_q; ++q) {
+			const u32x4 k = quads[q];
+			my_rank += (k[0] < my_key ? 1 : 0) + (k[1] < my_key ? 1 : 0) + (k[2] < my_key ? 1 : 0) + (k[3] < my_key ? 1 : 0);
 		}
 	}
 	__syncthreads(); // everybody is done reading s_unsorted (it aliases wave 0's scratch)
-	if (tid < n_smp) {
-		s_key[my_rank] = my_key;
-		s_idx[my_rank] = static_cast<uint16_t>(tid);
-	}
+	if (tid < n_smp) { s_key[my_rank] = my_key; }
 	__syncthreads();
 
 	RdWaveScratch& W = s_rd[wave];
 	for (int cut = wave + 1; cut <= 16; cut += kMaxSampledVectors) { // wave-uniform
 		const int rbw = P::kBits - cut;
-		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
+		rd_build_runs(W, nullptr, s_key, n_smp, cut, lane);
 		// histogram of run lengths; number of distinct left parts
 		int distinct = 0;
 		for (int b = 0; b < n_smp; b += 64) {
@@ -323,20 +355,13 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 		for (int top = n_smp; top >= 1 && taken < 8; top -= 64) {
 			const int      cval = top - lane;
 			const uint32_t h    = cval >= 1 ? W.hist[cval] : 0u;
-			uint32_t       inc  = h;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t t = __shfl_up(inc, d);
-				if (lane >= d) { inc += t; }
-			}
+			const uint32_t inc    = wave_scan_add_u32(h);
 			const uint32_t before = static_cast<uint32_t>(taken) + inc - h;
 			const uint32_t after  = static_cast<uint32_t>(taken) + inc;
 			const uint32_t mine   = (after < 8u ? after : 8u) - (before < 8u ? before : 8u);
-			uint32_t       part   = mine * static_cast<uint32_t>(cval > 0 ? cval : 0);
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) { part += __shfl_xor(part, d); }
-			covered += part;
-			taken += static_cast<int>(__shfl(inc, 63));
+			const uint32_t part   = wave_scan_add_u32(mine * static_cast<uint32_t>(cval > 0 ? cval : 0));
+			covered += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(part), 63));
+			taken += __builtin_amdgcn_readlane(static_cast<int>(inc), 63);
 		}
 		const uint32_t excs = static_cast<uint32_t>(n_smp) - covered;
 		const int      ds   = distinct < 8 ? distinct : 8;
@@ -361,10 +386,14 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	}
 	__syncthreads();
 	if (wave == 0) { // the dictionary of the chosen cut: the (<= 8) best-ranked runs
+		// (the other wavefronts are past their cut searches: their scratch now holds the order replay's arrays, which keeps the
+		//  workgroup's LDS small enough for six of them per CU — this single-wavefront tail then overlaps other rowgroups' searches)
+		static_assert(sizeof(RdOrderLds) <= (kMaxSampledVectors - 1) * sizeof(RdWaveScratch), "order replay arrays alias s_rd[1..]");
+		RdOrderLds& s_order = *reinterpret_cast<RdOrderLds*>(&s_rd[1]);
 		const int best_cut = s_best_cut;
 		const int rbw      = P::kBits - best_cut;
 		const int ds       = s_cut_ds[best_cut];
-		rd_build_runs(W, s_key, s_idx, n_smp, rbw, lane);
+		rd_build_runs(W, s_first, s_key, n_smp, best_cut, lane);
 		// distinct left parts in order of first occurrence in the sample, with their counts
 		// (run starts are compacted into s_order.sorted[] = first occurrence, so the order loop walks D runs, not 288 samples)
 		int distinct = 0;
@@ -372,18 +401,18 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 			const int      j    = b + lane;
 			const bool     head = j < n_smp && W.len[j] != 0;
 			const uint64_t hb   = __ballot(head);
-			if (head) { s_order.sorted[distinct + __builtin_popcountll(hb & ((1ull << lane) - 1ull))] = W.first[j]; }
+			if (head) { s_order.sorted[distinct + __builtin_popcountll(hb & ((1ull << lane) - 1ull))] = s_first[j]; }
 			distinct += __builtin_popcountll(hb);
 		}
 		wave_lds_sync();
 		for (int b = 0; b < n_smp; b += 64) {
 			const int      j   = b + lane;
 			const uint32_t L   = j < n_smp ? W.len[j] : 0u;
-			const uint32_t fo  = j < n_smp ? W.first[j] : 0u;
+			const uint32_t fo  = j < n_smp ? s_first[j] : 0u;
 			int            ord = 0;
 			for (int g = 0; g < distinct; ++g) { ord += s_order.sorted[g] < fo ? 1 : 0; } // broadcast reads
 			if (L != 0) {
-				s_order.okey[ord] = static_cast<uint32_t>(s_key[j] >> rbw);
+				s_order.okey[ord] = rd_left_of(s_key[j], best_cut);
 				s_order.ocnt[ord] = L;
 			}
 		}
