@@ -156,6 +156,17 @@ __device__ __forceinline__ int64_t encode_value_safe(double v, double exp10, dou
 	return cast64_x86(t);
 }
 
+// min / max of doubles that ignore a quiet NaN operand (IEEE minNum / maxNum, which is what the instructions compute)
+__device__ __forceinline__ double fmin_num(double a, double b) {
+	double d;
+	asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+__device__ __forceinline__ double fmax_num(double a, double b) {
+	double d;
+	asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
 // include/alp/encoder.hpp:91-106
 __device__ __forceinline__ int count_bits(int64_t mx, int64_t mn) {
 	const uint64_t d = static_cast<uint64_t>(mx) - static_cast<uint64_t>(mn);

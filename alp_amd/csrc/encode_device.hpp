@@ -53,17 +53,6 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src_lane) {
 // A wave-uniform lane mask (a ballot) as this lane's predicate: the SGPR pair is used directly as the select mask.
 __device__ __forceinline__ bool lane_in(uint64_t ballot) { return __builtin_amdgcn_inverse_ballot_w64(ballot); }
 
-// min / max of doubles that ignore a quiet NaN operand (IEEE minNum / maxNum, which is what the instructions compute)
-__device__ __forceinline__ double fmin_num(double a, double b) {
-	double d;
-	asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-	return d;
-}
-__device__ __forceinline__ double fmax_num(double a, double b) {
-	double d;
-	asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-	return d;
-}
 // cross-lane copy of a double by DPP (register to register); lanes without a valid source lane keep their own value
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double v) {

@@ -64,6 +64,49 @@ def adversarial_vectors():
     return cases
 
 
+def search_boundary_values():
+    """doubles on the decision boundaries of the (e,f) search's arithmetic: v * 10^e around 2^63 and 2^64 (the int64 product of
+    the decoder wraps there, the encoder switches to its sentinel), the values the sentinel 2^63 - 1024 decodes to, encoded
+    integers r with r * 10^f around 2^63, signed zeros and the smallest magnitudes.  Used one value per (constant) vector, so the
+    rowgroup state shows the first (e,f) candidate that round-trips it (or ALP_RD if none does)."""
+    import math
+    vals = [0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, math.inf, -math.inf, math.nan, 1.7976931348623157e308]
+    sentinel = 9223372036854774784.0
+    for e in range(19):
+        fe = float(f"1e-{e}")
+        for big in (sentinel, 2.0**63, 2.0**63 + 2048.0, 2.0**64, 2.0**64 - 2048.0, 2.0**62, 2.0**53, 2.0**51):
+            for base in (big * fe, big / 10.0**e):
+                x = base
+                vals += [x, -x]
+                up = dn = x
+                for _ in range(2):
+                    up, dn = math.nextafter(up, math.inf), math.nextafter(dn, -math.inf)
+                    vals += [up, dn, -up]
+        for f in range(e + 1):
+            for d in (-1, 0, 1):
+                r = (1 << 63) // 10**f + d
+                vals += [(r * 10**f) / 10**e, -(r * 10**f) / 10**e]
+        # half-integers between 2^51 and 2^52: negative ones survive the magic-number rounding with their half (t + M < 2^52)
+        for k2 in (2**52 + 1, 2**52 + 3, 2**53 - 1, 2**53 - 3, 3 * 2**51 + 1, 2**52 - 1, 2**53 + 2):  # k2 / 2 = the value of t aimed at
+            vals += [k2 / (2 * 10**e), -k2 / (2 * 10**e), (k2 / 2.0) * fe, -(k2 / 2.0) * fe]
+    out = np.array(vals, np.float64)
+    return out
+
+
+def search_boundary_mixtures(seed, n_vectors=4):
+    """vectors whose 32 sampled positions (every 32nd value) hold boundary values mixed with two-decimal values, so that the
+    candidates' exception counts and ranges — not just the first that fits — decide the rowgroup state"""
+    rng = np.random.default_rng(seed)
+    pool = search_boundary_values()
+    pool = pool[np.isfinite(pool)]
+    x = np.round(rng.uniform(-1000, 1000, n_vectors * VEC), 2)
+    for v in range(n_vectors):
+        k = int(rng.integers(1, 12))
+        pos = rng.choice(32, k, replace=False) * 32 + v * VEC
+        x[pos] = rng.choice(pool, k)
+    return x
+
+
 # ---- single precision (SURVEY.md §8(f) item 2) --------------------------------------------------------------------
 def decimal_column_f32(n_vectors, decimals=2, lo=0.0, hi=1000.0, seed=42):
     rng = np.random.default_rng(seed)

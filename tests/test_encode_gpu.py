@@ -282,3 +282,35 @@ def test_look_back_block_boundaries(ctx, oracle, n_vectors):
     w_rg, w_vec, w_packed, w_exc = layout.compact(want)
     assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
     assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc)
+
+
+def test_search_boundary_values_first_fitting_candidate(ctx, oracle):
+    """The (e,f) search keeps its arithmetic in doubles wherever that is provably the reference's result and falls back to the
+    literal int64 path on the two ambiguous boundaries (init_kernels.hip, PrecF64::step).  One constant sample set per boundary
+    value: the state then names the first candidate that round-trips the value, or ALP_RD when none does."""
+    from alp_amd import capi
+    vals = datagen.search_boundary_values()
+    vals = vals[np.unique(vals.view(np.uint64), return_index=True)[1]]
+    states = torch.zeros((vals.size, 32), dtype=torch.uint8, device="cuda")
+    smp = torch.from_numpy(np.repeat(vals, 32)).cuda()
+    for i in range(vals.size):
+        ctx.state_from_samples(smp[32 * i: 32 * i + 32], states[i])
+    ctx.synchronize()
+    got = states.cpu().numpy().reshape(-1).view(capi.ROWGROUP_DTYPE)
+    for i, v in enumerate(vals):
+        w_rg = layout.compact(oracle.encode_column(np.full(1024, v)))[0][0]
+        assert got["scheme"][i] == w_rg["scheme"], f"value {v!r}: scheme"
+        if w_rg["scheme"] == 2:
+            assert got["k"][i] == w_rg["k"] and np.array_equal(got["combos"][i], w_rg["combos"]), f"value {v!r}: {got['combos'][i]} != {w_rg['combos']}"
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_search_boundary_mixtures_whole_streams(ctx, oracle, seed):
+    col_np = datagen.search_boundary_mixtures(seed)
+    want = layout.compact(oracle.encode_column(col_np))
+    dcol, x = gpu_encode(ctx, col_np)
+    for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"seed {seed}: {what}"
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))

@@ -97,3 +97,25 @@ def test_fuzz_columns_oracle_equals_reference(oracle, ref, seed):
         a, b = of.encode_column(c), rf.encode_column(c)
         golden_io.assert_same_encoding(a, b, f"f32 seed {seed}", word=np.uint32)
         assert np.array_equal(of.decode_column(a).view(np.uint32), c.view(np.uint32))
+
+
+def _unique_bits(values):
+    return values[np.unique(values.view(np.uint64), return_index=True)[1]]
+
+
+def test_search_boundary_values_oracle_equals_reference(oracle, ref):
+    """one constant vector per boundary value of the (e,f) search (datagen.search_boundary_values): the rowgroup state shows
+    the first candidate that round-trips it; restatement against the real reference"""
+    vals = _unique_bits(datagen.search_boundary_values())
+    for i, v in enumerate(vals):
+        col = np.full(1024, v)
+        a, b = oracle.encode_column(col), ref.encode_column(col)
+        golden_io.assert_same_encoding(a, b, f"boundary value {i}: {v!r}")
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_search_boundary_mixtures_oracle_equals_reference(oracle, ref, seed):
+    col = datagen.search_boundary_mixtures(seed)
+    a, b = oracle.encode_column(col), ref.encode_column(col)
+    golden_io.assert_same_encoding(a, b, f"boundary mixture {seed}")
+    assert np.array_equal(oracle.decode_column(a).view(np.uint64), col.view(np.uint64))
