@@ -144,21 +144,23 @@ struct PrecF32 {
 	static __device__ __forceinline__ Coef coef(int e, int f) { return Coef {kExpArrF[e], kFracArrF[f], kFracArrF[e], kFactArrF[f]}; }
 	struct Acc {
 		int     non_exc;
-		int64_t mx, mn;
+		int32_t mx32, mn32;
+		int64_t mx, mn; // filled by finish()
 	};
 	static __device__ __forceinline__ void start(Acc& a) {
 		a.non_exc = 0;
-		a.mx = kEncMin, a.mn = kEncMax;
+		a.mx32 = INT32_MIN, a.mn32 = INT32_MAX;
 	}
+	// every operation of the float arithmetic is one instruction; kept free of branches (see PrecF64::step)
 	static __device__ __forceinline__ void step(Acc& a, float v, const Coef& c) {
-		const int32_t q = encode_value_f32(v, c.exp10, c.frac_f); // the SAFE branch does not exist as built (alp_device_f32.hpp)
-		if (decode_value_f32(q, c.fact, c.frac_e) == v) {
-			++a.non_exc;
-			a.mx = q > a.mx ? q : a.mx;
-			a.mn = q < a.mn ? q : a.mn;
-		}
+		const int32_t q  = encode_value_f32(v, c.exp10, c.frac_f); // the SAFE branch does not exist as built (alp_device_f32.hpp)
+		const bool    ok = decode_value_f32(q, c.fact, c.frac_e) == v;
+		a.non_exc += ok ? 1 : 0;
+		const int32_t hi = ok ? q : INT32_MIN, lo = ok ? q : INT32_MAX;
+		a.mx32 = hi > a.mx32 ? hi : a.mx32;
+		a.mn32 = lo < a.mn32 ? lo : a.mn32;
 	}
-	static __device__ __forceinline__ void finish(Acc&) {}
+	static __device__ __forceinline__ void finish(Acc& a) { a.mx = a.mx32, a.mn = a.mn32; }
 	static __device__ __forceinline__ int      bits(int64_t mx, int64_t mn) { return count_bits32(static_cast<int32_t>(mx), static_cast<int32_t>(mn)); }
 	static __device__ __forceinline__ uint64_t pattern(float v) { return static_cast<uint64_t>(__float_as_uint(v)); }
 };
