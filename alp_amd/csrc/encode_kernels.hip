@@ -384,6 +384,32 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	PackedUnits packed_units;
 	wave_lds_sync(); // this wavefront's staged values
 	pack_u64_units(L, d.bw, lane, packed_units);
+	// Likewise the exception record: its image is laid out in the (now free) staging area, so that after the wait it leaves as a
+	// few contiguous 8-byte-per-lane stores instead of two one-lane stores per exception step, and the input values need not
+	// stay in registers across the wait.  The values always fit (8 B x 1024); the positions follow them when the whole record
+	// fits (<= 819 exceptions; always for ALP_RD), else they are written from the ballots after the wait.  Pad bytes are zero.
+	const bool     alp_rec      = d.scheme == ALPGPU_SCHEME_ALP;
+	const uint32_t val_bytes    = alp_rec ? 8u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
+	const bool     pos_staged   = my_e <= sizeof(L.vals);
+	const uint32_t staged_bytes = pos_staged ? static_cast<uint32_t>(my_e) : val_bytes;
+	if (cnt > 0) {
+		uint8_t* img = reinterpret_cast<uint8_t*>(L.vals);
+		wave_lds_sync(); // the pack's reads of the staging area are issued; the LDS executes one wavefront's operations in order
+		if (lane == 0) { reinterpret_cast<uint64_t*>(img)[(staged_bytes >> 3) - 1] = 0ull; } // the pad lives in the last word
+		wave_lds_sync();
+		const int rbw = d.bw;
+		for_each_exception(ballots, lane, [&](int r, int m, int j) {
+			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
+			const uint16_t pos  = static_cast<uint16_t>(128 * m + 2 * lane + j);
+			if (alp_rec) {
+				reinterpret_cast<uint64_t*>(img)[r] = bits;
+			} else {
+				reinterpret_cast<uint16_t*>(img)[r] = static_cast<uint16_t>(bits >> rbw);
+			}
+			if (pos_staged) { reinterpret_cast<uint16_t*>(img + val_bytes)[r] = pos; }
+		});
+		wave_lds_sync();
+	}
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
 	{
 		uint32_t spins = 0;
@@ -415,19 +441,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	if (packed_capacity == 1) {
 #endif
 	if (cnt > 0) {
-		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
-		const int  rbw = d.bw;
-		for_each_exception(ballots, lane, [&](int r, int m, int j) {
-			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
-			const uint16_t pos  = static_cast<uint16_t>(128 * m + 2 * lane + j);
-			if (alp) {
-				reinterpret_cast<uint64_t*>(rec)[r]              = bits;
-				reinterpret_cast<uint16_t*>(rec + 8ull * cnt)[r] = pos;
-			} else {
-				reinterpret_cast<uint16_t*>(rec)[r]              = static_cast<uint16_t>(bits >> rbw);
-				reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
-			}
-		});
+		const uint64_t* img64 = reinterpret_cast<const uint64_t*>(L.vals);
+		uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
+		const int       n_w   = static_cast<int>(staged_bytes >> 3);
+		for (int w = lane; w < n_w; w += 64) { rec64[w] = img64[w]; }
+		if (!pos_staged) { // > 819 exceptions in an ALP vector: positions (and their pad) straight from the ballots
+			uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
+			for_each_exception(ballots, lane, [&](int r, int m, int j) { rpos[r] = static_cast<uint16_t>(128 * m + 2 * lane + j); });
+			const int n_pos = static_cast<int>((my_e - val_bytes) >> 1);
+			if (cnt + lane < n_pos) { rpos[cnt + lane] = 0; }
+		}
 	}
 	store_packed_units(packed_units, d.bw, reinterpret_cast<ull2v*>(dst), lane);
 	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 32) {
