@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 			const uint64_t lmask = (1ull << lbw) - 1ull;
 			d.bw = static_cast<uint8_t>(rbw), d.lbw = static_cast<uint8_t>(lbw);
 			const RdOrderView order = load_rd_order(rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, *rgp, lane);
+			uint32_t dict[8]; // read once: left inside the loop, the compiler re-reads the dictionary from memory for every value
+#pragma unroll
+			for (int dd = 0; dd < 8; ++dd) { dict[dd] = rgp->rd_dict[dd]; }
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				u32x4     q;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 					int            idx  = ds;
 #pragma unroll
 					for (int dd = 7; dd >= 0; --dd) {
-						if (dd < ds && rgp->rd_dict[dd] == left) { idx = dd; }
+						if (dd < ds && dict[dd] == left) { idx = dd; }
 					}
 					const bool exc = idx == ds;
 					ballots[m][j]  = __ballot(exc);
@@ -147,6 +150,31 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	PackedUnitsF32 packed_units;
 	wave_lds_sync();
 	pack_u32_units(L, d.bw, lane, packed_units);
+	// the exception record's image goes to the (now free) staging area and leaves as contiguous stores after the wait, see
+	// k_encode_fused: values always fit (4 B x 1024), the positions follow them when the whole record does (<= 682 exceptions;
+	// always for ALP_RD), else they are written from the ballots after the wait.  Pad bytes are zero.
+	const bool     alp_rec      = d.scheme == ALPGPU_SCHEME_ALP;
+	const uint32_t val_bytes    = alp_rec ? 4u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
+	const bool     pos_staged   = my_e <= sizeof(L.vals);
+	const uint32_t staged_bytes = pos_staged ? static_cast<uint32_t>(my_e) : val_bytes;
+	if (cnt > 0) {
+		uint8_t* img = reinterpret_cast<uint8_t*>(L.vals);
+		wave_lds_sync(); // the pack's reads are issued; one wavefront's LDS operations execute in order
+		if (pos_staged && lane == 0) { reinterpret_cast<uint64_t*>(img)[(staged_bytes >> 3) - 1] = 0ull; } // the pad lives in the last word
+		wave_lds_sync();
+		const int rbw = d.bw;
+		for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
+			const uint32_t bits = __float_as_uint(x.x[m][j]);
+			const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
+			if (alp_rec) {
+				reinterpret_cast<uint32_t*>(img)[r] = bits;
+			} else {
+				reinterpret_cast<uint16_t*>(img)[r] = static_cast<uint16_t>(bits >> rbw);
+			}
+			if (pos_staged) { reinterpret_cast<uint16_t*>(img + val_bytes)[r] = pos; }
+		});
+		wave_lds_sync();
+	}
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
 	{
 		uint32_t spins = 0;
@@ -173,19 +201,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
 	if (cnt > 0) {
-		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
-		const int  rbw = d.bw;
-		for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
-			const uint32_t bits = __float_as_uint(x.x[m][j]);
-			const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
-			if (alp) {
-				reinterpret_cast<uint32_t*>(rec)[r]              = bits;
-				reinterpret_cast<uint16_t*>(rec + 4ull * cnt)[r] = pos;
-			} else {
-				reinterpret_cast<uint16_t*>(rec)[r]              = static_cast<uint16_t>(bits >> rbw);
-				reinterpret_cast<uint16_t*>(rec + 2ull * cnt)[r] = pos;
-			}
-		});
+		const uint32_t* img32 = reinterpret_cast<const uint32_t*>(L.vals);
+		uint32_t*       rec32 = reinterpret_cast<uint32_t*>(rec);
+		const int       n_w   = static_cast<int>(staged_bytes >> 2);
+		for (int w = lane; w < n_w; w += 64) { rec32[w] = img32[w]; }
+		if (!pos_staged) { // > 682 exceptions in an ALP vector: positions (and their pad) straight from the ballots
+			uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
+			for_each_exception_f32(ballots, lane, [&](int r, int m, int j) { rpos[r] = static_cast<uint16_t>(256 * m + 4 * lane + j); });
+			const int n_pos = static_cast<int>((my_e - val_bytes) >> 1);
+			if (cnt + lane < n_pos) { rpos[cnt + lane] = 0; }
+		}
 	}
 	store_packed_units_f32(packed_units, d.bw, reinterpret_cast<u32x4*>(dst), lane);
 	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 16) {

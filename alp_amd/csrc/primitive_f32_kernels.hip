@@ -201,6 +201,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_rd_encode_f32(const float*
 		u32x4*                       rdst  = reinterpret_cast<u32x4*>(right + v * kVec);
 		uint64_t*                    ldst  = reinterpret_cast<uint64_t*>(left + v * kVec);
 		int                          soff  = 0;
+		uint32_t                     dict[8]; // read once (see k_encode_fused_f32)
+#pragma unroll
+		for (int dd = 0; dd < 8; ++dd) { dict[dd] = rgp->rd_dict[dd]; }
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
 			u32x4    q;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_rd_encode_f32(const float*
 				int            idx  = ds;
 #pragma unroll
 				for (int dd = 7; dd >= 0; --dd) {
-					if (dd < ds && rgp->rd_dict[dd] == l) { idx = dd; }
+					if (dd < ds && dict[dd] == l) { idx = dd; }
 				}
 				lw |= static_cast<uint64_t>(idx) << (16 * j);
 				bal[j] = __ballot(idx == ds);
