@@ -119,6 +119,30 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t x) {
 	return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
+// The 32-byte rowgroup state, fetched ONCE per wavefront: one 32-byte read (lane i < 8 takes word i), then register moves.
+// Read field by field from memory, the state cost the encode kernels a chain of dependent one-byte vector loads (scheme, then k,
+// then the candidates ...), each a full memory round trip in front of the arithmetic.  The copy must only ever be indexed with
+// compile-time constants (it lives in registers).
+__device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state(const alpgpu_rowgroup_state* __restrict__ p, int lane) {
+	static_assert(sizeof(alpgpu_rowgroup_state) == 32, "eight words");
+	const uint32_t mine = reinterpret_cast<const uint32_t*>(p)[lane & 7];
+	uint32_t       w[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { w[i] = __builtin_amdgcn_readlane(mine, i); }
+	alpgpu_rowgroup_state s;
+	s.scheme = static_cast<uint8_t>(w[0]);
+	s.k      = static_cast<uint8_t>(w[0] >> 8);
+#pragma unroll
+	for (int i = 0; i < 10; ++i) { s.combos[i] = static_cast<uint8_t>(w[(2 + i) >> 2] >> (8 * ((2 + i) & 3))); }
+	s.rd_rbw       = static_cast<uint8_t>(w[3]);
+	s.rd_lbw       = static_cast<uint8_t>(w[3] >> 8);
+	s.rd_dict_size = static_cast<uint8_t>(w[3] >> 16);
+	s.pad          = static_cast<uint8_t>(w[3] >> 24);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { s.rd_dict[i] = static_cast<uint16_t>(w[4 + (i >> 1)] >> (16 * (i & 1))); }
+	return s;
+}
+
 // ---- scalar codec arithmetic --------------------------------------------------
 
 // static_cast<int64_t>(double) with x86-64 semantics (cvttsd2si): NaN / |x| >= 2^63 -> INT64_MIN.

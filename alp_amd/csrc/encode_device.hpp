@@ -112,11 +112,12 @@ __device__ __forceinline__ void second_level_select(const VecIn& in, const alpgp
 #pragma unroll
 	for (int kk = 0; kk < 6; kk += 2) {
 		if (kk < k) { // wave-uniform
-			const int  c     = kk + half;
-			const bool valid = c < k;
-			const int  cc    = valid ? c : 0;
-			const int  e     = rgp->combos[2 * cc];
-			const int  f     = rgp->combos[2 * cc + 1];
+			// candidate kk for the low half-wave, kk + 1 for the high one (candidate 0 again if there is none); rgp may be a
+			// register copy of the state: constant indices only
+			const int     kHi   = kk + 1 < 5 ? kk + 1 : 0; // a constant once the loop is unrolled
+			const bool    hi_ok = half != 0 && kk + 1 < k;
+			const int     e     = hi_ok ? rgp->combos[2 * kHi] : (half != 0 ? rgp->combos[0] : rgp->combos[2 * kk]);
+			const int     f     = hi_ok ? rgp->combos[2 * kHi + 1] : (half != 0 ? rgp->combos[1] : rgp->combos[2 * kk + 1]);
 			const int64_t enc = encode_value_safe(sv, kExpArr[e], kFracArr[f]);
 			const double  dec = decode_value(enc, kFactArr[f], kFracArr[e]);
 			const bool    ok  = dec == sv;
@@ -156,8 +157,13 @@ __device__ __forceinline__ void second_level_select(const VecIn& in, const alpgp
 			}
 		}
 	}
-	e_out = rgp->combos[2 * best];
-	f_out = rgp->combos[2 * best + 1];
+	e_out = rgp->combos[0];
+	f_out = rgp->combos[1];
+#pragma unroll
+	for (int i = 1; i < 5; ++i) {
+		e_out = best == i ? rgp->combos[2 * i] : e_out;
+		f_out = best == i ? rgp->combos[2 * i + 1] : f_out;
+	}
 	wave_lds_sync();
 }
 

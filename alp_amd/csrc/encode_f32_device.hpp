@@ -54,10 +54,12 @@ __device__ __forceinline__ void second_level_select_f32(const VecInF& in, const 
 #pragma unroll
 	for (int kk = 0; kk < 6; kk += 2) {
 		if (kk < k) { // wave-uniform
-			const int      c     = kk + half;
-			const int      cc    = c < k ? c : 0;
-			const int      e     = rgp->combos[2 * cc];
-			const int      f     = rgp->combos[2 * cc + 1];
+			// candidate kk for the low half-wave, kk + 1 for the high one (candidate 0 again if there is none); rgp may be a
+			// register copy of the state: constant indices only
+			const int      kHi   = kk + 1 < 5 ? kk + 1 : 0; // a constant once the loop is unrolled
+			const bool     hi_ok = half != 0 && kk + 1 < k;
+			const int      e     = hi_ok ? rgp->combos[2 * kHi] : (half != 0 ? rgp->combos[0] : rgp->combos[2 * kk]);
+			const int      f     = hi_ok ? rgp->combos[2 * kHi + 1] : (half != 0 ? rgp->combos[1] : rgp->combos[2 * kk + 1]);
 			const int32_t  enc   = encode_value_f32(sv, kExpArrF[e], kFracArrF[f]);
 			const float    dec   = decode_value_f32(enc, kFactArrF[f], kFracArrF[e]);
 			const bool     ok    = dec == sv;
@@ -92,8 +94,13 @@ __device__ __forceinline__ void second_level_select_f32(const VecInF& in, const 
 			}
 		}
 	}
-	e_out = rgp->combos[2 * best];
-	f_out = rgp->combos[2 * best + 1];
+	e_out = rgp->combos[0];
+	f_out = rgp->combos[1];
+#pragma unroll
+	for (int i = 1; i < 5; ++i) {
+		e_out = best == i ? rgp->combos[2 * i] : e_out;
+		f_out = best == i ? rgp->combos[2 * i + 1] : f_out;
+	}
 	wave_lds_sync();
 }
 

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	d.base                   = 0;
 	d.bw = d.e = d.f = d.lbw = 0;
 	d.exc_cnt = d.scheme = 0;
-	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
+	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane); // once, into registers
+	const alpgpu_rowgroup_state* rgp = &st;
 	if (live) {
 		x        = load_vector_f32(in, v, lane);
 		d.scheme = rgp->scheme;

@@ -310,7 +310,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	d.base                   = 0;
 	d.bw = d.e = d.f = d.lbw = 0;
 	d.exc_cnt = d.scheme = 0;
-	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
+	// the rowgroup's state, once, into registers (alp_device.hpp); its read is in flight together with the input's
+	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane);
+	const alpgpu_rowgroup_state* rgp = &st;
 #ifdef ALPGPU_FUSED_TIMING
 	unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif

@@ -34,7 +34,9 @@ __device__ __forceinline__ RdOrderView load_rd_order(const uint16_t* __restrict_
 		if (i < D) { V.keys[k] = order_rg[1 + i]; }
 	}
 	// the table must belong to this state: its first entries are the dictionary
-	const uint32_t mine = lane < 8 ? rg.rd_dict[lane] : 0u;
+	uint32_t mine = 0u; // rg may be a register copy of the state: constant indices only
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { mine = lane == i ? rg.rd_dict[i] : mine; }
 	const bool     bad  = lane < V.ds && V.keys[0] != mine;
 	V.count = D;
 	V.valid = __ballot(bad) == 0;
