@@ -62,6 +62,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	d.exc_cnt = d.scheme = 0;
 	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane); // once, into registers
 	const alpgpu_rowgroup_state* rgp = &st;
+	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
+	// that nothing but the ordered offset stands between the wait and the stores
+	const uint64_t base_p = totals[0], base_e = totals[1];
 	if (live) {
 		x        = load_vector_f32(in, v, lane);
 		d.scheme = rgp->scheme;
@@ -190,7 +193,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	const uint64_t excl = s_excl;
 	if (excl == ~0ull) { return; }
 
-	const uint64_t base_p = totals[0], base_e = totals[1];
 	const uint64_t pre    = excl + local;
 	d.packed_off          = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
 	d.exc_off             = base_e + (pre & 0x7FFFFFFFull) * 8ull;

@@ -313,6 +313,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	// the rowgroup's state, once, into registers (alp_device.hpp); its read is in flight together with the input's
 	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane);
 	const alpgpu_rowgroup_state* rgp = &st;
+	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
+	// that nothing but the ordered offset stands between the wait and the stores
+	const uint64_t base_p = totals[0], base_e = totals[1];
 #ifdef ALPGPU_FUSED_TIMING
 	unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
@@ -428,7 +431,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	if (excl == ~0ull) { return; } // stalled: nothing of this tile is written
 
 	// ---- 4. write at the final offsets ----
-	const uint64_t base_p = totals[0], base_e = totals[1]; // bytes used by earlier launches of this column
 	const uint64_t pre    = excl + local;
 	d.packed_off          = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
 	d.exc_off             = base_e + (pre & 0x7FFFFFFFull) * 8ull;

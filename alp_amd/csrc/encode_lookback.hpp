@@ -66,7 +66,8 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	const bool     closes  = i == kBlockTiles - 1 || tile == gridDim.x - 1; // this tile completes its block
 	bool           stalled = false;
 	uint32_t       spins   = 0;
-	auto give_up = [&]() { return ++spins > kSpinLimit || status_load(totals + 3) != 0; };
+	// the stall flag of another tile is a far-side read like the status words: looked at every 16th unsuccessful round only
+	auto give_up = [&]() { return ++spins > kSpinLimit || ((spins & 15u) == 0 && status_load(totals + 3) != 0); };
 #ifdef ALPGPU_ABLATE_LOOKBACK // timing experiment: worst-case strides instead of the scan (the output is NOT compact)
 	if (lane == 0) {
 		*s_excl = status_pack(0, tile * N_SIZES * 66, tile * N_SIZES * 1280);
