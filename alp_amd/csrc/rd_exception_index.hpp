@@ -26,12 +26,18 @@ __device__ __forceinline__ RdOrderView load_rd_order(const uint16_t* __restrict_
 #pragma unroll
 	for (int k = 0; k < 5; ++k) { V.keys[k] = 0xFFFFFFFFu; }
 	if (order_rg == nullptr) { return V; }
+	// count and entries are read together (the table's stride covers 1 + 288 entries whatever the count): one round trip
+	uint32_t  raw[5];
 	const int D = order_rg[0];
-	if (D < V.ds || D > 288) { return V; }
 #pragma unroll
 	for (int k = 0; k < 5; ++k) {
 		const int i = 64 * k + lane;
-		if (i < D) { V.keys[k] = order_rg[1 + i]; }
+		raw[k]      = i < 288 ? order_rg[1 + i] : 0xFFFFu;
+	}
+	if (D < V.ds || D > 288) { return V; }
+#pragma unroll
+	for (int k = 0; k < 5; ++k) {
+		if (64 * k + lane < D) { V.keys[k] = raw[k]; }
 	}
 	// the table must belong to this state: its first entries are the dictionary
 	uint32_t mine = 0u; // rg may be a register copy of the state: constant indices only
