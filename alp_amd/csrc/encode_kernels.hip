@@ -263,10 +263,12 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 // wavefronts = kWavesPerWg consecutive vectors
 //   1. encodes its vectors (registers -> LDS), knows their sizes,
 //   2. publishes the tile's size as ONE 64-bit status word {flag | packed 128-B units | exception 8-B units},
-//   3. packs every vector into registers (the packed words do not depend on where they go),
+//   3. packs every vector into registers and lays out its exception record in LDS (neither depends on where it will go),
 //   4. wavefront 0 finds the tile's exclusive prefix with the two-level look-back of encode_lookback.hpp and hands it to the
 //      other wavefronts through LDS words (no workgroup barrier is involved),
-//   5. every wavefront stores its packed words / exception record / descriptor at the now-known offsets.
+//   5. every wavefront stores its packed words / exception record / descriptor at the now-known offsets: contiguous stores only.
+// A wavefront's life is a chain of dependent memory round trips (~1 us each under this streaming load), not arithmetic: the
+// rowgroup state and the column's running totals are therefore read once, up front, next to the input.
 // Offsets are therefore the same vector-order exclusive scan as in the two-pass form: the output is byte-identical.
 // Status words are written with one agent-scope relaxed atomic store (the data IS the flag) and polled with agent-scope
 // relaxed atomic loads (cdna_hip_programming.md §6 G16, recipe R2).  Forward progress needs the predecessor tiles to be
