@@ -22,7 +22,7 @@ def main():
     f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as w:
-        w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-extras\n")
+        w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- " + os.environ.get("PROF_CMD", "python bench.py --steps 10 --warmup 2 --no-extras") + "\n")
         w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
         for r in rows:
             w.write(",".join([json.dumps(short(r["Name"]))] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
