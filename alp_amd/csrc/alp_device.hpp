@@ -24,6 +24,12 @@ constexpr int kRowgroup   = 100;
 #define ALPGPU_WAVES_PER_WG 4
 #endif
 constexpr int kWavesPerWg = ALPGPU_WAVES_PER_WG; // wavefronts (= vectors) per workgroup of the wave-per-vector kernels
+// The single-pass encode kernels use tiles of 8 vectors: half as many tiles to order as with 4 (3.24 against 3.49 ms per 1 Mi
+// vectors; 2: 4.56, 3: 3.82, 6: 4.22, 16: 4.03 — measured at 95 VGPRs, where two such workgroups fit a CU)
+#ifndef ALPGPU_FUSED_WAVES
+#define ALPGPU_FUSED_WAVES 8
+#endif
+constexpr int kFusedWaves = ALPGPU_FUSED_WAVES; // wavefronts (= vectors) per tile of k_encode_fused / k_encode_fused_f32
 
 // ---- constants (reference include/alp/constants.hpp:66-154): bit-identical tables --------------------
 __device__ __constant__ const double kFracArr[21] = {

@@ -28,13 +28,13 @@ __device__ __forceinline__ void desc_sizes_f32(const alpgpu_vector_desc& d, uint
 	}
 }
 
-__global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+__global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                        uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                        uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
                                                                        uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order) {
-	__shared__ EncodeLdsF32 lds[kWavesPerWg];
-	__shared__ uint64_t     s_size[kWavesPerWg];
+	__shared__ EncodeLdsF32 lds[kFusedWaves];
+	__shared__ uint64_t     s_size[kFusedWaves];
 	__shared__ uint64_t     s_excl;
 	__shared__ uint32_t     s_count;
 	__shared__ uint32_t     s_ready;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	__syncthreads();
 
 	EncodeLdsF32&  L    = lds[wave];
-	const uint64_t vl   = tile * kWavesPerWg + wave;
+	const uint64_t vl   = tile * kFusedWaves + wave;
 	const bool     live = vl < n_vectors_launch;
 	const uint64_t v    = v_first + vl;
 	VecInF             x;
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	if (lane == 0) {
 		s_size[wave]           = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (arrived == kWavesPerWg - 1) {
+		if (arrived == kFusedWaves - 1) {
 			uint64_t aggregate = 0;
 #pragma unroll
-			for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+			for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
 			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused_f32(const flo
 	}
 	uint64_t local = 0;
 #pragma unroll
-	for (int w = 0; w < kWavesPerWg; ++w) { local += w < wave ? s_size[w] : 0; }
+	for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
 	const uint64_t excl = s_excl;
 	if (excl == ~0ull) { return; }
 
@@ -237,9 +237,9 @@ int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const a
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
-		const uint64_t n_tiles  = (n_launch + kWavesPerWg - 1) / kWavesPerWg;
+		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-		hipLaunchKernelGGL(k_encode_fused_f32, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
+		hipLaunchKernelGGL(k_encode_fused_f32, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
 		                   n_launch, col->d_rd_order);
 		hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(1), 0, stream, col->d_totals);

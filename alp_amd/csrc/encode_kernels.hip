@@ -259,8 +259,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 }
 
 // ---- single pass: analysis, ordered offsets (decoupled look-back) and pack in ONE kernel -------------------------------
-// The two-pass form above reads the input twice and does the encode arithmetic twice.  Here a workgroup (tile) of kWavesPerWg
-// wavefronts = kWavesPerWg consecutive vectors
+// The two-pass form above reads the input twice and does the encode arithmetic twice.  Here a workgroup (tile) of kFusedWaves
+// wavefronts = kFusedWaves consecutive vectors
 //   1. encodes its vectors (registers -> LDS), knows their sizes,
 //   2. publishes the tile's size as ONE 64-bit status word {flag | packed 128-B units | exception 8-B units},
 //   3. packs every vector into registers and lays out its exception record in LDS (neither depends on where it will go),
@@ -276,15 +276,15 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 // every spin is bounded, and a stall sets totals[3] (reported as ALPGPU_ERR_HIP by alpgpu_column_totals; the two-pass
 // form is selectable with ALPGPU_OPT_ENCODE_TWO_PASS).  The field widths bound one launch to kFusedMaxVectors vectors;
 // longer columns are chained launch by launch through totals[0..1].  Where a wavefront's time goes: profiles/r01_fused_phases.txt.
-__global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double* __restrict__ in,
+__global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double* __restrict__ in,
                                                                    const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                    alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                    uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                    uint64_t* __restrict__ totals, uint64_t packed_capacity,
                                                                    uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch,
                                                                    const uint16_t* __restrict__ rd_order) {
-	__shared__ EncodeLds lds[kWavesPerWg];
-	__shared__ uint64_t  s_size[kWavesPerWg]; // per vector: (packed units << 31) | exception units
+	__shared__ EncodeLds lds[kFusedWaves];
+	__shared__ uint64_t  s_size[kFusedWaves]; // per vector: (packed units << 31) | exception units
 	__shared__ uint64_t  s_excl;              // tile's exclusive prefix in the same packing, or ~0 on a stall
 	__shared__ uint32_t  s_count;             // worker wavefronts that have posted their size
 	__shared__ uint32_t  s_ready;             // set by the scout once s_excl is valid
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 
 	// ---- the workers: one vector each -------------------------------------------------------------------------------
 	EncodeLds&     L    = lds[wave];
-	const uint64_t vl   = tile * kWavesPerWg + wave; // vector index inside this launch
+	const uint64_t vl   = tile * kFusedWaves + wave; // vector index inside this launch
 	const bool     live = vl < n_vectors_launch;
 	const uint64_t v    = v_first + vl;
 	// ---- 1. encode into registers / LDS ----
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	if (lane == 0) {
 		s_size[wave] = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (arrived == kWavesPerWg - 1) {
+		if (arrived == kFusedWaves - 1) {
 			uint64_t aggregate = 0;
 #pragma unroll
-			for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+			for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
 			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_fused(const double*
 	ALPGPU_PHASE_MARK(2); // ordered offset: look-back (wave 0) / wait for it (others)
 	uint64_t local = 0;
 #pragma unroll
-	for (int w = 0; w < kWavesPerWg; ++w) { local += w < wave ? s_size[w] : 0; }
+	for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
 	const uint64_t excl = s_excl;
 	if (excl == ~0ull) { return; } // stalled: nothing of this tile is written
 
@@ -503,7 +503,7 @@ static unsigned grid_for(uint64_t n_vectors, int n_cus, int wgs_per_cu) {
 uint64_t encode_workspace_bytes(uint64_t n_vectors) {
 	const uint64_t two_pass = ((n_vectors + kScanTile - 1) / kScanTile) * 16 + 16;
 	const uint64_t per_launch = n_vectors < kFusedMaxVectors ? n_vectors : kFusedMaxVectors;
-	const uint64_t fused    = lookback_words((per_launch + kWavesPerWg - 1) / kWavesPerWg) * 8 + 64;
+	const uint64_t fused    = lookback_words((per_launch + kFusedWaves - 1) / kFusedWaves) * 8 + 64;
 	return two_pass > fused ? two_pass : fused;
 }
 
@@ -517,9 +517,9 @@ int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpg
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
-		const uint64_t n_tiles  = (n_launch + kWavesPerWg - 1) / kWavesPerWg;
+		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kWavesPerWg), 0, stream, d_in, col->d_rowgroups,
+		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
 		                   n_launch, col->d_rd_order);
 		hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, stream, col->d_totals);

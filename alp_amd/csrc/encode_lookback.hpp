@@ -56,8 +56,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 // status: [gridDim.x] tile words followed by [ceil(gridDim.x / kBlockTiles)] block words, all zero at launch.
-// N_SIZES = vectors per tile (entries of s_size); s_count counts the tile's kWavesPerWg wavefronts.
-template <int N_SIZES = kWavesPerWg>
+// N_SIZES = vectors per tile (entries of s_size); s_count counts the tile's kFusedWaves wavefronts.
+template <int N_SIZES = kFusedWaves>
 __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
                                               uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
 	uint64_t*      bstatus = status + gridDim.x;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	uint64_t aggregate = 0;
 	if (closes && !stalled) {
 		uint32_t lspins = 0;
-		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kWavesPerWg) {
+		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kFusedWaves) {
 			if (++lspins > kSpinLimit) {
 				stalled = true;
 				break;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	// the other wavefronts add up the sizes posted before theirs once released: every one of them must have posted (LDS only)
 	if (!closes && !stalled) {
 		uint32_t lspins = 0;
-		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kWavesPerWg) {
+		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kFusedWaves) {
 			if (++lspins > kSpinLimit) {
 				stalled = true;
 				break;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void tile_lookback_flat(uint64_t tile, uint64_t* __re
 		uint64_t  excl      = 0;
 		bool      stalled   = false;
 #ifdef ALPGPU_FUSED_NO_LOOKBACK // timing experiment only: worst-case strides instead of the scan (output is NOT compact)
-		excl = status_pack(0, tile * kWavesPerWg * 66, tile * kWavesPerWg * 1280);
+		excl = status_pack(0, tile * kFusedWaves * 66, tile * kFusedWaves * 1280);
 		if (false) {
 #else
 		if (tile != 0) {
@@ -261,7 +261,7 @@ __device__ __forceinline__ void tile_lookback_flat(uint64_t tile, uint64_t* __re
 		}
 		// the tile's own aggregate: wait (LDS only) until every worker has posted its size
 		uint32_t spins = 0;
-		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kWavesPerWg) {
+		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kFusedWaves) {
 			if (++spins > kSpinLimit) {
 				stalled = true;
 				break;
@@ -270,7 +270,7 @@ __device__ __forceinline__ void tile_lookback_flat(uint64_t tile, uint64_t* __re
 		}
 		uint64_t aggregate = 0;
 #pragma unroll
-		for (int w = 0; w < kWavesPerWg; ++w) { aggregate += s_size[w]; }
+		for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
 		if (lane == 0) {
 			if (stalled) {
 				__hip_atomic_store(totals + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
