@@ -106,12 +106,34 @@ __device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgp
 	}
 }
 
+// the ALP_RD dictionary of a vector's rowgroup, read next to the packed words (see decode_kernels.hip: RdDict)
+struct RdDictF {
+	uint64_t lo, hi;
+};
+__device__ __forceinline__ RdDictF load_rd_dict_f32(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, bool is_rd) {
+	RdDictF dict {0ull, 0ull};
+	if (is_rd) { // wave-uniform
+		static_assert(offsetof(alpgpu_rowgroup_state, rd_dict) == 16, "dictionary = second half of the state");
+		const uint32_t  rg = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v / kRowgroup));
+		const uint64_t* dp = reinterpret_cast<const uint64_t*>(rgs + rg) + 2;
+		dict.lo            = dp[0];
+		dict.hi            = dp[1];
+	}
+	return dict;
+}
+
+// ALP vectors use the same two words for their decode constants: lo = FACT_ARR[f], hi = bits of FRAC_ARR[e]
+__device__ __forceinline__ RdDictF load_vector_consts_f32(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
+	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict_f32(rgs, v, true); } // wave-uniform
+	return RdDictF {static_cast<uint64_t>(kFactArrF[d.f]), static_cast<uint64_t>(__float_as_uint(kFracArrF[d.e]))};
+}
+
 // one vector, after its packed words / exception mask are visible in L; thread tid owns values 4*tid .. 4*tid+3
 // SINK (as in decode_kernels.hip) = kSinkStoreF: the quad is stored.  kSinkSumF: its four values are widened to double
 // (exact) and added to `acc` in index order.  kSinkCountF: `acc` counts the values v with lo <= v <= hi (NaN never does).
 constexpr int kSinkStoreF = 0, kSinkSumF = 1, kSinkCountF = 2;
 template <bool NT_STORE, int SINK = kSinkStoreF>
-__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
+__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const RdDictF& dict,
                                                          const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane,
                                                          double* acc = nullptr, float range_lo = 0.0f, float range_hi = 0.0f) {
 	const int    bw    = d.bw;
@@ -133,8 +155,8 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 	u32x4 out;
 	if (d.scheme == ALPGPU_SCHEME_ALP) {
 		const uint32_t base = static_cast<uint32_t>(d.base);
-		const uint32_t fact = kFactArrF[d.f];
-		const float    frac = kFracArrF[d.e];
+		const uint32_t fact = static_cast<uint32_t>(dict.lo);
+		const float    frac = __uint_as_float(static_cast<uint32_t>(dict.hi));
 		const u32x4    q    = unpack_quad_u32(units, bw, bw_mask32(bw), row, a);
 #pragma unroll
 		for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint(decode_value_f32(static_cast<int32_t>(q[c] + base), fact, frac)); }
@@ -154,10 +176,7 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 		const int      rbw  = bw;
 		const int      lbw  = d.lbw;
 		const uint32_t lmsk = (1u << lbw) - 1u;
-		const uint64_t dlo = static_cast<uint64_t>(rgp->rd_dict[0]) | (static_cast<uint64_t>(rgp->rd_dict[1]) << 16) |
-		                     (static_cast<uint64_t>(rgp->rd_dict[2]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[3]) << 48);
-		const uint64_t dhi = static_cast<uint64_t>(rgp->rd_dict[4]) | (static_cast<uint64_t>(rgp->rd_dict[5]) << 16) |
-		                     (static_cast<uint64_t>(rgp->rd_dict[6]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[7]) << 48);
+		const uint64_t dlo = dict.lo, dhi = dict.hi;
 		const u32x4     q    = unpack_quad_u32(units, rbw, bw_mask32(rbw), row, a);
 		const uint64_t* lsrc = reinterpret_cast<const uint64_t*>(L.stage + 128 * rbw);
 		const int       p    = (tid >> 4) * lbw;
@@ -214,6 +233,9 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // tail vectors of the last workgroup are simply loaded again
 		d[i]             = descs[v];
 	}
+	RdDictF dict[V];
+#pragma unroll
+	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts_f32(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
 #pragma unroll
 	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads_f32(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
 #pragma unroll
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 		for (int i = 0; i < V; ++i) {
 			double acc = 0.0;
 			if (v0 + i < n_vectors) {
-				decode_staged_vector_f32<NT_STORE, SINK>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, nullptr, tid, wave, lane, &acc, range_lo,
+				decode_staged_vector_f32<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, tid, wave, lane, &acc, range_lo,
 				                                         range_hi);
 			}
 #pragma unroll
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {
-			decode_staged_vector_f32<NT_STORE>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, out + (v0 + i) * kVec, tid, wave, lane);
+			decode_staged_vector_f32<NT_STORE>(L[i], d[i], dict[i], excs + d[i].exc_off, out + (v0 + i) * kVec, tid, wave, lane);
 		}
 	}
 }

@@ -126,8 +126,33 @@ __device__ __forceinline__ void consume_pair(double ox, double oy, double* acc, 
 	}
 }
 
+// The ALP_RD dictionary of a vector's rowgroup (eight u16 entries = bytes 16..31 of the state) as two words.  It is read right
+// after the descriptor, together with the packed words — read inside the decode it was a third dependent round trip, behind the
+// barrier, for every ALP_RD vector.
+struct RdDict {
+	uint64_t lo, hi;
+};
+__device__ __forceinline__ RdDict load_rd_dict(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, bool is_rd) {
+	RdDict dict {0ull, 0ull};
+	if (is_rd) { // wave-uniform
+		static_assert(offsetof(alpgpu_rowgroup_state, rd_dict) == 16, "dictionary = second half of the state");
+		const uint32_t  rg = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v / kRowgroup));
+		const uint64_t* dp = reinterpret_cast<const uint64_t*>(rgs + rg) + 2;
+		dict.lo            = dp[0];
+		dict.hi            = dp[1];
+	}
+	return dict;
+}
+
+// ALP vectors use the same two words for their decode constants: lo = FACT_ARR[f], hi = bits of FRAC_ARR[e] — table reads that
+// depend only on the descriptor and likewise belong in front of the barrier.
+__device__ __forceinline__ RdDict load_vector_consts(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
+	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict(rgs, v, true); } // wave-uniform
+	return RdDict {static_cast<uint64_t>(kFactArr[d.f]), static_cast<uint64_t>(__double_as_longlong(kFracArr[d.e]))};
+}
+
 template <bool NT_STORE, int SINK = kSinkStore>
-__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const alpgpu_rowgroup_state* __restrict__ rgp,
+__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const RdDict& dict,
                                                      const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
                                                      double range_lo = 0.0, double range_hi = 0.0) {
 	const int      bw       = d.bw;
@@ -139,8 +164,8 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 	const UnitsPtr units {reinterpret_cast<const ulonglong2*>(L.stage)};
 	if (d.scheme == ALPGPU_SCHEME_ALP) {
 		const uint64_t base = static_cast<uint64_t>(d.base);
-		const int64_t  fact = kFactArr[d.f];
-		const double   frac = kFracArr[d.e];
+		const int64_t  fact = static_cast<int64_t>(dict.lo);
+		const double   frac = __longlong_as_double(static_cast<long long>(dict.hi));
 		const uint64_t mask = bw_mask(bw);
 		// Conversion shortcut, decided once per vector from its descriptor.  If every value base + digit of this vector
 		// lies in (-2^51, 2^51) and times 10^f stays inside int64, then
@@ -190,10 +215,7 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 		const int      lbw  = d.lbw;
 		const uint64_t mask = bw_mask(rbw);
 		const uint32_t lmsk = (1u << lbw) - 1u;
-		const uint64_t dlo = static_cast<uint64_t>(rgp->rd_dict[0]) | (static_cast<uint64_t>(rgp->rd_dict[1]) << 16) |
-		                     (static_cast<uint64_t>(rgp->rd_dict[2]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[3]) << 48);
-		const uint64_t dhi = static_cast<uint64_t>(rgp->rd_dict[4]) | (static_cast<uint64_t>(rgp->rd_dict[5]) << 16) |
-		                     (static_cast<uint64_t>(rgp->rd_dict[6]) << 32) | (static_cast<uint64_t>(rgp->rd_dict[7]) << 48);
+		const uint64_t dlo = dict.lo, dhi = dict.hi;
 		const uint32_t* lsrc = reinterpret_cast<const uint32_t*>(L.stage + 128 * rbw);
 #pragma unroll
 		for (int mm = 0; mm < kStepsPerWave; ++mm) {
@@ -303,6 +325,9 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // the odd tail vector is simply loaded twice
 		d[i]             = descs[v];
 	}
+	RdDict dict[V];
+#pragma unroll
+	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
 #pragma unroll
 	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
 #pragma unroll
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		for (int i = 0; i < V; ++i) {
 			double acc = 0.0;
 			if (v0 + i < n_vectors) {
-				decode_staged_vector<NT_STORE, SINK>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
+				decode_staged_vector<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
 			}
 #pragma unroll
 			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {
-			decode_staged_vector<NT_STORE>(L[i], d[i], rgs + (v0 + i) / kRowgroup, excs + d[i].exc_off,
+			decode_staged_vector<NT_STORE>(L[i], d[i], dict[i], excs + d[i].exc_off,
 			                               reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
 		}
 	}
