@@ -271,7 +271,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
 		const double n        = static_cast<double>(col->n_vectors);
 		const bool   hinted   = col->packed_bytes_hint != 0 || col->exc_bytes_hint != 0;
-		const bool   narrow   = static_cast<double>(col->packed_bytes_hint) <= 20.0 * 128.0 * n;
+		const bool   narrow   = static_cast<double>(col->packed_bytes_hint) <= 17.0 * 128.0 * n; // crossover measured between 16 and 18 bits (tools/sweep_vpw.py)
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
 		variant               = (variant & ~1) | ((hinted && (narrow || with_exc)) ? 0 : 1);
 	}
