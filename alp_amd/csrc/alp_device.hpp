@@ -12,6 +12,7 @@
 // lane16 columns (2*(lane & 7), +1), so their packed words are one aligned 16-byte unit.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/alpgpu.h"
@@ -147,6 +148,24 @@ __device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state(const alpgp
 #pragma unroll
 	for (int i = 0; i < 8; ++i) { s.rd_dict[i] = static_cast<uint16_t>(w[4 + (i >> 1)] >> (16 * (i & 1))); }
 	return s;
+}
+
+// The ALP_RD dictionary of a vector's rowgroup (eight u16 entries = bytes 16..31 of the state) as two words.  The column decode
+// kernels read it right after the descriptor, together with the packed words — read inside the decode it was a third dependent
+// round trip, behind the barrier, for every ALP_RD vector.
+struct RdDict {
+	uint64_t lo, hi;
+};
+__device__ __forceinline__ RdDict load_rd_dict(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, bool is_rd) {
+	RdDict dict {0ull, 0ull};
+	if (is_rd) { // wave-uniform
+		static_assert(offsetof(alpgpu_rowgroup_state, rd_dict) == 16, "dictionary = second half of the state");
+		const uint32_t  rg = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v / kRowgroup));
+		const uint64_t* dp = reinterpret_cast<const uint64_t*>(rgs + rg) + 2;
+		dict.lo            = dp[0];
+		dict.hi            = dp[1];
+	}
+	return dict;
 }
 
 // ---- scalar codec arithmetic --------------------------------------------------

@@ -106,26 +106,11 @@ __device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgp
 	}
 }
 
-// the ALP_RD dictionary of a vector's rowgroup, read next to the packed words (see decode_kernels.hip: RdDict)
-struct RdDictF {
-	uint64_t lo, hi;
-};
-__device__ __forceinline__ RdDictF load_rd_dict_f32(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, bool is_rd) {
-	RdDictF dict {0ull, 0ull};
-	if (is_rd) { // wave-uniform
-		static_assert(offsetof(alpgpu_rowgroup_state, rd_dict) == 16, "dictionary = second half of the state");
-		const uint32_t  rg = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v / kRowgroup));
-		const uint64_t* dp = reinterpret_cast<const uint64_t*>(rgs + rg) + 2;
-		dict.lo            = dp[0];
-		dict.hi            = dp[1];
-	}
-	return dict;
-}
-
-// ALP vectors use the same two words for their decode constants: lo = FACT_ARR[f], hi = bits of FRAC_ARR[e]
-__device__ __forceinline__ RdDictF load_vector_consts_f32(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
-	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict_f32(rgs, v, true); } // wave-uniform
-	return RdDictF {static_cast<uint64_t>(kFactArrF[d.f]), static_cast<uint64_t>(__float_as_uint(kFracArrF[d.e]))};
+// The per-vector constants, read in front of the barrier: ALP_RD = the rowgroup's dictionary (RdDict, alp_device.hpp); ALP vectors use
+// the same two words for lo = FACT_ARR[f], hi = bits of FRAC_ARR[e]
+__device__ __forceinline__ RdDict load_vector_consts_f32(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
+	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict(rgs, v, true); } // wave-uniform
+	return RdDict {static_cast<uint64_t>(kFactArrF[d.f]), static_cast<uint64_t>(__float_as_uint(kFracArrF[d.e]))};
 }
 
 // one vector, after its packed words / exception mask are visible in L; thread tid owns values 4*tid .. 4*tid+3
@@ -133,7 +118,7 @@ __device__ __forceinline__ RdDictF load_vector_consts_f32(const alpgpu_rowgroup_
 // (exact) and added to `acc` in index order.  kSinkCountF: `acc` counts the values v with lo <= v <= hi (NaN never does).
 constexpr int kSinkStoreF = 0, kSinkSumF = 1, kSinkCountF = 2;
 template <bool NT_STORE, int SINK = kSinkStoreF>
-__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const RdDictF& dict,
+__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const RdDict& dict,
                                                          const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane,
                                                          double* acc = nullptr, float range_lo = 0.0f, float range_hi = 0.0f) {
 	const int    bw    = d.bw;
@@ -233,7 +218,7 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // tail vectors of the last workgroup are simply loaded again
 		d[i]             = descs[v];
 	}
-	RdDictF dict[V];
+	RdDict dict[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts_f32(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
 #pragma unroll

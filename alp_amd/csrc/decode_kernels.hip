@@ -126,26 +126,8 @@ __device__ __forceinline__ void consume_pair(double ox, double oy, double* acc, 
 	}
 }
 
-// The ALP_RD dictionary of a vector's rowgroup (eight u16 entries = bytes 16..31 of the state) as two words.  It is read right
-// after the descriptor, together with the packed words — read inside the decode it was a third dependent round trip, behind the
-// barrier, for every ALP_RD vector.
-struct RdDict {
-	uint64_t lo, hi;
-};
-__device__ __forceinline__ RdDict load_rd_dict(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, bool is_rd) {
-	RdDict dict {0ull, 0ull};
-	if (is_rd) { // wave-uniform
-		static_assert(offsetof(alpgpu_rowgroup_state, rd_dict) == 16, "dictionary = second half of the state");
-		const uint32_t  rg = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v / kRowgroup));
-		const uint64_t* dp = reinterpret_cast<const uint64_t*>(rgs + rg) + 2;
-		dict.lo            = dp[0];
-		dict.hi            = dp[1];
-	}
-	return dict;
-}
-
-// ALP vectors use the same two words for their decode constants: lo = FACT_ARR[f], hi = bits of FRAC_ARR[e] — table reads that
-// depend only on the descriptor and likewise belong in front of the barrier.
+// The per-vector constants, read in front of the barrier: ALP_RD = the rowgroup's dictionary (RdDict, alp_device.hpp); ALP vectors use
+// the same two words for lo = FACT_ARR[f], hi = bits of FRAC_ARR[e] — table reads that depend only on the descriptor.
 __device__ __forceinline__ RdDict load_vector_consts(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
 	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict(rgs, v, true); } // wave-uniform
 	return RdDict {static_cast<uint64_t>(kFactArr[d.f]), static_cast<uint64_t>(__double_as_longlong(kFracArr[d.e]))};
