@@ -297,8 +297,19 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 				const typename P::Coef k = P::coef(P::combos().e[c], P::combos().f[c]);
 				typename P::Acc        acc;
 				P::start(acc);
+				if constexpr (P::kBits == 64) {
+					int s = 0; // four samples per trip, spelled out: the unroller declines this body (a rarely taken branch inside)
+					for (; s + 4 <= samples_size; s += 4) {
+						P::step(acc, smp[wave * 32 + s], k);
+						P::step(acc, smp[wave * 32 + s + 1], k);
+						P::step(acc, smp[wave * 32 + s + 2], k);
+						P::step(acc, smp[wave * 32 + s + 3], k);
+					}
+					for (; s < samples_size; ++s) { P::step(acc, smp[wave * 32 + s], k); }
+				} else {
 #pragma unroll 4
-				for (int s = 0; s < samples_size; ++s) { P::step(acc, smp[wave * 32 + s], k); }
+					for (int s = 0; s < samples_size; ++s) { P::step(acc, smp[wave * 32 + s], k); }
+				}
 				P::finish(acc);
 				const int     non_exc = acc.non_exc;
 				const int64_t mx = acc.mx, mn = acc.mn;
