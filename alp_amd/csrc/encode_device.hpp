@@ -81,6 +81,19 @@ __device__ __forceinline__ void wave_minmax_f64(double& mn, double& mx) {
 	mx = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(b1) << 32) | b0));
 }
 
+// the same reduction inside each 32-lane half: lane 31 ends up with the result of lanes 0..31, lane 63 with that of lanes 32..63
+__device__ __forceinline__ void half_minmax_f64(double& mn, double& mx) {
+#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
+	mn = fmin_num(mn, dpp_f64<CTRL, ROWS>(mn));                                                                         \
+	mx = fmax_num(mx, dpp_f64<CTRL, ROWS>(mx));
+	ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
+	ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
+	ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
+	ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8
+	ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+#undef ALPGPU_MINMAX_STEP
+}
+
 __device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint64_t v, int lane) {
 	const double2* p = reinterpret_cast<const double2*>(in + v * kVec);
 	VecIn          r;
@@ -112,29 +125,44 @@ __device__ __forceinline__ void second_level_select(const VecIn& in, const alpgp
 #pragma unroll
 	for (int kk = 0; kk < 6; kk += 2) {
 		if (kk < k) { // wave-uniform
-			// candidate kk for the low half-wave, kk + 1 for the high one (candidate 0 again if there is none); rgp may be a
-			// register copy of the state: constant indices only
-			const int     kHi   = kk + 1 < 5 ? kk + 1 : 0; // a constant once the loop is unrolled
-			const bool    hi_ok = half != 0 && kk + 1 < k;
-			const int     e     = hi_ok ? rgp->combos[2 * kHi] : (half != 0 ? rgp->combos[0] : rgp->combos[2 * kk]);
-			const int     f     = hi_ok ? rgp->combos[2 * kHi + 1] : (half != 0 ? rgp->combos[1] : rgp->combos[2 * kk + 1]);
-			const int64_t enc = encode_value_safe(sv, kExpArr[e], kFracArr[f]);
-			const double  dec = decode_value(enc, kFactArr[f], kFracArr[e]);
-			const bool    ok  = dec == sv;
+			// candidate kk for the low half-wave, kk + 1 for the high one (candidate 0 again if there is none).  Both candidates
+			// are wave-uniform (rgp is a register copy of the state: constant indices only), so their table entries are scalar
+			// reads and a lane merely selects its half's set.
+			const int    kHi   = kk + 1 < 5 ? kk + 1 : 0; // a constant once the loop is unrolled
+			const bool   has_b = kk + 1 < k;
+			const int    e_a = rgp->combos[2 * kk], f_a = rgp->combos[2 * kk + 1];
+			const int    e_b = has_b ? rgp->combos[2 * kHi] : rgp->combos[0], f_b = has_b ? rgp->combos[2 * kHi + 1] : rgp->combos[1];
+			const bool   hi     = half != 0;
+			const double exp10  = hi ? kExpArr[e_b] : kExpArr[e_a];
+			const double frac_f = hi ? kFracArr[f_b] : kFracArr[f_a];
+			const double frac_e = hi ? kFracArr[e_b] : kFracArr[e_a];
+			const double fact_d = hi ? kExpArr[f_b] : kExpArr[f_a]; // 10^f, exact in double for f <= 18
+			const double sentinel_from = (hi ? f_b : f_a) == 0 ? kUpperLimit : __builtin_inf();
+			// the sample's round trip in doubles wherever that is provably the reference's arithmetic (the argument is spelled
+			// out at PrecF64::step in init_kernels.hip); the two ambiguous cases send the whole wavefront down the literal path
+			constexpr double k2p63 = 9223372036854775808.0, k2p64 = 18446744073709551616.0;
+			const double t   = (sv * exp10) * frac_f;
+			double       r   = __builtin_trunc((t + kMagic) - kMagic);
+			const double p   = r * fact_d;
+			const double ap  = __builtin_fabs(p);
+			bool         ok  = (ap < k2p63) & (__double_as_longlong(p * frac_e) == __double_as_longlong(sv));
+			const bool   lit = (ap == k2p63) | ((t > sentinel_from) & (t < k2p64));
+			if (__ballot(lit) != 0) {
+				const int64_t fact = hi ? kFactArr[f_b] : kFactArr[f_a];
+				const int64_t enc  = encode_value_safe(sv, exp10, frac_f);
+				ok                 = decode_value(enc, fact, frac_e) == sv;
+				r                  = static_cast<double>(enc); // the cast of a double, the sentinel 2^63 - 1024 or -2^63: exact
+			}
 			const uint64_t bal  = __ballot(!ok);
 			const uint32_t excs = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
-			int64_t mx = ok ? enc : INT64_MIN;
-			int64_t mn = ok ? enc : INT64_MAX;
-#pragma unroll
-			for (int d = 16; d >= 1; d >>= 1) { // stays inside the 32-lane half
-				const int64_t omx = __shfl_xor(mx, d);
-				const int64_t omn = __shfl_xor(mn, d);
-				mx                = omx > mx ? omx : mx;
-				mn                = omn < mn ? omn : mn;
-			}
-			const uint32_t size = 32u * static_cast<uint32_t>(count_bits(mx, mn)) + excs * 80u;
-			const uint32_t s0   = __builtin_amdgcn_readlane(size, 0);
-			const uint32_t s1   = __builtin_amdgcn_readlane(size, 32);
+			const double   qnan = __longlong_as_double(0x7FF8000000000000ll);
+			double         mn = ok ? r : qnan, mx = mn; // v_min / v_max_f64 ignore the quiet NaN of a failed sample
+			half_minmax_f64(mn, mx);
+			// no sample encodes: the reference compares INT64_MIN with INT64_MAX and gets a width of 1 (encoder.hpp:263-264,279)
+			const bool     none = !(mx >= mn);
+			const uint32_t size = 32u * static_cast<uint32_t>(count_bits(none ? INT64_MIN : cast64_x86(mx), none ? INT64_MAX : cast64_x86(mn))) + excs * 80u;
+			const uint32_t s0   = __builtin_amdgcn_readlane(size, 31);
+			const uint32_t s1   = __builtin_amdgcn_readlane(size, 63);
 			sizes[kk] = s0;
 			if (kk + 1 < 5) { sizes[kk + 1] = s1; }
 		}
