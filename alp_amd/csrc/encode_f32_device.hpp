@@ -67,16 +67,23 @@ __device__ __forceinline__ void second_level_select_f32(const VecInF& in, const 
 			const uint32_t excs  = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
 			int32_t        mx    = ok ? enc : INT32_MIN;
 			int32_t        mn    = ok ? enc : INT32_MAX;
-#pragma unroll
-			for (int d = 16; d >= 1; d >>= 1) { // stays inside the 32-lane half
-				const int32_t omx = __shfl_xor(mx, d);
-				const int32_t omn = __shfl_xor(mn, d);
-				mx                = omx > mx ? omx : mx;
-				mn                = omn < mn ? omn : mn;
-			}
+			// min / max inside each 32-lane half by DPP (register to register): lane 31 / 63 end up with their half's result
+#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
+	{                                                                                                                   \
+		const int32_t omx = __builtin_amdgcn_update_dpp(mx, mx, CTRL, ROWS, 0xf, false);                                \
+		const int32_t omn = __builtin_amdgcn_update_dpp(mn, mn, CTRL, ROWS, 0xf, false);                                \
+		mx                = omx > mx ? omx : mx;                                                                        \
+		mn                = omn < mn ? omn : mn;                                                                        \
+	}
+			ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
+			ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
+			ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
+			ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8
+			ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+#undef ALPGPU_MINMAX_STEP
 			const uint32_t size = 32u * static_cast<uint32_t>(count_bits32(mx, mn)) + excs * 48u;
-			sizes[kk]           = __builtin_amdgcn_readlane(size, 0);
-			if (kk + 1 < 5) { sizes[kk + 1] = __builtin_amdgcn_readlane(size, 32); }
+			sizes[kk]           = __builtin_amdgcn_readlane(size, 31);
+			if (kk + 1 < 5) { sizes[kk + 1] = __builtin_amdgcn_readlane(size, 63); }
 		}
 	}
 	int      best = 0, worse = 0;
