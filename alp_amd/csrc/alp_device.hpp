@@ -118,6 +118,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Inclusive add-scan over the 64 lanes as DPP row shifts + row broadcasts (register to register; lane 63 ends up with the total).
+// A __shfl_up / __shfl_xor step is a ds_bpermute, i.e. a round trip through the LDS crossbar; chains of those sat on the
+// critical paths of the rowgroup search and of the look-back.
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
+	int v = static_cast<int>(x);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+	return static_cast<uint32_t>(v);
+}
+
 __device__ __forceinline__ uint64_t bw_mask(int bw) { return bw >= 64 ? ~0ULL : ((1ULL << bw) - 1ULL); }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x) {

@@ -182,13 +182,23 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 			mx = R.enc[m][j] > mx ? R.enc[m][j] : mx;
 		}
 	}
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-		const int32_t omn = __shfl_xor(mn, d);
-		const int32_t omx = __shfl_xor(mx, d);
-		mn                = omn < mn ? omn : mn;
-		mx                = omx > mx ? omx : mx;
+	// wavefront min / max by DPP (register to register; lanes without a source lane keep their own value), result in lane 63
+#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
+	{                                                                                                                   \
+		const int32_t omn = __builtin_amdgcn_update_dpp(mn, mn, CTRL, ROWS, 0xf, false);                                \
+		const int32_t omx = __builtin_amdgcn_update_dpp(mx, mx, CTRL, ROWS, 0xf, false);                                \
+		mn                = omn < mn ? omn : mn;                                                                        \
+		mx                = omx > mx ? omx : mx;                                                                        \
 	}
+	ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
+	ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
+	ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
+	ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8
+	ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+	ALPGPU_MINMAX_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3
+#undef ALPGPU_MINMAX_STEP
+	mn     = __builtin_amdgcn_readlane(mn, 63);
+	mx     = __builtin_amdgcn_readlane(mx, 63);
 	R.base = mn;
 	R.bw   = count_bits32(mx, mn);
 }

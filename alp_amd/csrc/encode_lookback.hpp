@@ -49,10 +49,15 @@ __device__ unsigned int* g_lookback_phase; // [n_tiles][4]: level-1 ticks, level
 
 __device__ __forceinline__ uint64_t status_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void     status_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Sum of the lanes' status payloads {packed units << 31 | exception units} (flags already masked off), wave-uniform.  The two
+// 31-bit fields are reduced separately with DPP adds and joined by an ADD, which is what a 64-bit sum of the words gives; as
+// six dependent 64-bit __shfl_xor steps (12 ds_bpermutes) this sum was ~1k cycles on the scout's path, two or three times per tile.
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-	for (int dd = 32; dd >= 1; dd >>= 1) { v += static_cast<uint64_t>(__shfl_xor(static_cast<long long>(v), dd)); }
-	return v;
+	const uint32_t lo = wave_scan_add_u32(static_cast<uint32_t>(v) & 0x7FFFFFFFu);
+	const uint32_t hi = wave_scan_add_u32(static_cast<uint32_t>(v >> 31));
+	const uint64_t l  = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lo), 63));
+	const uint64_t h  = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hi), 63));
+	return (h << 31) + l;
 }
 
 // status: [gridDim.x] tile words followed by [ceil(gridDim.x / kBlockTiles)] block words, all zero at launch.

@@ -174,19 +174,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 	return v;
 }
 
-// Inclusive scans over the 64 lanes as DPP row shifts + row broadcasts (register to register).  The cut search below is a
-// chain of dependent scans per 64-sample chunk; as __shfl_up steps (ds_bpermute, one LDS-crossbar round trip each) that chain
-// was the latency that bounded ALP_RD rowgroups.
-__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
-	int v = static_cast<int>(x);
-	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
-	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
-	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
-	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
-	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
-	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
-	return static_cast<uint32_t>(v);
-}
+// (wave_scan_add_u32: alp_device.hpp)  The cut search below is a chain of dependent scans per 64-sample chunk; as __shfl_up steps
+// (ds_bpermute, one LDS-crossbar round trip each) that chain was the latency that bounded ALP_RD rowgroups.
 // values >= -1
 __device__ __forceinline__ int wave_scan_max_i32(int v) {
 	int t;
