@@ -340,17 +340,24 @@ __device__ __forceinline__ void pack_u64_units(const EncodeLds& L, int bw, int l
 		ull2v     acc = {0ull, 0ull};
 		const int u   = lane + 64 * t;
 		if (64 * t < n_units && u < n_units) { // first test is wave-uniform
+			// Word k of the column pair's stream = bits [64k, 64k + 64).  Its first contributing row r straddles the word's start
+			// (its low `sh` bits belong to word k - 1): one right shift; every later row starts inside the word: left shifts only,
+			// no direction to decide per row.  The next row's values are requested before the current ones are used.
 			const int k    = u >> 3;
 			const int a    = u & 7;
 			const int bit0 = 64 * k;
 			int       r    = static_cast<int>((static_cast<uint32_t>(bit0) * inv_bw) >> 20); // = bit0 / bw
-			int       p    = r * bw;
-			while (p < bit0 + 64 && r < 64) {
-				const ull2v v  = vals2[8 * r + a];
-				const int   sh = p - bit0;
-				acc |= sh >= 0 ? (v << static_cast<unsigned long long>(sh)) : (v >> static_cast<unsigned long long>(-sh));
-				p += bw;
+			const int sh   = bit0 - r * bw;                                                   // 0 <= sh < bw <= 64
+			acc            = vals2[8 * r + a] >> static_cast<unsigned long long>(sh);
+			int   p        = bw - sh; // where row r + 1 starts inside this word (1..64)
+			ull2v nxt      = vals2[8 * (r + 1 < 64 ? r + 1 : 63) + a];
+			++r;
+			while (p < 64 && r < 64) {
+				const ull2v v = nxt;
 				++r;
+				nxt = vals2[8 * (r < 64 ? r : 63) + a];
+				acc |= v << static_cast<unsigned long long>(p);
+				p += bw;
 			}
 		}
 		P.acc[t] = acc;

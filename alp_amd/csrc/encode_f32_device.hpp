@@ -250,14 +250,19 @@ __device__ __forceinline__ void pack_u32_units(const EncodeLdsF32& L, int bw, in
 			const int k    = u >> 3;
 			const int a    = u & 7;
 			const int bit0 = 32 * k;
+			// as pack_u64_units: the first row straddles the word's start (one right shift), the later ones start inside it
 			int       r    = static_cast<int>((static_cast<uint32_t>(bit0) * inv_bw) >> 20); // = bit0 / bw
-			int       p    = r * bw;
-			while (p < bit0 + 32 && r < 32) {
-				const u32x4 v  = vals4[8 * r + a];
-				const int   sh = p - bit0;
-				acc |= sh >= 0 ? (v << static_cast<uint32_t>(sh)) : (v >> static_cast<uint32_t>(-sh));
-				p += bw;
+			const int sh   = bit0 - r * bw;                                                   // 0 <= sh < bw <= 32
+			acc            = vals4[8 * r + a] >> static_cast<uint32_t>(sh);
+			int   p        = bw - sh; // where row r + 1 starts inside this word (1..32)
+			u32x4 nxt      = vals4[8 * (r + 1 < 32 ? r + 1 : 31) + a];
+			++r;
+			while (p < 32 && r < 32) {
+				const u32x4 v = nxt;
 				++r;
+				nxt = vals4[8 * (r < 32 ? r : 31) + a];
+				acc |= v << static_cast<uint32_t>(p);
+				p += bw;
 			}
 		}
 		P.acc[t] = acc;
