@@ -212,8 +212,8 @@ struct AlpEncoded {
 // a software double->int64 conversion and its x86 range check).  For the verification, (double)(int64)(enc * 10^f) is the
 // correctly rounded value of an integer product that does not wrap when |enc * 10^f| < 2^63, i.e. exactly the IEEE product
 // r * 10^f of two exactly representable doubles (one multiply instead of a 64-bit integer multiply and a software
-// int64->double conversion).  A step in which any lane leaves these ranges (|t| >= 2^51, which includes -0.0's stand-in
-// 9.2e18 and +-Inf, or |r * 10^f| >= 2^63) is redone for the whole wavefront with the literal arithmetic; NaN never asks
+// int64->double conversion).  A step in which any lane leaves these ranges (|t| >= 2^51, which includes +-Inf, or
+// |r * 10^f| >= 2^63) is redone for the whole wavefront with the literal arithmetic; NaN never asks
 // for that (its compares are false) and is an exception on both routes.  Results are bit-identical by construction.
 __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int f, int lane, AlpEncoded& R) {
 	(void)lane; // every cross-lane step below is a ballot, a DPP move or a readlane
@@ -234,9 +234,11 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 		for (int j = 0; j < 2; ++j) {
 			const double   v    = j == 0 ? in.x[m].x : in.x[m].y;
 			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(v));
-			// pass 1 (encoder.hpp:326-338): for doubles only -0.0 matches (the mask literal evaluates to
-			// 0xFFE0000000000000); NaN/Inf go through the arithmetic and fail the compare
-			const double vv = bits == 0x8000000000000000ull ? kUpperLimit : v;
+			// pass 1 (encoder.hpp:326-338): for doubles only -0.0 matches (the mask literal evaluates to 0xFFE0000000000000,
+			// SURVEY.md §8 A6) and is replaced by a value that cannot round-trip; NaN/Inf go through the arithmetic and fail the
+			// compare.  Here -0.0 simply goes through as well (it encodes to 0 and decodes to +0.0, which == would accept) and is
+			// made an exception by its bit pattern below: one compare instead of a compare and two selects per step.
+			const double vv = v;
 			double       t  = vv * exp10;
 			t               = t * frac_f;
 			const double u  = t + kMagic;
@@ -249,11 +251,13 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 				enc = cast64_x86(r);
 				dec = decode_value(enc, fact, frac_e);
 			}
-			const bool exc = dec != vv; // IEEE compare: NaN is always an exception
+			const bool exc = (dec != vv) | (bits == 0x8000000000000000ull); // IEEE compare: NaN is always an exception
 			R.enc[m][j]    = enc;
 			R.ballot[m][j] = __ballot(exc);
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
-			const double rm = exc ? qnan : r;
+			// a quiet NaN whatever the low word says: only the high word is replaced
+			const uint64_t rb = static_cast<uint64_t>(__double_as_longlong(r));
+			const double   rm = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(exc ? 0x7FF80000u : static_cast<uint32_t>(rb >> 32)) << 32) | (rb & 0xFFFFFFFFull)));
 			rmin            = fmin_num(rmin, rm);
 			rmax            = fmax_num(rmax, rm);
 		}
