@@ -219,6 +219,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 					ev[r] = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
 					ep[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
 				});
+				// the pad up to the record's 8-byte size is zero, as in the single-pass encode
+				const int n_pos = static_cast<int>((((10u * static_cast<uint32_t>(R.cnt) + 7u) & ~7u) - 8u * static_cast<uint32_t>(R.cnt)) >> 1);
+				if (R.cnt + lane < n_pos) { ep[R.cnt + lane] = 0; }
 			}
 			// (enc - base) -> LDS in natural order, then FFOR pack
 			ulonglong2*    lv   = reinterpret_cast<ulonglong2*>(L.vals);
@@ -239,6 +242,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 					ev[r] = R.left[m][j];
 					ep[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
 				});
+				const int n_pos = static_cast<int>((((4u * static_cast<uint32_t>(R.cnt) + 7u) & ~7u) - 2u * static_cast<uint32_t>(R.cnt)) >> 1);
+				if (R.cnt + lane < n_pos) { ep[R.cnt + lane] = 0; } // zero pad, as in the single-pass encode
 			}
 			ulonglong2* lv = reinterpret_cast<ulonglong2*>(L.vals);
 #pragma unroll

@@ -93,7 +93,7 @@ typedef struct alpgpu_vector_desc {
 	                         ALP: 128*bw bytes.  ALP_RD: 128*rbw bytes (right, u64 lanes) then 128*lbw (left, u16 lanes) */
 	uint64_t exc_off;     /* byte offset of this vector's exception record in the exception stream (multiple of 8).
 	                         ALP: cnt*8 B values (f64 bits) then cnt*2 B positions.  ALP_RD: cnt*2 B left parts then cnt*2 B positions.
-	                         record size is rounded up to 8 bytes; the single-pass encode writes the pad bytes as zero */
+	                         record size is rounded up to 8 bytes; both encode forms write the pad bytes as zero (the streams are byte-reproducible into a dirty buffer) */
 	int64_t  base;        /* ALP: frame-of-reference base (for_base).  ALP_RD: 0 */
 	uint8_t  bw;          /* ALP: bit width 0..64.  ALP_RD: right bit width */
 	uint8_t  e;           /* ALP: exponent index (state.exp) */

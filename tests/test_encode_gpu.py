@@ -314,3 +314,23 @@ def test_search_boundary_mixtures_whole_streams(ctx, oracle, seed):
     out = ctx.decode(dcol)
     ctx.synchronize()
     assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+
+
+@pytest.mark.parametrize("two_pass", [0, 1])
+def test_exception_record_pad_bytes_are_zero_whatever_was_in_the_buffer(ctx, oracle, two_pass):
+    """the exception stream is byte-reproducible even into a dirty buffer: both encode forms write the pad of every record"""
+    from alp_amd import capi
+    col_np = np.concatenate([datagen.mixed_column(130, seed=5, exc_rate=0.03), datagen.rd_column(110, seed=6)])
+    want = layout.compact(oracle.encode_column(col_np))
+    x = torch.from_numpy(col_np).cuda()
+    dcol = capi.DeviceColumn(col_np.size // 1024)
+    dcol.exc.fill_(0xA5)
+    dcol.packed.fill_(0x5A)
+    try:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, two_pass)
+        ctx.encode(x, dcol)
+        ctx.synchronize()
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
+    for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"two_pass={two_pass}: {what}"

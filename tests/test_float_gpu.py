@@ -347,3 +347,17 @@ def test_long_float_column_lookback_offsets(ctx, of32):
     w_rg, w_vec, w_packed, w_exc = layout.compact(want, 4)
     assert np.array_equal(vec["packed_off"], w_vec["packed_off"]) and np.array_equal(vec["exc_off"], w_vec["exc_off"])
     assert np.array_equal(packed, w_packed) and np.array_equal(exc, w_exc)
+
+
+def test_float_exception_record_pad_bytes_are_zero_in_a_dirty_buffer(ctx, of32):
+    from alp_amd import capi
+    col_np = np.concatenate([datagen.mixed_column_f32(130, seed=5, exc_rate=0.03), datagen.rd_column_f32(110, seed=6)])
+    want = layout.compact(of32.encode_column(col_np), 4)
+    x = torch.from_numpy(col_np).cuda()
+    dcol = capi.DeviceColumn(col_np.size // 1024, dtype="f32")
+    dcol.exc.fill_(0xA5)
+    dcol.packed.fill_(0x5A)
+    ctx.encode(x, dcol)
+    ctx.synchronize()
+    for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), what
