@@ -69,7 +69,7 @@ _sig("alpgpu_ctx_destroy", None, _vp)
 _sig("alpgpu_set_stream", _int, _vp, _vp)
 _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
-OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS = 1, 2, 3
+OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL = 1, 2, 3, 4
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
@@ -137,21 +137,33 @@ def _check(rc: int, what: str):
 
 
 class Context:
-    """One per device / process.  Uses torch's current stream unless told otherwise."""
+    """One per device / process.  With use_torch_stream (default) every call is enqueued on torch's CURRENT stream of the
+    device at the time of the call (so `with torch.cuda.stream(s):` works as for torch's own ops); set_stream() pins a
+    stream instead."""
 
     def __init__(self, device: int = 0, use_torch_stream: bool = True):
         h = _vp()
         _check(lib.alpgpu_ctx_create(device, C.byref(h)), "alpgpu_ctx_create")
-        self.h = h
+        self._h = h
         self.device = device
-        if use_torch_stream:
+        self._follow_torch = bool(use_torch_stream)
+        self._last_stream = None
+
+    @property
+    def h(self):
+        """the context handle; re-points the context at torch's current stream first when it follows torch"""
+        if self._follow_torch and self._h:
             import torch
-            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            if cur != self._last_stream:
+                _check(lib.alpgpu_set_stream(self._h, _vp(cur)), "alpgpu_set_stream")
+                self._last_stream = cur
+        return self._h
 
     def close(self):
-        if getattr(self, "h", None):
-            lib.alpgpu_ctx_destroy(self.h)
-            self.h = None
+        if getattr(self, "_h", None):
+            lib.alpgpu_ctx_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -160,7 +172,9 @@ class Context:
             pass
 
     def set_stream(self, stream_handle: int):
-        _check(lib.alpgpu_set_stream(self.h, _vp(stream_handle)), "alpgpu_set_stream")
+        """pin the context to this hipStream_t handle (it stops following torch's current stream)"""
+        self._follow_torch = False
+        _check(lib.alpgpu_set_stream(self._h, _vp(stream_handle)), "alpgpu_set_stream")
 
     def set_option(self, option: int, value: int):
         _check(lib.alpgpu_set_option(self.h, option, value), "alpgpu_set_option")
@@ -230,9 +244,11 @@ class Context:
 
     def from_blob(self, blob: np.ndarray):
         """-> (DeviceColumn, n_values); raises AlpGpuError on a malformed blob"""
+        if blob.size < 64:
+            raise AlpGpuError("blob shorter than its 64-byte header")
         hdr = np.frombuffer(blob[:64].tobytes(), dtype=np.uint64)
         n_vectors, packed_bytes, exc_bytes = int(hdr[3]), int(hdr[5]), int(hdr[6])
-        if blob.size < 64 or n_vectors > (1 << 40) or packed_bytes > (1 << 50) or exc_bytes > (1 << 50):
+        if n_vectors > (1 << 40) or packed_bytes > (1 << 50) or exc_bytes > (1 << 50):
             raise AlpGpuError("blob header is implausible")
         dtype = "f32" if int(hdr[7]) == 4 else "f64"
         col = DeviceColumn(n_vectors, self.device, packed_capacity=packed_bytes + 1024, exc_capacity=exc_bytes + 64, dtype=dtype)

@@ -22,8 +22,12 @@ struct alpgpu_ctx {
 	char        name[128];
 	uint64_t    hbm_bytes;
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
+	int         force_stall;     // debug: the single pass gives up in its look-back, the recovery route re-encodes
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
+	hipEvent_t  ws_event;        // recorded behind the last encode that used the workspace ...
+	hipStream_t ws_stream;       // ... on this stream
+	int         ws_busy;
 };
 
 namespace {
@@ -88,8 +92,16 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_auto     = 1;
 	ctx->decode_vpw      = 0;
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
+	ctx->force_stall     = 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
+	ctx->ws_stream       = nullptr;
+	ctx->ws_busy         = 0;
+	if (hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) {
+		(void)hipStreamDestroy(ctx->own_stream);
+		delete ctx;
+		return fail(ALPGPU_ERR_HIP, "hipEventCreate failed");
+	}
 	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { // A/B runs
 		ctx->decode_variant = std::atoi(v);
 		ctx->decode_auto    = 0;
@@ -104,6 +116,8 @@ int alpgpu_init(int device, alpgpu_ctx** out_ctx) { return alpgpu_ctx_create(dev
 void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 	if (!ctx) { return; }
 	(void)hipSetDevice(ctx->device);
+	if (ctx->ws_busy) { (void)hipEventSynchronize(ctx->ws_event); }
+	(void)hipEventDestroy(ctx->ws_event);
 	(void)hipStreamDestroy(ctx->own_stream);
 	if (ctx->workspace) { (void)hipFree(ctx->workspace); }
 	delete ctx;
@@ -137,6 +151,9 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_PLAIN_STORES:
 		ctx->decode_variant = (ctx->decode_variant & ~2) | (value ? 2 : 0);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DEBUG_FORCE_STALL:
+		ctx->force_stall = value ? 1 : 0;
 		return ALPGPU_OK;
 	default:
 		return fail(ALPGPU_ERR_INVALID, "unknown option");
@@ -195,16 +212,26 @@ uint64_t alpgpu_packed_capacity(uint64_t n_vectors) { return n_vectors * 8448ull
 // worst case per vector: 1024 exceptions x (8 B value + 2 B position)
 uint64_t alpgpu_exc_capacity(uint64_t n_vectors) { return n_vectors * 10240ull + 64ull; }
 
+// One scan / status workspace per context.  Work that uses it is ordered behind the previous user: same stream = stream
+// order; another stream (alpgpu_set_stream between two encodes, e.g. a torch stream switch) waits on the event recorded
+// behind the previous encode; growing the buffer waits for that event on the host before the old buffer is freed.
 static int ensure_workspace(alpgpu_ctx* ctx, uint64_t bytes) {
+	if (ctx->ws_busy && ctx->ws_stream != ctx->stream) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ws_event, 0)); }
 	if (ctx->workspace_bytes >= bytes) { return ALPGPU_OK; }
-	// grows only between launches of different sizes; the old buffer may still be in use by queued work
-	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	if (ctx->ws_busy) { ALPGPU_HIP(hipEventSynchronize(ctx->ws_event)); }
+	ctx->ws_busy = 0;
 	if (ctx->workspace) { ALPGPU_HIP(hipFree(ctx->workspace)); }
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	const uint64_t want  = bytes < (1ull << 20) ? (1ull << 20) : bytes * 2;
 	ALPGPU_HIP(hipMalloc(&ctx->workspace, want));
 	ctx->workspace_bytes = want;
+	return ALPGPU_OK;
+}
+static int workspace_used(alpgpu_ctx* ctx) {
+	ALPGPU_HIP(hipEventRecord(ctx->ws_event, ctx->stream));
+	ctx->ws_stream = ctx->stream;
+	ctx->ws_busy   = 1;
 	return ALPGPU_OK;
 }
 
@@ -215,13 +242,14 @@ static int check_column(const alpgpu_column* col, uint64_t n_vectors) {
 	if (n_vectors && (!col->d_rowgroups || !col->d_vectors || !col->d_packed || !col->d_exc || !col->d_totals)) {
 		return fail(ALPGPU_ERR_INVALID, "column buffers must be allocated by the caller");
 	}
-	return ALPGPU_OK;
+	return ALPGPU_OK; // (an empty column may have no buffers at all: every entry point returns early for it)
 }
 
 int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (n_vectors == 0) { return ALPGPU_OK; }
 	if (alpgpu::launch_rowgroup_init(ctx->stream, d_in, n_vectors, col->d_rowgroups, col->d_rd_order) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
 	}
@@ -246,16 +274,29 @@ int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, u
 	return state_from_samples(ctx, d_samples, n_samples, d_state, 1);
 }
 
+// Single pass, with the recovery route enqueued behind it: the two-pass kernels, gated on the stall flag the single pass
+// raises when its look-back gives up (d_totals[6]).  No host synchronisation; when nothing stalled — always, in practice —
+// the four gated launches cost a few microseconds.  A column is therefore complete whenever this returns ALPGPU_OK and the
+// stream has drained, whatever the dispatch order of the single pass was.
 int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (n_vectors == 0) {
+		if (col->d_totals) { ALPGPU_HIP(hipMemsetAsync(col->d_totals, 0, 64, ctx->stream)); }
+		return ALPGPU_OK;
+	}
 	if (int rc = ensure_workspace(ctx, alpgpu::encode_workspace_bytes(n_vectors))) { return rc; }
-	const int rc = ctx->encode_two_pass
-	                   ? alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace), ctx->n_cus)
-	                   : alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace));
+	uint64_t* ws = static_cast<uint64_t*>(ctx->workspace);
+	int       rc;
+	if (ctx->encode_two_pass) {
+		rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus);
+	} else {
+		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0);
+		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus, col->d_totals + 6); }
+	}
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
-	return ALPGPU_OK;
+	return workspace_used(ctx);
 }
 
 // Rowgroup init, then the vector encode, on the context's stream.  (Running the rowgroup search of the next chunk of the column
@@ -428,6 +469,7 @@ static int column_to_blob(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t n_
 		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
 	}
 	if (t[2]) { return fail(ALPGPU_ERR_CAPACITY, "the column overflowed its streams; nothing to serialise"); }
+	if (t[3]) { return fail(ALPGPU_ERR_HIP, "the column's encode did not complete (look-back stall and failed recovery); nothing to serialise"); }
 	const uint64_t need = alpgpu_blob_size(col->n_vectors, t[0], t[1]);
 	if (written) { *written = need; }
 	if (capacity < need) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
@@ -534,16 +576,21 @@ int alpgpu_column_from_blob_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t si
 
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
 	ALPGPU_CHECK_CTX(ctx);
-	if (!col || !col->d_totals) { return fail(ALPGPU_ERR_INVALID, "null column"); }
+	if (!col) { return fail(ALPGPU_ERR_INVALID, "null column"); }
 	uint64_t t[4] = {0, 0, 0, 0};
-	ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
-	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	if (col->d_totals) {
+		ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	} else if (col->n_vectors != 0) {
+		return fail(ALPGPU_ERR_INVALID, "column without d_totals");
+	}
 	if (packed_bytes) { *packed_bytes = t[0]; }
 	if (exc_bytes) { *exc_bytes = t[1]; }
 	if (overflow) { *overflow = static_cast<int>(t[2]); }
 	col->packed_bytes_hint = t[0];
 	col->exc_bytes_hint    = t[1];
-	if (t[3]) { return fail(ALPGPU_ERR_HIP, "single-pass encode stalled in its offset look-back; re-encode with ALPGPU_OPT_ENCODE_TWO_PASS"); }
+	// cannot happen through alpgpu_encode_*: the recovery route clears the flag (alpgpu_encode_vectors_f64)
+	if (t[3]) { return fail(ALPGPU_ERR_HIP, "single-pass encode stalled in its offset look-back and was not recovered"); }
 	return t[2] ? fail(ALPGPU_ERR_CAPACITY, "an output stream overflowed its capacity") : ALPGPU_OK;
 }
 
@@ -557,6 +604,7 @@ int alpgpu_rowgroup_init_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vect
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
+	if (n_vectors == 0) { return ALPGPU_OK; }
 	if (alpgpu::launch_rowgroup_init_f32(ctx->stream, d_in, n_vectors, col->d_rowgroups, col->d_rd_order) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
 	}
@@ -579,15 +627,25 @@ int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, ui
 	return state_from_samples_f32(ctx, d_samples, n_samples, d_state, 1);
 }
 
-int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
+int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) { // see alpgpu_encode_vectors_f64
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
-	if (int rc = ensure_workspace(ctx, alpgpu::encode_workspace_bytes(n_vectors))) { return rc; }
-	if (alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, static_cast<uint64_t*>(ctx->workspace)) != ALPGPU_OK) {
-		return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError());
+	if (n_vectors == 0) {
+		if (col->d_totals) { ALPGPU_HIP(hipMemsetAsync(col->d_totals, 0, 64, ctx->stream)); }
+		return ALPGPU_OK;
 	}
-	return ALPGPU_OK;
+	if (int rc = ensure_workspace(ctx, alpgpu::encode_workspace_bytes(n_vectors))) { return rc; }
+	uint64_t* ws = static_cast<uint64_t*>(ctx->workspace);
+	int       rc;
+	if (ctx->encode_two_pass) {
+		rc = alpgpu::launch_encode_vectors_f32(ctx->stream, d_in, n_vectors, col, ws);
+	} else {
+		rc = alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0);
+		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors_f32(ctx->stream, d_in, n_vectors, col, ws, col->d_totals + 6); }
+	}
+	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
+	return workspace_used(ctx);
 }
 
 int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {

@@ -6,8 +6,11 @@
 //   ffor::ffor (int32 / uint32 / uint16)  include/fastlanes/ffor.hpp:7-15 -> src/fastlanes_generated_ffor.cpp:1776-7378, :357-1775
 //   alp::rd_encoder<float>::encode        include/alp/rd.hpp:109-147
 //
-// Single pass, same scheme as k_encode_fused (encode_kernels.hip): one wavefront per 1024-value vector, four vectors per
-// workgroup (tile), output offsets in vector order from the decoupled look-back of encode_lookback.hpp.
+// Single pass, same scheme as k_encode_fused (encode_kernels.hip): one wavefront per 1024-value vector, kFusedWaves vectors per
+// workgroup (tile), output offsets in vector order from the decoupled look-back of encode_lookback.hpp.  The same kernel body,
+// compiled in two more modes, is the two-pass form (ALPGPU_OPT_ENCODE_TWO_PASS and the recovery route of a stalled single pass):
+// ANALYZE stops after the sizes are known and leaves them in the descriptors, PACK takes its offsets from the scan of those
+// (k_scan_tiles / k_scan_totals of encode_kernels.hip) instead of the look-back.
 // Ownership: lane L holds the value quads i = 256*m + 4*L + j (m = 0..3, j = 0..3), so the 4 KiB input is read with four
 // 1-KiB-contiguous 16-byte-per-lane loads; in the FastLanes u32 layout (alp_device_f32.hpp) a quad is one 16-byte unit:
 // row = 8*m + (L >> 3), unit column a = L & 7.
@@ -18,21 +21,24 @@
 
 namespace alpgpu {
 
-__device__ __forceinline__ void desc_sizes_f32(const alpgpu_vector_desc& d, uint64_t& packed, uint64_t& exc) {
-	if (d.scheme == ALPGPU_SCHEME_ALP) {
-		packed = 128ull * d.bw;
-		exc    = (6ull * d.exc_cnt + 7ull) & ~7ull; // cnt x f32 bits, then cnt x u16 positions
-	} else {
-		packed = 128ull * (static_cast<uint64_t>(d.bw) + d.lbw);
-		exc    = (4ull * d.exc_cnt + 7ull) & ~7ull; // cnt x u16 left parts, then cnt x u16 positions
-	}
-}
+enum FusedMode { kSinglePass = 0, kAnalyze = 1, kPack = 2 };
+constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors per tile of the two-pass scan
 
+// kSinglePass: `status` = look-back words.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only), `gate` as in
+// encode_kernels.hip, v_first = 0.
+template <int MODE>
 __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                        uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                        uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
-                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order) {
+                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order,
+                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate) {
+	if (MODE != kSinglePass && gate != nullptr && *gate == 0) { return; }
+	if (MODE == kPack && totals[2] != 0) { // capacity overflow (reported through alpgpu_column_totals): no stream bytes, descriptors a decoder can follow
+		const uint64_t vo = v_first + static_cast<uint64_t>(blockIdx.x) * kFusedWaves + (threadIdx.x >> 6);
+		if ((threadIdx.x & 63) == 0 && vo < v_first + n_vectors_launch) { descs[vo] = empty_descriptor(); }
+		return;
+	}
 	__shared__ EncodeLdsF32 lds[kFusedWaves];
 	__shared__ uint64_t     s_size[kFusedWaves];
 	__shared__ uint64_t     s_excl;
@@ -139,8 +145,12 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 		d.exc_cnt = static_cast<uint16_t>(cnt);
 	}
 	uint64_t my_p = 0, my_e = 0;
-	if (live) { desc_sizes_f32(d, my_p, my_e); }
-	if (lane == 0) {
+	if (live) { record_sizes<4>(d, my_p, my_e); }
+	if (MODE == kAnalyze) { // the sizes are all the scan needs
+		if (live && lane == 0) { descs[v] = d; }
+		return;
+	}
+	if (MODE == kSinglePass && lane == 0) {
 		s_size[wave]           = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (arrived == kFusedWaves - 1) {
@@ -179,26 +189,32 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 		});
 		wave_lds_sync();
 	}
-	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
-	{
+	if (MODE == kSinglePass) {
+		if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
 		uint32_t spins = 0;
 		while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
 			if (++spins > 64u * kSpinLimit) { return; }
 			__builtin_amdgcn_s_sleep(2);
 		}
-	}
-	uint64_t local = 0;
+		uint64_t local = 0;
 #pragma unroll
-	for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
-	const uint64_t excl = s_excl;
-	if (excl == ~0ull) { return; }
-
-	const uint64_t pre    = excl + local;
-	d.packed_off          = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
-	d.exc_off             = base_e + (pre & 0x7FFFFFFFull) * 8ull;
+		for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
+		const uint64_t excl = s_excl;
+		if (excl == ~0ull) { return; }
+		const uint64_t pre = excl + local;
+		d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
+		d.exc_off          = base_e + (pre & 0x7FFFFFFFull) * 8ull;
+	} else if (live) { // kPack: the scan left the offsets inside the vector's scan tile in its descriptor
+		const uint64_t st_ = v / kScanTileF32;
+		d.packed_off       = descs[v].packed_off + status[2 * st_];
+		d.exc_off          = descs[v].exc_off + status[2 * st_ + 1];
+	}
 	if (!live) { return; }
-	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) {
-		if (lane == 0) { __hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) { // see k_encode_fused
+		if (lane == 0) {
+			__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			descs[v] = empty_descriptor();
+		}
 		return;
 	}
 	uint8_t* dst = packed + d.packed_off;
@@ -231,25 +247,42 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 __global__ void k_fused_finish_f32(uint64_t* __restrict__ totals) {
 	totals[0] = totals[4];
 	totals[1] = totals[5];
+	if (totals[3] != 0) { totals[6] = 1; } // the gate of the recovery kernels (see k_fused_finish)
 }
 
-int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range) {
+int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
+                                  bool force_stall) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-		hipLaunchKernelGGL(k_encode_fused_f32, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
+		hipLaunchKernelGGL(k_encode_fused_f32<kSinglePass>, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch, col->d_rd_order);
+		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, static_cast<const uint64_t*>(nullptr));
 		hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(1), 0, stream, col->d_totals);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall) {
 	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors);
+	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors, force_stall);
+}
+
+// the two-pass form for float columns (gate: see launch_encode_vectors in encode_kernels.hip)
+int launch_encode_vectors_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, const uint64_t* gate) {
+	if (n_vectors == 0) {
+		if (gate == nullptr) { (void)hipMemsetAsync(col->d_totals, 0, 64, stream); }
+		return ALPGPU_OK;
+	}
+	const dim3 grid(static_cast<unsigned>((n_vectors + kFusedWaves - 1) / kFusedWaves)), block(64 * kFusedWaves);
+	hipLaunchKernelGGL(k_encode_fused_f32<kAnalyze>, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
+	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate);
+	if (launch_scan_offsets(stream, col, n_vectors, d_workspace, true, gate) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
+	hipLaunchKernelGGL(k_encode_fused_f32<kPack>, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
+	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 } // namespace alpgpu

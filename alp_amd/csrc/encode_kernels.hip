@@ -22,29 +22,18 @@
 #include "encode_lookback.hpp"
 #include "launch.hpp"
 
-#include <cstdlib>
-
 namespace alpgpu {
 
 constexpr int kScanTile = 1024;
 
-#ifdef ALPGPU_FUSED_TIMING // experiment builds only (tools/fused_phases.py): where a wavefront of k_encode_fused spends its life
-__device__ unsigned int* g_fused_phase; // [n_vectors][4] deltas, written by lane 0 of the vector's wavefront
-#define ALPGPU_PHASE_MARK(k)                                                                                           \
-	do {                                                                                                               \
-		const unsigned long long now_ = __builtin_readcyclecounter();                                                  \
-		if (lane == 0 && live && g_fused_phase) { g_fused_phase[4 * v + (k)] = static_cast<unsigned int>(now_ - t_prev_); } \
-		t_prev_ = now_;                                                                                                \
-	} while (0)
-#else
-#define ALPGPU_PHASE_MARK(k)
-#endif
-
 // ---- pass 1: analysis -----------------------------------------------------------------------------------
+// `gate` (all kernels of this form): nullptr, or a word that must be non-zero for the kernel to do anything — the recovery route
+// of a stalled single pass is enqueued behind every single-pass encode and runs only when the stall flag was raised.
 __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_analyze(const double* __restrict__ in,
                                                                      const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                                     alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors) {
+                                                                     alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors, const uint64_t* __restrict__ gate) {
 	__shared__ EncodeLds lds[kWavesPerWg];
+	if (gate != nullptr && *gate == 0) { return; }
 	const int            lane = lane_id();
 	const int            wave = wave_in_wg();
 	EncodeLds&           L    = lds[wave];
@@ -87,27 +76,19 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_analyze(const doubl
 }
 
 // ---- pass 2: offsets ------------------------------------------------------------------------------------
-__device__ __forceinline__ void desc_sizes(const alpgpu_vector_desc& d, uint64_t& packed, uint64_t& exc) {
-	if (d.scheme == ALPGPU_SCHEME_ALP) {
-		packed = 128ull * d.bw;
-		exc    = (10ull * d.exc_cnt + 7ull) & ~7ull;
-	} else {
-		packed = 128ull * (static_cast<uint64_t>(d.bw) + d.lbw);
-		exc    = (4ull * d.exc_cnt + 7ull) & ~7ull;
-	}
-}
-
 // block = 256 threads, 4 consecutive descriptors per thread
+template <int VALUE_BYTES>
 __global__ __launch_bounds__(256) void k_scan_tiles(alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors,
-                                                    uint64_t* __restrict__ tile_sums /* [n_tiles][2] */) {
+                                                    uint64_t* __restrict__ tile_sums /* [n_tiles][2] */, const uint64_t* __restrict__ gate) {
 	__shared__ uint64_t sp[256], se[256];
+	if (gate != nullptr && *gate == 0) { return; }
 	const uint64_t      v0 = static_cast<uint64_t>(blockIdx.x) * kScanTile + 4ull * threadIdx.x;
 	uint64_t            p[4], e[4];
 	uint64_t            tp = 0, te = 0;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		p[i] = e[i] = 0;
-		if (v0 + i < n_vectors) { desc_sizes(descs[v0 + i], p[i], e[i]); }
+		if (v0 + i < n_vectors) { record_sizes<VALUE_BYTES>(descs[v0 + i], p[i], e[i]); }
 		tp += p[i];
 		te += e[i];
 	}
@@ -144,9 +125,10 @@ __global__ __launch_bounds__(256) void k_scan_tiles(alpgpu_vector_desc* __restri
 
 // single workgroup of 1024 threads: exclusive scan of tile sums in place; totals + overflow flag
 __global__ __launch_bounds__(1024) void k_scan_totals(uint64_t* __restrict__ tile_sums, uint64_t n_tiles, uint64_t packed_capacity,
-                                                      uint64_t exc_capacity, uint64_t* __restrict__ totals) {
+                                                      uint64_t exc_capacity, uint64_t* __restrict__ totals, const uint64_t* __restrict__ gate) {
 	__shared__ uint64_t sp[1024], se[1024];
 	__shared__ uint64_t carry[2];
+	if (gate != nullptr && *gate == 0) { return; }
 	if (threadIdx.x == 0) { carry[0] = carry[1] = 0; }
 	__syncthreads();
 	for (uint64_t t0 = 0; t0 < n_tiles; t0 += 1024) {
@@ -192,13 +174,19 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
                                                                   alpgpu_vector_desc* __restrict__ descs,
                                                                   const uint64_t* __restrict__ tile_bases, uint8_t* __restrict__ packed,
                                                                   uint8_t* __restrict__ excs, const uint64_t* __restrict__ totals,
-                                                                  uint64_t n_vectors, const uint16_t* __restrict__ rd_order) {
+                                                                  uint64_t n_vectors, const uint16_t* __restrict__ rd_order, const uint64_t* __restrict__ gate) {
 	__shared__ EncodeLds lds[kWavesPerWg];
-	if (totals[2] != 0) { return; } // capacity overflow: write nothing (reported through alpgpu_column_totals)
+	if (gate != nullptr && *gate == 0) { return; }
 	const int      lane   = lane_id();
 	const int      wave   = wave_in_wg();
 	EncodeLds&     L      = lds[wave];
 	const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kWavesPerWg;
+	if (totals[2] != 0) { // capacity overflow (reported through alpgpu_column_totals): write no stream bytes, leave descriptors a decoder can follow
+		for (uint64_t v = static_cast<uint64_t>(blockIdx.x) * kWavesPerWg + wave; v < n_vectors; v += stride) {
+			if (lane == 0) { descs[v] = empty_descriptor(); }
+		}
+		return;
+	}
 	for (uint64_t v = static_cast<uint64_t>(blockIdx.x) * kWavesPerWg + wave; v < n_vectors; v += stride) {
 		const alpgpu_rowgroup_state* rgp  = rgs + v / kRowgroup;
 		alpgpu_vector_desc           d    = descs[v];
@@ -278,8 +266,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 // Status words are written with one agent-scope relaxed atomic store (the data IS the flag) and polled with agent-scope
 // relaxed atomic loads (cdna_hip_programming.md §6 G16, recipe R2).  Forward progress needs the predecessor tiles to be
 // resident or finished, which the in-order dispatch of a 1-D grid provides in practice but HIP does not promise:
-// every spin is bounded, and a stall sets totals[3] (reported as ALPGPU_ERR_HIP by alpgpu_column_totals; the two-pass
-// form is selectable with ALPGPU_OPT_ENCODE_TWO_PASS).  The field widths bound one launch to kFusedMaxVectors vectors;
+// every spin is bounded, a stall sets totals[3] and nothing of a stalled tile is written; the two-pass kernels enqueued behind
+// every single-pass encode (gated on that flag: launch_encode_recovery) then redo the column on the same stream.  The field widths bound one launch to kFusedMaxVectors vectors;
 // longer columns are chained launch by launch through totals[0..1].  Where a wavefront's time goes: profiles/r01_fused_phases.txt.
 __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double* __restrict__ in,
                                                                    const alpgpu_rowgroup_state* __restrict__ rgs,
@@ -287,7 +275,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
                                                                    uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                    uint64_t* __restrict__ totals, uint64_t packed_capacity,
                                                                    uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch,
-                                                                   const uint16_t* __restrict__ rd_order) {
+                                                                   const uint16_t* __restrict__ rd_order, uint32_t spin_limit) {
 	__shared__ EncodeLds lds[kFusedWaves];
 	__shared__ uint64_t  s_size[kFusedWaves]; // per vector: (packed units << 31) | exception units
 	__shared__ uint64_t  s_excl;              // tile's exclusive prefix in the same packing, or ~0 on a stall
@@ -323,15 +311,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
 	// that nothing but the ordered offset stands between the wait and the stores
 	const uint64_t base_p = totals[0], base_e = totals[1];
-#ifdef ALPGPU_FUSED_TIMING
-	unsigned long long t_prev_ = __builtin_readcyclecounter();
-#endif
 	if (live) {
 		x        = load_vector(in, v, lane);
-#ifdef ALPGPU_FUSED_TIMING
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-		ALPGPU_PHASE_MARK(0); // input load
 		d.scheme = rgp->scheme;
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
@@ -376,8 +357,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 		d.exc_cnt = static_cast<uint16_t>(cnt);
 	}
 	uint64_t my_p = 0, my_e = 0; // bytes
-	if (live) { desc_sizes(d, my_p, my_e); }
-	ALPGPU_PHASE_MARK(1); // encode arithmetic + staging
+	if (live) { record_sizes<8>(d, my_p, my_e); }
 	// post this vector's size; the last worker to arrive publishes the tile's aggregate (so successors never wait for
 	// this tile's own look-back), then everybody waits — on LDS words only — for the scout's exclusive prefix
 	if (lane == 0) {
@@ -422,7 +402,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 		});
 		wave_lds_sync();
 	}
-	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane); }
+	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
 	{
 		uint32_t spins = 0;
 		while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
@@ -430,7 +410,6 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 			__builtin_amdgcn_s_sleep(2);
 		}
 	}
-	ALPGPU_PHASE_MARK(2); // ordered offset: look-back (wave 0) / wait for it (others)
 	uint64_t local = 0;
 #pragma unroll
 	for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
@@ -443,8 +422,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	d.exc_off             = base_e + (pre & 0x7FFFFFFFull) * 8ull;
 	if (!live) { return; }
 	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) {
-		if (lane == 0) { __hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-		return; // this vector does not fit: report, write nothing past the buffers
+		// this vector does not fit: report, write nothing past the buffers, and leave a descriptor that a decoder can follow
+		// without leaving them (bit width 0, no exceptions: the column's content is unspecified, its extents are not)
+		if (lane == 0) {
+			__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			descs[v] = empty_descriptor();
+		}
+		return;
 	}
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
@@ -474,35 +458,15 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	}
 #endif
 	if (lane == 0) { descs[v] = d; }
-#ifdef ALPGPU_FUSED_TIMING
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-	ALPGPU_PHASE_MARK(3); // exception record + pack + stores
 }
 
-#ifdef ALPGPU_FUSED_TIMING
-extern "C" int alpgpu_debug_fused_phases(unsigned int* d_buffer) { // device buffer of n_vectors * 4 u32, or NULL to switch off
-	return hipMemcpyToSymbol(HIP_SYMBOL(g_fused_phase), &d_buffer, sizeof(d_buffer)) == hipSuccess ? 0 : -1;
-}
-extern "C" int alpgpu_debug_lookback_phases(unsigned int* d_buffer) { // device buffer of n_tiles * 4 u32
-	return hipMemcpyToSymbol(HIP_SYMBOL(g_lookback_phase), &d_buffer, sizeof(d_buffer)) == hipSuccess ? 0 : -1;
-}
-#endif
 
-// publishes the running totals after a fused launch (single thread; keeps totals[0..1] stable while the launch runs)
+// publishes the running totals after a fused launch (single thread; keeps totals[0..1] stable while the launch runs) and
+// latches the stall flag into totals[6], the gate of the recovery kernels (k_scan_totals clears totals[3] on its way)
 __global__ void k_fused_finish(uint64_t* __restrict__ totals) {
 	totals[0] = totals[4];
 	totals[1] = totals[5];
-}
-
-// One workgroup per kWavesPerWg consecutive vectors, handed out by the hardware dispatcher in order (the kernels' loops
-// then run once): measured 15-25 % more HBM bandwidth than a persistent grid-stride launch for this access pattern
-// (profiles/r01_membw2_waves_per_vector.txt).  ALPGPU_ENCODE_PERSISTENT=1 restores the capped grid for A/B runs.
-static unsigned grid_for(uint64_t n_vectors, int n_cus, int wgs_per_cu) {
-	const uint64_t need = (n_vectors + kWavesPerWg - 1) / kWavesPerWg;
-	static const bool persistent = std::getenv("ALPGPU_ENCODE_PERSISTENT") != nullptr;
-	const uint64_t cap  = persistent ? static_cast<uint64_t>(n_cus) * wgs_per_cu : (1ull << 30);
-	return static_cast<unsigned>(need < cap ? (need ? need : 1) : cap);
+	if (totals[3] != 0) { totals[6] = 1; }
 }
 
 uint64_t encode_workspace_bytes(uint64_t n_vectors) {
@@ -513,12 +477,14 @@ uint64_t encode_workspace_bytes(uint64_t n_vectors) {
 }
 
 int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col) {
-	// d_totals: [0] packed bytes, [1] exception bytes, [2] overflow, [3] look-back stall, [4..5] running totals of the launch in flight
+	// d_totals: [0] packed bytes, [1] exception bytes, [2] overflow, [3] look-back stall, [4..5] running totals of the launch in flight,
+	// [6] gate of the recovery kernels (a stall happened), [7] unused
 	return hipMemsetAsync(col->d_totals, 0, 64, stream) == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 // vectors [v_first, v_first + n_range): continues the streams where d_totals[0..1] say the previous range ended
-int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range) {
+int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
+                              bool force_stall) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
@@ -526,32 +492,46 @@ int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpg
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch, col->d_rd_order);
+		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit);
 		hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, stream, col->d_totals);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace) {
+int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall) {
 	if (launch_encode_reset_totals(stream, col) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
-	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors);
+	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors, force_stall);
 }
 
+// the scan of the two-pass form (shared with the float column kernels): descriptor sizes -> offsets, totals, overflow flag
+int launch_scan_offsets(hipStream_t stream, const alpgpu_column* col, uint64_t n_vectors, uint64_t* d_workspace, bool f32, const uint64_t* gate) {
+	const uint64_t n_tiles = (n_vectors + kScanTile - 1) / kScanTile;
+	if (f32) {
+		hipLaunchKernelGGL(k_scan_tiles<4>, dim3(static_cast<unsigned>(n_tiles)), dim3(256), 0, stream, col->d_vectors, n_vectors, d_workspace, gate);
+	} else {
+		hipLaunchKernelGGL(k_scan_tiles<8>, dim3(static_cast<unsigned>(n_tiles)), dim3(256), 0, stream, col->d_vectors, n_vectors, d_workspace, gate);
+	}
+	hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream, d_workspace, n_tiles, col->packed_capacity, col->exc_capacity, col->d_totals, gate);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// The two-pass form.  gate == nullptr: unconditionally (ALPGPU_OPT_ENCODE_TWO_PASS), one workgroup per kWavesPerWg vectors.
+// gate != nullptr: the recovery route behind a single-pass encode — a capped grid (the kernels stride over the column), so
+// that the four launches cost microseconds when the gate is closed, which is always unless the look-back stalled.
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
-                          int n_cus) {
+                          int n_cus, const uint64_t* gate) {
 	if (n_vectors == 0) {
-		(void)hipMemsetAsync(col->d_totals, 0, 64, stream);
+		if (gate == nullptr) { (void)hipMemsetAsync(col->d_totals, 0, 64, stream); }
 		return ALPGPU_OK;
 	}
-	const uint64_t n_tiles = (n_vectors + kScanTile - 1) / kScanTile;
 	const dim3     block(64 * kWavesPerWg);
-	hipLaunchKernelGGL(k_encode_analyze, dim3(grid_for(n_vectors, n_cus, 16)), block, 0, stream, d_in, col->d_rowgroups, col->d_vectors,
-	                   n_vectors);
-	hipLaunchKernelGGL(k_scan_tiles, dim3(static_cast<unsigned>(n_tiles)), dim3(256), 0, stream, col->d_vectors, n_vectors, d_workspace);
-	hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream, d_workspace, n_tiles, col->packed_capacity, col->exc_capacity,
-	                   col->d_totals);
-	hipLaunchKernelGGL(k_encode_pack, dim3(grid_for(n_vectors, n_cus, 16)), block, 0, stream, d_in, col->d_rowgroups, col->d_vectors,
-	                   d_workspace, col->d_packed, col->d_exc, col->d_totals, n_vectors, col->d_rd_order);
+	const uint64_t need = (n_vectors + kWavesPerWg - 1) / kWavesPerWg;
+	const uint64_t cap  = gate != nullptr ? static_cast<uint64_t>(n_cus) * 16 : (1ull << 30);
+	const dim3     grid(static_cast<unsigned>(need < cap ? need : cap));
+	hipLaunchKernelGGL(k_encode_analyze, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, n_vectors, gate);
+	if (launch_scan_offsets(stream, col, n_vectors, d_workspace, false, gate) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
+	hipLaunchKernelGGL(k_encode_pack, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, d_workspace, col->d_packed, col->d_exc, col->d_totals,
+	                   n_vectors, col->d_rd_order, gate);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

@@ -23,6 +23,29 @@ __device__ __forceinline__ uint64_t status_pack(uint64_t flag, uint64_t packed_u
 	return flag | (packed_units << 31) | exc_units;
 }
 
+// what a vector that did not fit its streams gets: a decoder stays inside the buffers (the column's content is unspecified)
+__device__ __forceinline__ alpgpu_vector_desc empty_descriptor() {
+	alpgpu_vector_desc z;
+	z.packed_off = z.exc_off = 0;
+	z.base                   = 0;
+	z.bw = z.e = z.f = z.lbw = 0;
+	z.exc_cnt                = 0;
+	z.scheme                 = ALPGPU_SCHEME_ALP;
+	return z;
+}
+
+// bytes a vector's record takes in the packed and in the exception stream; VALUE_BYTES = 8 (double column) or 4 (float column)
+template <int VALUE_BYTES>
+__device__ __forceinline__ void record_sizes(const alpgpu_vector_desc& d, uint64_t& packed, uint64_t& exc) {
+	if (d.scheme == ALPGPU_SCHEME_ALP) {
+		packed = 128ull * d.bw;
+		exc    = ((VALUE_BYTES + 2ull) * d.exc_cnt + 7ull) & ~7ull; // cnt x value bits, then cnt x u16 positions
+	} else {
+		packed = 128ull * (static_cast<uint64_t>(d.bw) + d.lbw);
+		exc    = (4ull * d.exc_cnt + 7ull) & ~7ull; // cnt x u16 left parts, then cnt x u16 positions
+	}
+}
+
 // ---- two-level form (default) -------------------------------------------------------------------------------------------
 // Measured on MI355X (tools/fused_phases.py, profiles/r01_fused_phases.txt): with the flat look-back below a wavefront spends
 // ~37 % of its life waiting for its offset, and wider windows or faster polling make it worse — agent-scope loads of status
@@ -37,15 +60,6 @@ __device__ __forceinline__ uint64_t status_pack(uint64_t flag, uint64_t packed_u
 // Exclusive prefix of a tile = base of its block + sizes of its predecessors in the block.  ~2 rounds and ~130 status loads
 // per tile instead of ~5 and ~320, and no positive feedback between look-back latency and look-back distance.
 constexpr int kBlockTiles = 64;
-#ifdef ALPGPU_FUSED_TIMING
-__device__ unsigned int* g_lookback_phase; // [n_tiles][4]: level-1 ticks, level-1 retries, level-2 ticks, level-2 retries
-#define ALPGPU_LB_NOTE(k, val)                                                                                          \
-	do {                                                                                                                \
-		if (lane == 0 && g_lookback_phase) { g_lookback_phase[4 * tile + (k)] = static_cast<unsigned int>(val); }        \
-	} while (0)
-#else
-#define ALPGPU_LB_NOTE(k, val)
-#endif
 
 __device__ __forceinline__ uint64_t status_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void     status_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -62,9 +76,11 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 
 // status: [gridDim.x] tile words followed by [ceil(gridDim.x / kBlockTiles)] block words, all zero at launch.
 // N_SIZES = vectors per tile (entries of s_size); s_count counts the tile's kFusedWaves wavefronts.
+// spin_limit: unsuccessful polls before the tile gives up (kSpinLimit; 0 makes every tile that has to wait give up at once —
+// the debug option that exercises the recovery route).
 template <int N_SIZES = kFusedWaves>
 __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
-                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
+                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane, uint32_t spin_limit = kSpinLimit) {
 	uint64_t*      bstatus = status + gridDim.x;
 	const uint64_t block   = tile / kBlockTiles;
 	const int      i       = static_cast<int>(tile % kBlockTiles);
@@ -72,7 +88,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	bool           stalled = false;
 	uint32_t       spins   = 0;
 	// the stall flag of another tile is a far-side read like the status words: looked at every 16th unsuccessful round only
-	auto give_up = [&]() { return ++spins > kSpinLimit || ((spins & 15u) == 0 && status_load(totals + 3) != 0); };
+	auto give_up = [&]() { return ++spins > spin_limit || ((spins & 15u) == 0 && status_load(totals + 3) != 0); };
 #ifdef ALPGPU_ABLATE_LOOKBACK // timing experiment: worst-case strides instead of the scan (the output is NOT compact)
 	if (lane == 0) {
 		*s_excl = status_pack(0, tile * N_SIZES * 66, tile * N_SIZES * 1280);
@@ -83,19 +99,12 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 
 	// level 1: the sizes of the i predecessors inside this block
 	uint64_t local = 0;
-#ifdef ALPGPU_FUSED_TIMING
-	const unsigned long long lb_t0 = __builtin_readcyclecounter();
-	unsigned                 lb_r1 = 0, lb_r2 = 0;
-#endif
 	// both levels' first rounds are issued together: one trip across the fabric instead of two when nothing is late
 	uint64_t first1 = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
 	uint64_t first2 = (block != 0 && static_cast<int64_t>(block) - 1 - lane >= 0) ? status_load(bstatus + (block - 1 - lane)) : kFlagPrefix;
 	bool     fresh1 = true, fresh2 = true;
 	if (i != 0) {
 		for (;;) {
-#ifdef ALPGPU_FUSED_TIMING
-			++lb_r1;
-#endif
 			const uint64_t st = fresh1 ? first1 : (lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate);
 			fresh1            = false;
 			if (__ballot((st >> 62) == 0) == 0) {
@@ -109,11 +118,6 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 			__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
 		}
 	}
-#ifdef ALPGPU_FUSED_TIMING
-	const unsigned long long lb_t1 = __builtin_readcyclecounter();
-	ALPGPU_LB_NOTE(0, lb_t1 - lb_t0);
-	ALPGPU_LB_NOTE(1, lb_r1);
-#endif
 	// a closing tile needs its own size as well (LDS only): it publishes the block's aggregate before looking further back
 	uint64_t aggregate = 0;
 	if (closes && !stalled) {
@@ -134,9 +138,6 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	if (block != 0 && !stalled) {
 		int64_t look = static_cast<int64_t>(block) - 1; // nearest block not yet accounted for
 		while (look >= 0) {
-#ifdef ALPGPU_FUSED_TIMING
-			++lb_r2;
-#endif
 			const int64_t  idx        = look - lane;
 			const uint64_t st         = fresh2 ? first2 : (idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix);
 			fresh2                    = false;
@@ -170,10 +171,6 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 			look -= 64;
 		}
 	}
-#ifdef ALPGPU_FUSED_TIMING
-	ALPGPU_LB_NOTE(2, __builtin_readcyclecounter() - lb_t1);
-	ALPGPU_LB_NOTE(3, lb_r2);
-#endif
 	// the other wavefronts add up the sizes posted before theirs once released: every one of them must have posted (LDS only)
 	if (!closes && !stalled) {
 		uint32_t lspins = 0;
@@ -205,92 +202,5 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 
 // words of status workspace one launch over n_tiles tiles needs (tile words + block words)
 __host__ __device__ inline uint64_t lookback_words(uint64_t n_tiles) { return n_tiles + (n_tiles + kBlockTiles - 1) / kBlockTiles; }
-
-// ---- flat form (kept for A/B runs: -DALPGPU_FLAT_LOOKBACK) ----------------------------------------------------------------
-// The look-back of one tile (run by wavefront 0 after it has posted its own size): finds the tile's exclusive prefix,
-// waits for the tile's aggregate, publishes the inclusive prefix and releases the workgroup through LDS.
-__device__ __forceinline__ void tile_lookback_flat(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
-                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane) {
-		uint64_t* my_status = status + tile;
-		uint64_t  excl      = 0;
-		bool      stalled   = false;
-#ifdef ALPGPU_FUSED_NO_LOOKBACK // timing experiment only: worst-case strides instead of the scan (output is NOT compact)
-		excl = status_pack(0, tile * kFusedWaves * 66, tile * kFusedWaves * 1280);
-		if (false) {
-#else
-		if (tile != 0) {
-#endif
-			int64_t  look  = static_cast<int64_t>(tile) - 1; // nearest tile not yet accounted for
-			uint32_t spins = 0;
-			while (look >= 0) {
-				uint64_t st[kLookWindow / 64];
-#pragma unroll
-				for (int k = 0; k < kLookWindow / 64; ++k) {
-					const int64_t idx = look - (lane + 64 * k);
-					st[k]             = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;
-				}
-				// entries are ordered nearest-first (k major): take everything up to and including the first prefix,
-				// provided nothing before it is still invalid; otherwise poll again
-				bool     done = false, retry = false;
-				uint64_t part = 0;
-#pragma unroll
-				for (int k = 0; k < kLookWindow / 64; ++k) {
-					if (!done && !retry) { // wave-uniform
-						const uint64_t fl         = st[k] >> 62;
-						const uint64_t has_prefix = __ballot(fl == 2);
-						const uint64_t invalid    = __ballot(fl == 0);
-						const int      first_p    = has_prefix ? __builtin_ctzll(has_prefix) : 64;
-						const uint64_t upto       = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull); // lanes 0..first_p
-						if (invalid & upto) {
-							retry = true;
-						} else {
-							part += (first_p == 64 || lane <= first_p) ? (st[k] & ~(3ull << 62)) : 0ull;
-							done = first_p != 64;
-						}
-					}
-				}
-				if (retry) {
-					if (++spins > kSpinLimit || __hip_atomic_load(totals + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-						stalled = true;
-						break;
-					}
-					__builtin_amdgcn_s_sleep(ALPGPU_LOOK_SLEEP);
-					continue;
-				}
-#pragma unroll
-				for (int dd = 32; dd >= 1; dd >>= 1) { part += static_cast<uint64_t>(__shfl_xor(static_cast<long long>(part), dd)); }
-				excl += part;
-				if (done) { break; }
-				look -= kLookWindow;
-			}
-		}
-		// the tile's own aggregate: wait (LDS only) until every worker has posted its size
-		uint32_t spins = 0;
-		while (__hip_atomic_load(s_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kFusedWaves) {
-			if (++spins > kSpinLimit) {
-				stalled = true;
-				break;
-			}
-			__builtin_amdgcn_s_sleep(2);
-		}
-		uint64_t aggregate = 0;
-#pragma unroll
-		for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
-		if (lane == 0) {
-			if (stalled) {
-				__hip_atomic_store(totals + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				*s_excl = ~0ull;
-			} else {
-				__hip_atomic_store(my_status, kFlagPrefix | (excl + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				*s_excl = excl;
-				if (tile == gridDim.x - 1) { // running totals of the column, published by k_fused_finish
-					const uint64_t incl = excl + aggregate;
-					totals[4]           = totals[0] + ((incl >> 31) & 0x7FFFFFFFull) * 128ull;
-					totals[5]           = totals[1] + (incl & 0x7FFFFFFFull) * 8ull;
-				}
-			}
-			__hip_atomic_store(s_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-}
 
 } // namespace alpgpu

@@ -114,7 +114,8 @@ typedef struct alpgpu_column {
 	uint64_t               packed_capacity; /* bytes; worst case n_vectors * 8448 */
 	uint8_t*               d_exc;           /* exception stream, 8-byte aligned */
 	uint64_t               exc_capacity;    /* bytes; worst case n_vectors * 10240 */
-	uint64_t*              d_totals;        /* [8]: packed bytes used, exception bytes used, overflow flag, encode stall flag, 4 scratch words */
+	uint64_t*              d_totals;        /* [8]: packed bytes used, exception bytes used, overflow flag, encode stall flag (always 0 after
+	                                           alpgpu_encode_*), 4 scratch words */
 	/* host-side hints (0 = unknown): stream sizes as last seen by the host.  Filled by alpgpu_column_totals and
 	 * alpgpu_column_from_blob; decode uses them only to pick its launch shape (ALPGPU_OPT_DECODE_VECTORS_PER_WG = 0 "auto") */
 	uint64_t               packed_bytes_hint;
@@ -147,8 +148,13 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 #define ALPGPU_OPT_DECODE_VECTORS_PER_WG 1
 #define ALPGPU_OPT_DECODE_PLAIN_STORES 2
 /* ALPGPU_OPT_ENCODE_TWO_PASS: 1 = analysis pass + scan + pack pass (reads the input twice) instead of the default
- * single-pass encode whose output offsets come from an in-kernel look-back; both give byte-identical columns. */
+ * single-pass encode whose output offsets come from an in-kernel look-back; both give byte-identical columns, double and
+ * float.  The single pass needs its predecessor workgroups to run; should its look-back ever give up (HIP promises no
+ * dispatch order), the two-pass kernels enqueued behind it on the same stream redo the column: callers see a complete column. */
 #define ALPGPU_OPT_ENCODE_TWO_PASS 3
+/* ALPGPU_OPT_DEBUG_FORCE_STALL: 1 = every look-back of the single pass that has to wait gives up at once (tests of the
+ * recovery route; the result is still a complete, byte-identical column). */
+#define ALPGPU_OPT_DEBUG_FORCE_STALL 4
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
@@ -181,7 +187,8 @@ int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, u
  * the caller): second-level sampling, encode + exception compaction, analyze_ffor, FFOR pack (ALP);
  * split + dictionary encode + FFOR pack of right/left (ALP_RD).  Single pass over the input; output
  * offsets are assigned in vector order.  Writes d_vectors, d_packed, d_exc, d_totals.  If a stream is too small the
- * overflow flag is raised, nothing is written past the buffers and the column content is unspecified. */
+ * overflow flag is raised, nothing is written past the buffers and the column content is unspecified — but every vector
+ * that did not fit gets an empty descriptor, so decoding such a column stays inside the buffers. */
 int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
 
 /* alpgpu_rowgroup_init_f64 followed by alpgpu_encode_vectors_f64 */

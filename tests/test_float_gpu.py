@@ -340,8 +340,9 @@ def test_float_container_round_trip_and_tail(ctx):
 def test_long_float_column_lookback_offsets(ctx, of32):
     col_np = datagen.mixed_column_f32(3000, seed=77, exc_rate=0.02, decimals_per_rowgroup=(1, 2))
     want = of32.encode_column(col_np)
-    if not (want["scheme"] == 2).all():
-        pytest.skip("column resolved to ALP_RD somewhere")
+    # (the two-decimal rowgroups of this float column resolve to ALP_RD: both schemes alternate along the 3000 vectors, which is
+    # what the ordered offsets have to get right)
+    assert (want["scheme"] == 2).sum() >= 1000 and (want["scheme"] == 1).sum() >= 1000
     dcol, x = gpu_encode(ctx, col_np)
     rg, vec, packed, exc = dcol.to_host()
     w_rg, w_vec, w_packed, w_exc = layout.compact(want, 4)
