@@ -71,6 +71,7 @@ _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
 OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL = 1, 2, 3, 4
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
+_sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
 _sig("alpgpu_use_own_stream", _int, _vp)
@@ -181,6 +182,10 @@ class Context:
 
     def synchronize(self):
         _check(lib.alpgpu_synchronize(self.h), "alpgpu_synchronize")
+
+    def decode_vectors_per_wg(self, col: "DeviceColumn") -> int:
+        """the launch shape decode() would use for this column now (vectors per decode workgroup)"""
+        return int(lib.alpgpu_decode_vectors_per_wg(self.h, C.byref(col.c), 1 if col.dtype == "f32" else 0))
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(128)

@@ -319,6 +319,13 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	return variant;
 }
 
+// what alpgpu_decode_f64 / _f32 would launch for this column right now (option + size hints): vectors per decode workgroup
+int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32) {
+	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
+	if (is_f32) { return ctx->decode_vpw ? ctx->decode_vpw : 2; }
+	return (decode_variant_for(ctx, col) & 1) ? 1 : 2;
+}
+
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }

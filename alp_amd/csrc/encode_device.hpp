@@ -212,9 +212,9 @@ struct AlpEncoded {
 // a software double->int64 conversion and its x86 range check).  For the verification, (double)(int64)(enc * 10^f) is the
 // correctly rounded value of an integer product that does not wrap when |enc * 10^f| < 2^63, i.e. exactly the IEEE product
 // r * 10^f of two exactly representable doubles (one multiply instead of a 64-bit integer multiply and a software
-// int64->double conversion).  A step in which any lane leaves these ranges (|t| >= 2^51, which includes +-Inf, or
-// |r * 10^f| >= 2^63) is redone for the whole wavefront with the literal arithmetic; NaN never asks
-// for that (its compares are false) and is an exception on both routes.  Results are bit-identical by construction.
+// int64->double conversion).  A step in which any lane has |t| >= 2^51 (which includes +-Inf), a NaN, or |r * 10^f| == 2^63 is
+// redone for the whole wavefront with the literal arithmetic; |r * 10^f| > 2^63 is an exception outright (argument at the
+// test).  Results are bit-identical by construction.
 __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int f, int lane, AlpEncoded& R) {
 	(void)lane; // every cross-lane step below is a ballot, a DPP move or a readlane
 	const double  exp10  = kExpArr[e];
@@ -246,12 +246,24 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 			int64_t      enc = static_cast<int64_t>(static_cast<uint64_t>(__double_as_longlong(u)) - 0x4338000000000000ull);
 			const double prod = r * fact_d;
 			double       dec  = prod * frac_e;
-			const bool   wide = __builtin_fabs(t) >= 0x1p51 || __builtin_fabs(prod) >= 0x1p63;
+			// |prod| > 2^63 (prod = fl(P), P = enc * 10^f exactly): the reference's int64 product wraps, and the wrapped value can
+			// never decode to v — for |P| < 2^64 it has the opposite sign of v and is not zero, for larger |P| its magnitude is below
+			// 2^63 while |v| 10^e > 0.96 * 2^64 — so the value is an exception without computing it.  Two-decimal values up to 10^5
+			// land here all the time: the reference's search gives them (e,f) = (14,12), and |v| >= 92 233.72 wraps.  Only
+			// |t| >= 2^51 (incl. Inf), NaN and |prod| == 2^63 exactly (P = -2^63 is representable) take the literal route.
+			const double ap   = __builtin_fabs(prod);
+			const bool   big  = !(ap < 0x1p63);
+			bool         over = false; // the product wraps for sure
+			bool         wide = !(__builtin_fabs(t) < 0x1p51);
+			if (__ballot(big) != 0) {
+				over = ap > 0x1p63;
+				wide = wide | (big & !over);
+			}
 			if (__ballot(wide) != 0) { // wave-uniform, rare: the literal path of alp_device.hpp
 				enc = cast64_x86(r);
 				dec = decode_value(enc, fact, frac_e);
 			}
-			const bool exc = (dec != vv) | (bits == 0x8000000000000000ull); // IEEE compare: NaN is always an exception
+			const bool exc = (dec != vv) | (bits == 0x8000000000000000ull) | over; // IEEE compare: NaN is always an exception
 			R.enc[m][j]    = enc;
 			R.ballot[m][j] = __ballot(exc);
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);

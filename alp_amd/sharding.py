@@ -49,3 +49,25 @@ def timed_steps(step, steps: int, warmup: int, device_sync, dist=None, device=No
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     return elapsed
+
+
+def concat_shards(shards):
+    """The only "exchange" of the sharded encode: given the per-rank outputs in rank order — tuples
+    (rowgroup states, vector descriptors, packed stream, exception stream) as numpy arrays, descriptors with the fields
+    `packed_off` / `exc_off` counted from the start of the rank's own streams — returns the same four arrays for the whole
+    column: streams concatenated, every rank's offsets shifted by the bytes of the ranks before it.  The result is byte for
+    byte what one GPU produces for the unsharded column (tests/test_sharding.py)."""
+    import numpy as np
+    rgs, vecs, packs, excs = [], [], [], []
+    p_off = e_off = 0
+    for rg, vec, packed, exc in shards:
+        v = vec.copy()
+        v["packed_off"] += np.uint64(p_off)
+        v["exc_off"] += np.uint64(e_off)
+        rgs.append(rg)
+        vecs.append(v)
+        packs.append(packed)
+        excs.append(exc)
+        p_off += packed.size
+        e_off += exc.size
+    return np.concatenate(rgs), np.concatenate(vecs), np.concatenate(packs), np.concatenate(excs)

@@ -4,20 +4,30 @@ decoded doubles per GPU and fraction of the HBM roofline, with encode GB/s and t
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--column-gb 100]
 
-Workload (BASELINE.json configs[1]): 1 Mi vectors (1024 doubles each, 8 GiB decoded) per GPU of synthetic decimal
-doubles, ALP-encoded, bit widths sweeping 1..53 across rowgroups (rowgroup r has bw = 1 + r mod 53), per-vector
-base = splitmix64(42, v) mod 2^bw, (f, e) = (min(12, floor((62-bw) log10 2)), f+2), no exceptions; packed words
-are uniform random bits (every bit pattern is a valid FFOR stream of uniform digits).  All inputs are resident in
-HBM before the timed region.  A "step" = one alpgpu_decode_f64 over the whole column.  N > 1: every rank owns its
-own column of the same size (weak scaling; vectors are independent, there is no collective on the data path).
+N = 1 (BASELINE.json configs[1]): 1 Mi vectors (1024 doubles each, 8 GiB decoded) of synthetic decimal doubles,
+ALP-encoded, bit widths sweeping 1..53 across rowgroups (rowgroup r has bw = 1 + r mod 53), per-vector
+base = splitmix64(42, v) mod 2^bw, (f, e) = (min(12, floor((62-bw) log10 2)), f+2), no exceptions; packed words are
+uniform random bits (every bit pattern is a valid FFOR stream of uniform digits).  All inputs are resident in HBM
+before the timed region.  A "step" = one alpgpu_decode_f64 over the whole column.  Extras: the per-bit-width sweep,
+exceptions, fused consumers, the encode legs (configs[2], configs[3]), the float path, and the reference's CPU encode
+and decode timed on the box's host cores.
+
+N > 1, or --column-gb G at any N (BASELINE.json configs[4]): ONE column of G GB (default 100) of doubles, sharded by
+whole rowgroups over the ranks (alp_amd/sharding.py; no collective on the data path).  Two legs under the same
+barrier + max-over-ranks clock: DECODE of the rank's shard of the configs[1] column (the headline `value`, so that it
+is the same metric at every N) and ENCODE (rowgroup init + vector encode) of the rank's shard of the configs[2] mixed
+column, generated on the device from global rowgroup-block seeds (the column is the same whatever N is), then
+decoded back and compared bit for bit with the input.  At N = 1 the shard is capped to what fits one GPU and
+`config.workload` says so.  `scaling` is "strong": the column is fixed, the shards shrink.
 
 One JSON line is printed by rank 0 (see the driver contract in the task description / DESIGN.md).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,9 +40,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from alp_amd import capi  # noqa: E402  (raises if libalpgpu.so is missing: there is no CPU fallback)
+from alp_amd.sharding import rowgroup_shard  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VEC = 1024
+RG = 100
 
 
 def splitmix64(x: np.ndarray) -> np.ndarray:
@@ -41,6 +53,10 @@ def splitmix64(x: np.ndarray) -> np.ndarray:
     z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
     z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
     return z ^ (z >> np.uint64(31))
+
+
+def lib_sha16() -> str:
+    return hashlib.sha256(open(capi.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=None, exc_per_vec: int = 0, first_vector: int = 0):
@@ -105,92 +121,245 @@ def time_launches(fn, iters: int, warmup: int):
     return float(np.median(ts)), float(ts.mean())
 
 
-def synthetic_input(kind: str, n_vectors: int, device, seed: int):
-    """device-side synthetic double columns for the encode legs"""
+# ---- synthetic inputs of the encode legs ------------------------------------------------------
+MIX_BLOCK_RG = 640  # rowgroups per generation block of the mixed column: blocks are aligned to GLOBAL rowgroup indices and
+#                     seeded by their index, so the column is the same however it is sharded
+
+
+def mixed_block(block: int, device, seed: int) -> torch.Tensor:
+    """rowgroups [block * MIX_BLOCK_RG, (block + 1) * MIX_BLOCK_RG) of the mixed column: round(x, d) with x ~ U(-1e5, 1e5),
+    d cycling 1, 2, 4 by (global) rowgroup; 1 % full-precision values (exceptions); 0.1 % specials (NaN, +-Inf, -0.0)"""
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    n = n_vectors * VEC
-    if kind == "rd":
-        return torch.rand(n, dtype=torch.float64, device=device, generator=g)
+    g.manual_seed(seed * 1_000_003 + block)
+    n = MIX_BLOCK_RG * RG * VEC
     x = (torch.rand(n, dtype=torch.float64, device=device, generator=g) - 0.5) * 2e5
-    out = torch.empty_like(x)
-    nrg = (n_vectors + 99) // 100
-    for d in (1, 2, 4):  # decimals cycle per rowgroup
-        sc = 10.0 ** d
-        idx = torch.arange(nrg, device=device)
-        sel = (idx % 3 == (1, 2, 4).index(d)).repeat_interleave(100 * VEC)[:n]
-        out[sel] = torch.round(x[sel] * sc) / sc
-    m = torch.rand(n, device=device, generator=g) < 0.01  # 1 % full-precision values -> exceptions
+    rg = torch.arange(block * MIX_BLOCK_RG, (block + 1) * MIX_BLOCK_RG, device=device)
+    sc = torch.tensor([10.0, 100.0, 10000.0], dtype=torch.float64, device=device)[rg % 3].repeat_interleave(RG * VEC)
+    out = torch.round(x * sc) / sc
+    del sc
+    m = torch.rand(n, device=device, generator=g) < 0.01
     out[m] = x[m] * 3.141592653589793
-    sp = torch.rand(n, device=device, generator=g) < 0.001  # 0.1 % specials
+    del m, x
+    sp = torch.rand(n, device=device, generator=g) < 0.001
     specials = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0], dtype=torch.float64, device=device)
     out[sp] = specials[torch.randint(0, 4, (int(sp.sum()),), device=device, generator=g)]
     return out
 
 
-def cpu_baseline_leg(col, vec, gpu_out, sample_vectors: int):
-    """Times the REFERENCE's CPU decode (falp + patch_exceptions; oracle/_ref, built from /root/reference in the build
-    container) on this box's host cores over a bounded sample of the same column, and uses its output to check the
-    GPU result bit for bit.  The only place bench.py touches oracle/."""
+def mixed_column_shard(first_vector: int, n_vectors: int, device, seed: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """vectors [first_vector, first_vector + n_vectors) of the (global) mixed column, block by block"""
+    if out is None:
+        out = torch.empty(n_vectors * VEC, dtype=torch.float64, device=device)
+    per = MIX_BLOCK_RG * RG
+    v = first_vector
+    while v < first_vector + n_vectors:
+        b = v // per
+        blk = mixed_block(b, device, seed)
+        lo = v - b * per
+        hi = min(per, first_vector + n_vectors - b * per)
+        out[(v - first_vector) * VEC:(v - first_vector + hi - lo) * VEC] = blk[lo * VEC:hi * VEC]
+        v += hi - lo
+        del blk
+    return out
+
+
+def synthetic_input(kind: str, n_vectors: int, device, seed: int):
+    """device-side synthetic double columns for the single-GPU encode legs"""
+    if kind == "rd":
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        return torch.rand(n_vectors * VEC, dtype=torch.float64, device=device, generator=g)
+    return mixed_column_shard(0, n_vectors, device, seed)
+
+
+# ---- the reference's CPU path on this box's host cores (the only place bench.py touches oracle/) ---------------------------
+def _cpu_runner():
     from oracle import pyoracle
-    kind, runner = None, None
     flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    model = next((line.split(":", 1)[1].strip() for line in flags.splitlines() if line.startswith("model name")), "")
     if pyoracle.Reference.available():
         path = pyoracle.REF_AVX512_SO if ("avx512dq" in flags and os.path.exists(pyoracle.REF_AVX512_SO)) else pyoracle.REF_SO
-        runner, kind = pyoracle.Reference(path), "reference"
-    else:
-        runner, kind = pyoracle.Oracle(), "port"
-    n = min(sample_vectors, vec.size)
-    end = int(vec["packed_off"][n - 1]) + 128 * int(vec["bw"][n - 1])
-    packed_host = col.packed[:end].cpu().numpy()
+        return pyoracle.Reference(path), "reference", model
+    return pyoracle.Oracle(), "port", model
+
+
+def _run_threads(work, nthreads):
+    res = [0.0] * nthreads
+    ths = [threading.Thread(target=lambda t=t: res.__setitem__(t, work(t))) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    return time.perf_counter() - t0, res
+
+
+def cpu_decode_baseline(ctx, col, vec, gpu_out, budget_s: float = 10.0):
+    """Times the REFERENCE's CPU decode (falp + patch_exceptions; oracle/_ref, built from /root/reference in the build
+    container) on this box's host cores and checks the GPU result against it bit for bit.  Sample: every 8th rowgroup of
+    the benchmark column (8 and 53 are coprime: every bit width 1..53 is in it) = ~131 k vectors = 1 GiB of decoded
+    doubles, DRAM-resident; all-cores: the sample's vectors split over the threads, each writing its own part of one
+    output buffer.  A second, cache-resident figure (the first 1024 vectors, every thread its own copy of the output)
+    is reported next to it."""
+    runner, kind, model = _cpu_runner()
+    n_rg = (vec.size + RG - 1) // RG
+    rgs = np.arange(0, n_rg, 8)
+    idx = (rgs[:, None] * RG + np.arange(RG)[None, :]).reshape(-1)
+    idx = idx[idx < vec.size]
+    n = idx.size
+    sv = vec[idx]
+    # the sampled vectors' packed words at a fixed stride of 1024 words (what the reference's buffers look like)
+    starts, sizes = sv["packed_off"].astype(np.int64), 128 * sv["bw"].astype(np.int64)
     packed = np.zeros((n, 1024), np.int64)
     p8 = packed.view(np.uint8).reshape(n, 8192)
-    for v in range(n):
-        b, o = int(vec["bw"][v]), int(vec["packed_off"][v])
-        p8[v, :128 * b] = packed_host[o:o + 128 * b]
-    bw, e, f, base = (np.ascontiguousarray(vec[k][:n]) for k in ("bw", "e", "f", "base"))
+    for r0 in range(0, n, RG):  # one device->host copy per sampled rowgroup (contiguous in the stream)
+        r1 = min(n, r0 + RG)
+        lo, hi = int(starts[r0]), int(starts[r1 - 1] + sizes[r1 - 1])
+        chunk = col.packed[lo:hi].cpu().numpy()
+        for v in range(r0, r1):
+            o = int(starts[v]) - lo
+            p8[v, : sizes[v]] = chunk[o:o + sizes[v]]
+    bw, e, f, base = (np.ascontiguousarray(sv[k]) for k in ("bw", "e", "f", "base"))
     cnt = np.zeros(n, np.uint16)
     exc = np.zeros((n, 8), np.float64)
     pos = np.zeros((n, 8), np.uint16)
     threads = max(1, len(os.sched_getaffinity(0)))
-    per = n  # every thread decodes the whole (shared, read-only) sample into its own output buffer
-    outs = [np.empty(per * 1024, np.float64) for _ in range(threads)]
+    out = np.empty(n * 1024, np.float64)
 
-    def work(t, reps, res):
-        res[t] = runner.time_falp_column(packed, 1024, bw, e, f, base, cnt, exc, pos, 8, per, outs[t], reps)
+    def sl(a, lo, hi):
+        return a[lo:hi]
 
-    def run(nthreads, reps):
-        res = [0.0] * nthreads
-        ths = [threading.Thread(target=work, args=(t, reps, res)) for t in range(nthreads)]
-        t0 = time.perf_counter()
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        return time.perf_counter() - t0, res
+    def one_pass(nthreads, reps):
+        bounds = np.linspace(0, n, nthreads + 1).astype(np.int64)
 
-    run(threads, 1)  # warm (page-faults the outputs)
-    wall1, _ = run(threads, 1)
-    reps = int(max(1, min(500, 8.0 / max(wall1, 1e-3))))
-    wall, _ = run(threads, reps)
-    all_cores = threads * per * 8192 * reps / wall / 1e9
-    r1 = max(1, reps // 2)
-    t1 = runner.time_falp_column(packed, 1024, bw, e, f, base, cnt, exc, pos, 8, per, outs[0], r1)
-    single = per * 8192 * r1 / t1 / 1e9
-    got = gpu_out[: per * 1024].cpu().numpy()
-    exact = bool(np.array_equal(got.view(np.uint64), outs[0].view(np.uint64)))
-    model = ""
-    for line in flags.splitlines():
-        if line.startswith("model name"):
-            model = line.split(":", 1)[1].strip()
-            break
+        def work(t):
+            lo, hi = int(bounds[t]), int(bounds[t + 1])
+            if hi <= lo:
+                return 0.0
+            return runner.time_falp_column(sl(packed, lo, hi), 1024, sl(bw, lo, hi), sl(e, lo, hi), sl(f, lo, hi), sl(base, lo, hi), sl(cnt, lo, hi),
+                                           sl(exc, lo, hi), sl(pos, lo, hi), 8, hi - lo, out[lo * 1024:hi * 1024], reps)
+        return _run_threads(work, nthreads)
+
+    t1, _ = one_pass(1, 1)  # single thread, also page-faults the output and produces the values for the bit check
+    got = gpu_out.view(-1, 1024)[torch.from_numpy(idx).to(gpu_out.device)].cpu().numpy()
+    exact = bool(np.array_equal(got.view(np.uint64).reshape(-1), out.view(np.uint64)))
+    widths = sorted(set(int(b) for b in bw))
+    t1b, _ = one_pass(1, 1)
+    single = n * 8192 / min(t1, t1b) / 1e9
+    wall, _ = one_pass(threads, 1)
+    reps = int(max(1, min(200, budget_s * 0.5 / max(wall, 1e-3))))
+    wall, _ = one_pass(threads, reps)
+    all_cores = n * 8192 * reps / wall / 1e9
+    # cache-resident variant (what round 1 reported): 1024 vectors, private outputs
+    m = min(1024, n)
+    outs = [np.empty(m * 1024, np.float64) for _ in range(threads)]
+
+    def cwork(t, reps_):
+        return runner.time_falp_column(packed[:m], 1024, bw[:m], e[:m], f[:m], base[:m], cnt[:m], exc[:m], pos[:m], 8, m, outs[t], reps_)
+    w1, _ = _run_threads(lambda t: cwork(t, 2), threads)
+    creps = int(max(2, min(500, budget_s * 0.25 / max(w1 / 2, 1e-4))))
+    wc, _ = _run_threads(lambda t: cwork(t, creps), threads)
+    cache_all = threads * m * 8192 * creps / wc / 1e9
     return {
         "value": round(all_cores, 3), "unit": "GB/s decoded doubles", "cores": threads, "kind": kind,
-        "sample": f"falp+patch_exceptions on the first {per} vectors of the same column ({per * 8 // 1024} MiB decoded per pass per "
-                  f"thread, private output buffers), {reps} passes, {threads} host threads ({os.path.basename(runner.path)}; "
-                  f"single thread {single:.2f} GB/s; cpu: {model})",
-        "single_thread_value": round(single, 3), "gpu_matches_cpu_bit_exact": exact,
+        "sample": f"falp+patch_exceptions on every 8th rowgroup of the same column ({n} vectors = {n * 8 // 1024} MiB decoded, bit widths "
+                  f"{widths[0]}..{widths[-1]} all present, DRAM-resident, one shared output buffer), {reps} passes, {threads} host threads "
+                  f"({os.path.basename(runner.path)}; cpu: {model})",
+        "single_thread_value": round(single, 3), "cache_resident_all_cores_value": round(cache_all, 3),
+        "cache_resident_sample": f"first {m} vectors ({m * 8 // 1024} MiB per thread, private outputs), {creps} passes",
+        "gpu_matches_cpu_bit_exact": exact, "bit_widths_checked": len(widths),
     }
+
+
+def cpu_encode_baseline(x_gpu: torch.Tensor, ecol, budget_s: float = 10.0):
+    """The reference's CPU ENCODE (encoder::init per rowgroup, then encode + analyze_ffor + ffor per vector — the loop of
+    publication/source_code/bench_speed/bench_alp_encode.cpp:19-37 and test/test_alp_sample.cpp:137-166) on a DRAM-resident
+    1 GiB slice of the same mixed column: single thread, and all host cores over disjoint whole-rowgroup ranges."""
+    runner, kind, model = _cpu_runner()
+    if kind != "reference":
+        return {"kind": "port", "note": "oracle/_ref is not on this box; the C restatement has no encode timing loop"}
+    n = min(131_000, x_gpu.numel() // VEC // RG * RG)  # whole rowgroups, ~1 GiB
+    col = x_gpu[: n * VEC].cpu().numpy()
+    t1, sum_bw = runner.time_encode_column(col, n, 1)
+    single = n * 8192 / t1 / 1e9
+    # sum of the bit widths the reference chose == the GPU's over the same vectors (a cheap cross-check inside the bench)
+    gv = ecol.vectors[: n * 32].cpu().numpy().view(capi.VECTOR_DTYPE)
+    gpu_sum = int(gv["bw"].astype(np.int64).sum() + gv["lbw"].astype(np.int64).sum())
+    threads = max(1, len(os.sched_getaffinity(0)))
+    n_rg = n // RG
+    threads = min(threads, n_rg)
+    bounds = (np.linspace(0, n_rg, threads + 1).astype(np.int64)) * RG
+
+    def work(t, reps):
+        lo, hi = int(bounds[t]), int(bounds[t + 1])
+        return runner.time_encode_column(col[lo * VEC:hi * VEC], hi - lo, reps)[0] if hi > lo else 0.0
+    wall, _ = _run_threads(lambda t: work(t, 1), threads)
+    reps = int(max(1, min(100, budget_s * 0.6 / max(wall, 1e-3))))
+    wall, _ = _run_threads(lambda t: work(t, reps), threads)
+    return {"value": round(n * 8192 * reps / wall / 1e9, 3), "unit": "GB/s input doubles", "cores": threads, "kind": kind,
+            "single_thread_value": round(single, 3),
+            "sample": f"encoder::init + encode + analyze_ffor + ffor on the first {n} vectors ({n * 8 // 1024} MiB, DRAM-resident) of the mixed column, "
+                      f"{reps} passes, {threads} host threads over disjoint rowgroup ranges ({os.path.basename(runner.path)}; cpu: {model})",
+            "gpu_bit_width_sum_matches_cpu": bool(gpu_sum == sum_bw)}
+
+
+# ---- timed legs -------------------------------------------------------------------------------------------------------
+class Clock:
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # average step duration (HIP events, launch stream)
+        if self.dist is not None:
+            t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed, kern_ms = float(t[0]), float(t[1])
+        return elapsed, kern_ms
+
+    def total(self, x: int) -> int:
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=self.dev)
+        self.dist.all_reduce(t)
+        return int(t[0])
+
+
+def encode_alg_bytes(n, pb, eb):
+    """read 8192 per vector once, write the packed words, the exception records and 13 B of metadata"""
+    return n * 8192 + pb + eb + 13 * n
+
+
+def traffic_from_profile(result, n):
+    """roofline.traffic = HBM bytes per launch from the PMC counters — only from a profile taken with THIS library build"""
+    pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        t = json.load(open(pmc))
+        if t.get("vectors") == n and t.get("kernel") == "k_decode_column" and t.get("lib_sha16") == lib_sha16():
+            result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = t.get("source")
+        else:
+            result["roofline"]["traffic_note"] = "profiles/hbm_traffic.json was taken with another build or size of the library: not quoted"
+    except Exception:
+        pass
 
 
 def main():
@@ -198,8 +367,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps first (the first ~10 launches after an idle gap run 3-30 %% slower: tools/launch_trend.py)")
-    ap.add_argument("--vectors", type=int, default=1 << 20, help="vectors per GPU (default 1 Mi = 8 GiB decoded)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the per-bit-width sweep, the encode legs and the CPU baseline")
+    ap.add_argument("--vectors", type=int, default=1 << 20, help="N = 1 headline: vectors of the configs[1] column (default 1 Mi = 8 GiB decoded)")
+    ap.add_argument("--column-gb", type=float, default=None, help="configs[4]: size of the ONE column that is sharded over the ranks (default 100 when N > 1)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the per-bit-width sweep, the encode legs and the CPU baselines")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,178 +384,220 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     ctx = capi.Context(local_rank)  # launches on torch's current stream of this device
+    clock = Clock(dist, dev)
 
-    # the global column has world * vectors vectors; this rank decodes its contiguous whole-rowgroup shard of it
-    from alp_amd.sharding import rowgroup_shard
-    first_vector, n = rowgroup_shard(world * args.vectors, rank, world)
-    col, vec, alg_bytes = build_decode_column(n, local_rank, seed=42, first_vector=first_vector)
-    out = torch.empty(n * VEC, dtype=torch.float64, device=dev)
-
-    def step():
-        ctx.decode(col, out)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # average launch duration (HIP events, launch stream)
-    if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kern_ms = float(t[0]), float(t[1])
-
-    decoded_bytes = n * 8192
-    if dist is not None:  # shards differ by at most one rowgroup; sum the actual sizes
-        tb = torch.tensor([decoded_bytes], dtype=torch.int64, device=dev)
-        dist.all_reduce(tb)
-        total_decoded = int(tb[0])
+    sharded = world > 1 or args.column_gb is not None
+    if sharded:
+        result = sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev)
     else:
-        total_decoded = decoded_bytes
-    value = total_decoded * args.steps / elapsed / 1e9
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    result = {
-        "metric": "ALP fused decode (falp + patch) throughput, decoded doubles",
-        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "falp fused decode, synthetic decimal doubles, 1024-value vectors, bit-width sweep 1-53 across rowgroups, "
-                               "no exceptions (BASELINE.json configs[1])",
-                   "vectors_per_gpu": n, "decoded_bytes_per_gpu": decoded_bytes,
-                   "decode_launch_shape": "auto from the column's size hints (this column: 1 vector per 4-wave workgroup)", "parallelism": f"{world} independent shards (no collective)"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "k_decode_column", "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
-        "per_gpu_value": round(decoded_bytes * args.steps / elapsed / 1e9, 2),
-    }
-    pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            t = json.load(open(pmc))
-            if t.get("vectors") == n and t.get("kernel") == "k_decode_column":
-                result["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = t.get("source")
-        except Exception:
-            pass
-
-    if rank == 0 and world == 1 and not args.no_extras:
-        extras = {}
-        # per-bit-width sweep at the FULL column size (1 Mi vectors): smaller columns leave the packed stream resident in
-        # the 256 MiB Infinity Cache across launches and overstate narrow widths by up to 1.8x (profiles/r01_time_one.txt)
-        ns = n
-        sweep = {}
-        for bw in (1, 2, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 53):
-            c, _, ab = build_decode_column(ns, local_rank, seed=7, bw_of_rowgroup=bw)
-            med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
-            sweep[str(bw)] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
-            del c
-        extras["decode_sweep_by_bit_width"] = sweep
-        # 2 % exceptions (second run) and the 2-vectors-per-workgroup tuning option, which keeps twice the
-        # bytes in flight: better for narrow widths and for vectors with exceptions, worse for wide ones
-        exc_cases = {}
-        for label, bw_, exc_ in (("bw16_exc0", 16, 0), ("bw16_exc20", 16, 20), ("bw28_exc10", 28, 10), ("bw8_exc0", 8, 0)):
-            c, _, ab = build_decode_column(ns, local_rank, seed=8, bw_of_rowgroup=bw_, exc_per_vec=exc_)
-            row = {}
-            for vpw in (1, 2):
-                ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
-                med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
-                row[f"vectors_per_wg_{vpw}"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
-            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
-            med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
-            row["auto"] = {"decoded_GBps": round(ns * 8192 / med / 1e6, 1), "roofline_frac": round(ab / med / 1e6 / HBM_PEAK_GBPS, 4)}
-            exc_cases[label] = row
-            del c
-        extras["decode_exceptions_and_tuning"] = exc_cases
-        # decode fused into a SUM consumer: the 8 KiB per vector of decoded doubles never reach HBM
-        sums = torch.empty(n, dtype=torch.float64, device=dev)
-        med, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 10)
-        read_bytes = alg_bytes - n * 8192 + n * 8
-        extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
-                                      "roofline_frac_algorithmic": round(read_bytes / med / 1e6 / HBM_PEAK_GBPS, 4),
-                                      "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector"}
-        del sums
-        # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
-        for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
-            ne = n  # BASELINE.json configs[2] / [3]: 1 Mi vectors
-            x = synthetic_input(kind, ne, dev, seed=42)
-            ecol = capi.DeviceColumn(ne, local_rank)
-            med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
-            pb, eb, ov = ctx.column_totals(ecol)
-            dmed, _ = time_launches(lambda: ctx.decode(ecol, out), 7, 10)
-            rt = bool(torch.equal(out[: ne * VEC].view(torch.int64), x.view(torch.int64)))
-            extras[label] = {"input_GBps": round(ne * 8192 / med / 1e6, 1), "ms": round(med, 3), "vectors": ne,
-                             "compressed_bits_per_value": round((pb + eb + 32 * ne) * 8 / (ne * VEC), 2),
-                             "roofline_frac_algorithmic": round((ne * 8192 + pb + eb + 13 * ne) / med / 1e6 / HBM_PEAK_GBPS, 4),
-                             "decode_GBps": round(ne * 8192 / dmed / 1e6, 1), "gpu_roundtrip_bit_exact": rt}
-            del x, ecol
-        # a measured ceiling next to the nominal 8 TB/s: device-to-device copy of the 8 GiB output buffer
-        # (torch's copy kernel: 1 read + 1 write per byte) — what a plain streaming kernel reaches on this box today
-        src = torch.empty_like(out)
-        cmed, _ = time_launches(lambda: out.copy_(src), 7, 10)
-        copy_gbps = 2 * out.numel() * 8 / cmed / 1e6
-        extras["measured_copy_ceiling"] = {"GBps_read_plus_write": round(copy_gbps, 1), "frac_of_nominal_peak": round(copy_gbps / HBM_PEAK_GBPS, 4),
-                                           "decode_achieved_vs_copy": round(achieved / copy_gbps, 4),
-                                           "note": "torch tensor.copy_ of 8 GiB device to device, median of 7 after 10 warm-up copies"}
-        del src
-        # and a write-only one: the narrow bit widths of the sweep are almost pure output traffic
-        fmed, _ = time_launches(lambda: out.fill_(1.0), 7, 10)
-        fill_gbps = out.numel() * 8 / fmed / 1e6
-        extras["measured_fill_ceiling"] = {"GBps_write": round(fill_gbps, 1), "frac_of_nominal_peak": round(fill_gbps / HBM_PEAK_GBPS, 4),
-                                           "note": "torch tensor.fill_ of 8 GiB, median of 7 after 10 warm-up fills"}
-        # single precision: alpgpu_encode_f32 / alpgpu_decode_f32 on 1 Mi float vectors (4 GiB decoded)
-        fl = {}
-        outf = out.view(torch.float32)[: n * VEC]
-        for kind in ("decimal_mixed", "rd"):
-            g = torch.Generator(device=dev)
-            g.manual_seed(43)
-            if kind == "rd":
-                xf = torch.rand(n * VEC, dtype=torch.float32, device=dev, generator=g)
-            else:  # one- and two-decimal values in +-1000 (cycling per rowgroup), 1 % full-precision values, 0.1 % specials
-                xd = (torch.rand(n * VEC, dtype=torch.float64, device=dev, generator=g) - 0.5) * 2e3
-                sc = torch.where((torch.arange((n + 99) // 100, device=dev) % 2 == 0), 10.0, 100.0).to(torch.float64).repeat_interleave(100 * VEC)[: n * VEC]
-                xf = (torch.round(xd * sc) / sc).to(torch.float32)
-                m = torch.rand(n * VEC, device=dev, generator=g) < 0.01
-                xf[m] = (xd[m] * 3.141592653589793).to(torch.float32)
-                sp = torch.rand(n * VEC, device=dev, generator=g) < 0.001
-                specials = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0], dtype=torch.float32, device=dev)
-                xf[sp] = specials[torch.randint(0, 4, (int(sp.sum()),), device=dev, generator=g)]
-                del xd, sc, m, sp
-            fcol = capi.DeviceColumn(n, local_rank, dtype="f32")
-            emed, _ = time_launches(lambda: ctx.encode(xf, fcol), 3, 1)
-            pb, eb, ov = ctx.column_totals(fcol)
-            dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
-            rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
-            fsums = torch.empty(n, dtype=torch.float64, device=dev)
-            smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)
-            del fsums
-            fl[kind] = {"vectors": n, "encode_input_GBps": round(n * 4096 / emed / 1e6, 1), "encode_ms": round(emed, 3),
-                        "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
-                        "decode_GBps_decoded_floats": round(n * 4096 / dmed / 1e6, 1), "decode_ms": round(dmed, 3),
-                        "decode_roofline_frac_algorithmic": round((n * (4096 + 13) + pb + eb) / dmed / 1e6 / HBM_PEAK_GBPS, 4),
-                        "decode_sum_fused_ms": round(smed, 3), "gpu_roundtrip_bit_exact": rt}
-            del xf, fcol
-        extras["float_path"] = fl
-        result["extras"] = extras
-        ctx.decode(col, out)
-        torch.cuda.synchronize()
-        result["cpu_baseline"] = cpu_baseline_leg(col, vec, out, sample_vectors=1024)
+        result = single_gpu_bench(args, ctx, clock, local_rank, dev)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def headline(value, world, args, elapsed, kern_ms, alg_bytes, decoded_bytes_rank, workload, scaling, extra_config):
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    cfg = {"workload": workload}
+    cfg.update(extra_config)
+    return {
+        "metric": "ALP fused decode (falp + patch) throughput, decoded doubles",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "k_decode_column", "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "rank 0's kernel; achieved = algorithmic bytes of its launch / its average launch duration (max over ranks)"},
+        "per_gpu_value": round(decoded_bytes_rank * args.steps / elapsed / 1e9, 2),
+    }
+
+
+# ---- configs[4]: one column sharded over the ranks -------------------------------------------------------------------------
+def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
+    gb = args.column_gb if args.column_gb is not None else 100.0
+    total_vectors = int(gb * 1e9 / 8192) // RG * RG
+    first, n = rowgroup_shard(total_vectors, rank, world)
+    note = ""
+    free, _ = torch.cuda.mem_get_info(dev)
+    fit = int(free * 0.30 / 8192) // RG * RG  # input + output + the compressed column (and generator scratch) must fit
+    if n > fit:  # (N = 1 with a 100 GB column, or a small GPU): the largest shard that fits, and say so
+        note = f"; rank shards capped from {n} to {fit} vectors to fit {free / 2**30:.0f} GiB of free HBM"
+        n = fit
+    # ---- decode leg: the rank's shard of the configs[1] column
+    col, vec, alg_bytes = build_decode_column(n, local_rank, seed=42, first_vector=first)
+    out = torch.empty(n * VEC, dtype=torch.float64, device=dev)
+    elapsed, kern_ms = clock.run(lambda: ctx.decode(col, out), args.steps, args.warmup)
+    shape = ctx.decode_vectors_per_wg(col)
+    total_decoded = clock.total(n * 8192)
+    value = total_decoded * args.steps / elapsed / 1e9
+    result = headline(value, world, args, elapsed, kern_ms, alg_bytes, n * 8192,
+                      f"BASELINE.json configs[4]: one {total_vectors * 8192 / 1e9:.1f} GB column of doubles sharded by whole rowgroups over {world} GPU(s){note}; "
+                      "value = decode of each rank's shard of the configs[1] column (bit widths 1-53 by global rowgroup, no exceptions); "
+                      "encode of the rank's shard of the configs[2] mixed column in `encode`", "strong",
+                      {"column_vectors": total_vectors, "vectors_per_gpu": n, "decoded_bytes_per_gpu": n * 8192,
+                       "decode_launch_shape": f"{shape} vector(s) per 4-wave workgroup (chosen from the column's size hints)",
+                       "parallelism": f"{world} whole-rowgroup shards, no collective on the data path"})
+    del col
+    # ---- encode leg: the rank's shard of the mixed column, generated on the device; round trip checked at full size
+    x = mixed_column_shard(first, n, dev, seed=42)
+    ecol = capi.DeviceColumn(n, local_rank, packed_capacity=int(n * 8192 * 0.60) + 4096, exc_capacity=int(n * 8192 * 0.15) + 4096)
+    e_steps = max(3, min(args.steps, 10))
+    e_elapsed, e_ms = clock.run(lambda: ctx.encode(x, ecol), e_steps, 2)
+    pb, eb, ov = ctx.column_totals(ecol)
+    d_elapsed, d_ms = clock.run(lambda: ctx.decode(ecol, out), e_steps, 3)
+    rt = bool(torch.equal(out.view(torch.int64), x.view(torch.int64)))
+    rt_all = clock.total(1 if rt else 0) == (world if clock.dist is not None else 1)
+    total_in = clock.total(n * 8192)
+    e_alg = encode_alg_bytes(n, pb, eb)
+    result["encode"] = {
+        "workload": "rowgroup init + vector encode of the rank's shard of the mixed column (round(x, d), d in {1,2,4} by rowgroup, 1 % full-precision "
+                    "values, 0.1 % specials; the reference's search picks (14,12)-like pairs whose int64 product wraps for |v| >= 92233.72: 8-10 % exceptions)",
+        "value": round(total_in * e_steps / e_elapsed / 1e9, 2), "unit": "GB/s input doubles (whole job)", "per_gpu_value": round(n * 8192 * e_steps / e_elapsed / 1e9, 2),
+        "ms_per_step": round(e_elapsed / e_steps * 1e3, 4), "steps": e_steps,
+        "roofline": {"bound": "hbm", "achieved": round(e_alg / e_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(e_alg / e_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                     "kernels": "k_rowgroup_init + k_encode_fused (+ gated recovery launches)", "ms": round(e_ms, 4), "algorithmic_bytes_per_step": e_alg},
+        "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2), "overflow": int(ov),
+        "decode_of_the_encoded_shard": {"value": round(total_in * e_steps / d_elapsed / 1e9, 2), "unit": "GB/s decoded doubles (whole job)",
+                                        "roofline_frac_algorithmic": round((n * 8192 + pb + eb + 13 * n) / d_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+        "roundtrip_bit_exact_all_ranks": bool(rt_all),
+    }
+    return result
+
+
+# ---- N = 1: configs[1] headline + extras -----------------------------------------------------------------------------------
+def single_gpu_bench(args, ctx, clock, local_rank, dev):
+    n = args.vectors
+    col, vec, alg_bytes = build_decode_column(n, local_rank, seed=42)
+    out = torch.empty(n * VEC, dtype=torch.float64, device=dev)
+    elapsed, kern_ms = clock.run(lambda: ctx.decode(col, out), args.steps, args.warmup)
+    shape = ctx.decode_vectors_per_wg(col)
+    value = n * 8192 * args.steps / elapsed / 1e9
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    result = headline(value, 1, args, elapsed, kern_ms, alg_bytes, n * 8192,
+                      "falp fused decode, synthetic decimal doubles, 1024-value vectors, bit-width sweep 1-53 across rowgroups, no exceptions (BASELINE.json configs[1])",
+                      "weak", {"vectors_per_gpu": n, "decoded_bytes_per_gpu": n * 8192,
+                               "decode_launch_shape": f"{shape} vector(s) per 4-wave workgroup (chosen from the column's size hints)",
+                               "parallelism": "1 shard (python bench.py --gpus N shards ONE column over N ranks: configs[4])"})
+    traffic_from_profile(result, n)
+    if args.no_extras:
+        return result
+
+    def frac(bytes_, ms):
+        return round(bytes_ / ms / 1e6 / HBM_PEAK_GBPS, 4)
+
+    extras = {}
+    # per-bit-width sweep at the FULL column size (1 Mi vectors): smaller columns leave the packed stream resident in
+    # the 256 MiB Infinity Cache across launches and overstate narrow widths by up to 1.8x (profiles/r01_time_one.txt)
+    sweep = {}
+    for bw in (1, 2, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 53):
+        c, _, ab = build_decode_column(n, local_rank, seed=7, bw_of_rowgroup=bw)
+        med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
+        sweep[str(bw)] = {"decoded_GBps": round(n * 8192 / med / 1e6, 1), "roofline_frac": frac(ab, med), "vectors_per_wg": ctx.decode_vectors_per_wg(c)}
+        del c
+    extras["decode_sweep_by_bit_width"] = sweep
+    # 2 % exceptions (second run) and the 2-vectors-per-workgroup tuning option, which keeps twice the
+    # bytes in flight: better for narrow widths and for vectors with exceptions, worse for wide ones
+    exc_cases = {}
+    for label, bw_, exc_ in (("bw16_exc0", 16, 0), ("bw16_exc20", 16, 20), ("bw28_exc10", 28, 10), ("bw8_exc0", 8, 0)):
+        c, _, ab = build_decode_column(n, local_rank, seed=8, bw_of_rowgroup=bw_, exc_per_vec=exc_)
+        row = {}
+        for vpw in (1, 2):
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+            med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
+            row[f"vectors_per_wg_{vpw}"] = {"decoded_GBps": round(n * 8192 / med / 1e6, 1), "roofline_frac": frac(ab, med)}
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+        med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
+        row["auto"] = {"decoded_GBps": round(n * 8192 / med / 1e6, 1), "roofline_frac": frac(ab, med), "vectors_per_wg": ctx.decode_vectors_per_wg(c)}
+        exc_cases[label] = row
+        del c
+    extras["decode_exceptions_and_tuning"] = exc_cases
+    # decode fused into a SUM consumer: the 8 KiB per vector of decoded doubles never reach HBM
+    sums = torch.empty(n, dtype=torch.float64, device=dev)
+    med, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 10)
+    read_bytes = alg_bytes - n * 8192 + n * 8
+    extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
+                                  "roofline_frac_algorithmic": frac(read_bytes, med),
+                                  "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector"}
+    del sums
+    # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
+    enc_cpu = None
+    for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
+        x = synthetic_input(kind, n, dev, seed=42)
+        ecol = capi.DeviceColumn(n, local_rank)
+        med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
+        imed, _ = time_launches(lambda: ctx.rowgroup_init(x, ecol), 5, 1)
+        ctx.encode(x, ecol)
+        pb, eb, ov = ctx.column_totals(ecol)
+        dmed, _ = time_launches(lambda: ctx.decode(ecol, out), 7, 10)
+        rt = bool(torch.equal(out[: n * VEC].view(torch.int64), x.view(torch.int64)))
+        extras[label] = {"input_GBps": round(n * 8192 / med / 1e6, 1), "ms": round(med, 3), "rowgroup_init_ms": round(imed, 3), "vectors": n,
+                         "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
+                         "roofline_frac_algorithmic": frac(encode_alg_bytes(n, pb, eb), med),
+                         "decode_GBps": round(n * 8192 / dmed / 1e6, 1), "decode_roofline_frac_algorithmic": frac(encode_alg_bytes(n, pb, eb), dmed),
+                         "decode_vectors_per_wg": ctx.decode_vectors_per_wg(ecol), "gpu_roundtrip_bit_exact": rt}
+        if kind == "mixed":
+            enc_cpu = cpu_encode_baseline(x, ecol)
+        del x, ecol
+    # a measured ceiling next to the nominal 8 TB/s: device-to-device copy of the 8 GiB output buffer
+    # (torch's copy kernel: 1 read + 1 write per byte) — what a plain streaming kernel reaches on this box today
+    src = torch.empty_like(out)
+    cmed, _ = time_launches(lambda: out.copy_(src), 7, 10)
+    copy_gbps = 2 * out.numel() * 8 / cmed / 1e6
+    extras["measured_copy_ceiling"] = {"GBps_read_plus_write": round(copy_gbps, 1), "frac_of_nominal_peak": round(copy_gbps / HBM_PEAK_GBPS, 4),
+                                       "decode_achieved_vs_copy": round(achieved / copy_gbps, 4),
+                                       "note": "torch tensor.copy_ of 8 GiB device to device, median of 7 after 10 warm-up copies"}
+    del src
+    # and a write-only one: the narrow bit widths of the sweep are almost pure output traffic
+    fmed, _ = time_launches(lambda: out.fill_(1.0), 7, 10)
+    fill_gbps = out.numel() * 8 / fmed / 1e6
+    extras["measured_fill_ceiling"] = {"GBps_write": round(fill_gbps, 1), "frac_of_nominal_peak": round(fill_gbps / HBM_PEAK_GBPS, 4),
+                                       "note": "torch tensor.fill_ of 8 GiB, median of 7 after 10 warm-up fills"}
+    # single precision: alpgpu_encode_f32 / alpgpu_decode_f32 on 1 Mi float vectors (4 GiB decoded)
+    fl = {}
+    outf = out.view(torch.float32)[: n * VEC]
+    for kind in ("decimal_mixed", "rd"):
+        g = torch.Generator(device=dev)
+        g.manual_seed(43)
+        if kind == "rd":
+            xf = torch.rand(n * VEC, dtype=torch.float32, device=dev, generator=g)
+        else:  # one- and two-decimal values in +-1000 (cycling per rowgroup), 1 % full-precision values, 0.1 % specials
+            xd = (torch.rand(n * VEC, dtype=torch.float64, device=dev, generator=g) - 0.5) * 2e3
+            sc = torch.where((torch.arange((n + 99) // 100, device=dev) % 2 == 0), 10.0, 100.0).to(torch.float64).repeat_interleave(100 * VEC)[: n * VEC]
+            xf = (torch.round(xd * sc) / sc).to(torch.float32)
+            m = torch.rand(n * VEC, device=dev, generator=g) < 0.01
+            xf[m] = (xd[m] * 3.141592653589793).to(torch.float32)
+            sp = torch.rand(n * VEC, device=dev, generator=g) < 0.001
+            specials = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0], dtype=torch.float32, device=dev)
+            xf[sp] = specials[torch.randint(0, 4, (int(sp.sum()),), device=dev, generator=g)]
+            del xd, sc, m, sp
+        fcol = capi.DeviceColumn(n, local_rank, dtype="f32")
+        emed, _ = time_launches(lambda: ctx.encode(xf, fcol), 3, 1)
+        pb, eb, ov = ctx.column_totals(fcol)
+        dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
+        rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
+        fsums = torch.empty(n, dtype=torch.float64, device=dev)
+        smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)
+        del fsums
+        f_alg = n * (4096 + 13) + pb + eb
+        fl[kind] = {"vectors": n, "encode_input_GBps": round(n * 4096 / emed / 1e6, 1), "encode_ms": round(emed, 3),
+                    "encode_roofline_frac_algorithmic": frac(f_alg, emed),
+                    "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
+                    "decode_GBps_decoded_floats": round(n * 4096 / dmed / 1e6, 1), "decode_ms": round(dmed, 3),
+                    "decode_roofline_frac_algorithmic": frac(f_alg, dmed),
+                    "decode_sum_fused_ms": round(smed, 3), "decode_sum_roofline_frac_algorithmic": frac(f_alg - n * 4096 + n * 8, smed),
+                    "gpu_roundtrip_bit_exact": rt}
+        del xf, fcol
+    extras["float_path"] = fl
+    result["extras"] = extras
+    ctx.decode(col, out)
+    torch.cuda.synchronize()
+    result["cpu_baseline"] = cpu_decode_baseline(ctx, col, vec, out)
+    if enc_cpu is not None:
+        result["cpu_baseline"]["encode"] = enc_cpu
+    return result
 
 
 if __name__ == "__main__":

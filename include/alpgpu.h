@@ -156,6 +156,9 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * recovery route; the result is still a complete, byte-identical column). */
 #define ALPGPU_OPT_DEBUG_FORCE_STALL 4
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
+/* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
+ * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
+int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
 

@@ -1,5 +1,7 @@
-"""CPU: the N > 1 path — rowgroup sharding covers a column exactly once, and the world_size-2 timing harness
-(gloo here, RCCL on the GPU box) returns the max over ranks on every rank."""
+"""CPU: the N > 1 path — rowgroup sharding covers a column exactly once, the world_size-2 timing harness (gloo here,
+RCCL on the GPU box) returns the max over ranks on every rank, and the per-rank encodes of a sharded column concatenate
+(alp_amd.sharding.concat_shards) to exactly the unsharded column's records and streams (oracle on both sides here; the GPU
+side of the same statement is tests/test_sharding_gpu.py)."""
 import os
 import sys
 
@@ -62,3 +64,41 @@ def test_world_size_2_timing_and_coverage():
     assert abs(e0 - e1) < 1e-9, "every rank must report the max over ranks"
     assert e0 >= 3 * 0.02 * 0.9
     assert mn0 == mx0 == 4, "each vector processed exactly once per step (warm-up + 3 steps) by exactly one rank"
+
+
+def _encode_worker(rank, world, port, q):
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen
+    import layout
+    from oracle.pyoracle import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    column = np.concatenate([datagen.mixed_column(230, seed=5, exc_rate=0.02), datagen.rd_column(100, seed=6), datagen.mixed_column(137, seed=7)])  # 467 vectors
+    n = column.size // 1024
+    first, cnt = sharding.rowgroup_shard(n, rank, world)
+    mine = layout.compact(Oracle().encode_column(column[first * 1024:(first + cnt) * 1024]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)  # the host-side concat of (offset, length) pairs: no device collective
+    if rank == 0:
+        whole = layout.compact(Oracle().encode_column(column))
+        got = sharding.concat_shards(gathered)
+        q.put(all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(got, whole)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_sharded_encode_concatenates_to_the_unsharded_column():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_encode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok, "per-rank streams, concatenated with shifted offsets, must equal the single-rank streams byte for byte"
