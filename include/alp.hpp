@@ -4,7 +4,8 @@
 // MI355X kernels in libalpgpu.so through the C ABI (include/alpgpu.h): there is no CPU implementation behind this
 // header.  Each call ships ONE 1024-value vector (or one rowgroup for init) to the GPU and back, so it is a
 // compatibility surface — code that cares about throughput calls the batch entry points of include/alpgpu.h
-// (alpgpu_encode_f64 / alpgpu_decode_f64) or the alp::gpu helpers at the bottom of alp/gpu_bridge.hpp.
+// (alpgpu_encode_f64 / alpgpu_decode_f64); code that keeps the reference's per-vector loop shape calls alp::gpu::rowgroup<PT>
+// (alp/batch.hpp) once per rowgroup instead of four functions per vector.
 // Link with -lalpgpu.  See INTEGRATION.md.
 #ifndef ALP_HPP
 #define ALP_HPP
@@ -18,6 +19,7 @@
 #include "alp/encoder.hpp"
 #include "alp/falp.hpp"
 #include "alp/rd.hpp"
+#include "alp/batch.hpp"
 #include "alp/storer.hpp"
 #include "fastlanes/ffor.hpp"
 #include "fastlanes/unffor.hpp"

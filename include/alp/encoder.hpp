@@ -7,6 +7,7 @@
 #include "alp/constants.hpp"
 #include "alp/decoder.hpp"
 #include "alp/gpu_bridge.hpp"
+#include <cmath>
 #include "alp/sampler.hpp"
 #include <unordered_map>
 #include <utility>
@@ -143,8 +144,29 @@ struct encoder {
 		fetch_encoded(s, exceptions, exceptions_positions, exceptions_count, encoded_integers);
 	}
 
-	// encode_value / is_impossible_to_encode / count_bits (encoder.hpp:75-106) are internals of the reference's encoder that no
-	// caller outside include/alp/ uses; their arithmetic lives only in the device code (alp_amd/csrc/alp_device.hpp, alp_device_f32.hpp).
+	// encoder.hpp:75-106 upstream.  encode_value<SAFE> (one value -> its encoded integer) is an internal of the reference's encoder
+	// that no caller outside include/alp/ uses; its arithmetic lives only in the device code (alp_amd/csrc/alp_device.hpp,
+	// alp_device_f32.hpp) and is not offered per value.  The two helpers below are plain predicates / bit counting, kept for
+	// source compatibility:
+	//! encoder.hpp:75-78
+	static inline bool is_impossible_to_encode(const PT n) {
+		return !(n == n) || n - n != PT(0) || n > ENCODING_UPPER_LIMIT || n < ENCODING_LOWER_LIMIT || (n == PT(0) && std::signbit(n));
+	}
+	//! encoder.hpp:91-106
+	template <typename T>
+	static inline uint8_t count_bits(T x) {
+		uint8_t res = 0;
+		while (x) {
+			x >>= 1;
+			++res;
+		}
+		return res;
+	}
+	template <typename T>
+	static inline uint8_t count_bits(T max, T min) {
+		const uint64_t delta = (static_cast<uint64_t>(max) - static_cast<uint64_t>(min));
+		return count_bits<uint64_t>(delta);
+	}
 
 	//! min/max -> frame-of-reference base and bit width (encoder.hpp:109-120)
 	static inline void analyze_ffor(const ST* input_vector, bw_t& bit_width, ST* base_for) {

@@ -48,3 +48,13 @@ def test_cpp_dropin_header_against_reference_columns(tmp_path):
     tail_out = "\n".join(p.stdout.splitlines()[-15:])
     assert p.returncode == 0, f"drop-in harness failed:\n{tail_out}\n{p.stderr[-2000:]}"
     assert f"{len(lines)} columns, 0 failures" in p.stdout
+
+
+def test_rowgroup_batched_cpp_surface_matches_the_per_vector_functions(tmp_path):
+    """include/alp/batch.hpp: one call per rowgroup == the reference-shaped per-vector loop, byte for byte; prints both rates"""
+    exe = tmp_path / "batch_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", f"-I{ROOT}/include", "-o", str(exe), f"{ROOT}/tests/cpp/batch_test.cpp",
+                           f"-L{ROOT}/alp_amd", "-lalpgpu", f"-Wl,-rpath,{ROOT}/alp_amd"])
+    p = subprocess.run([str(exe), "2"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    assert p.returncode == 0 and "batch_test: 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
