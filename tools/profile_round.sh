@@ -1,0 +1,24 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>      e.g. r02
+# rocprofv3 --kernel-trace --stats and, in SEPARATE passes, --pmc FETCH_SIZE / --pmc WRITE_SIZE (MI355X_MICROARCH.md §HBM) for
+#   dec : python bench.py --steps 20 --warmup 10 --no-extras          (k_decode_column on the benchmark column)
+#   enc : python tools/prof_encode.py mixed 1048576                    (k_rowgroup_init, k_encode_fused)
+#   encf: python tools/prof_encode_f32.py decimal1 1048576             (k_rowgroup_init<f32>, k_encode_fused_f32) + float decode
+# raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_*
+TAG=$1
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/${TAG}_prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { # name, command...
+  name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_stats -- "$@" > $OUT/${name}_stats.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${name}_fetch -- "$@" > $OUT/${name}_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${name}_write -- "$@" > $OUT/${name}_write.log 2>&1
+}
+run dec python $ROOT/bench.py --steps 20 --warmup 10 --no-extras
+run enc python $ROOT/tools/prof_encode.py mixed 1048576
+run encf python $ROOT/tools/prof_float.py 1048576
+cd $ROOT
+grep -h '"metric"' $OUT/dec_stats.log | tail -1 > $OUT/bench_under_rocprof.json
+python tools/summarize_round.py $TAG $OUT
