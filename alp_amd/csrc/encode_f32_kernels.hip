@@ -6,8 +6,8 @@
 //   ffor::ffor (int32 / uint32 / uint16)  include/fastlanes/ffor.hpp:7-15 -> src/fastlanes_generated_ffor.cpp:1776-7378, :357-1775
 //   alp::rd_encoder<float>::encode        include/alp/rd.hpp:109-147
 //
-// Single pass, same scheme as k_encode_fused (encode_kernels.hip): tiles of kFusedWaves wavefronts, two 1024-value vectors per
-// wavefront (kF32PerWave), output offsets in vector order from the decoupled look-back of encode_lookback.hpp.  The same kernel body,
+// Single pass, same scheme as k_encode_fused (encode_kernels.hip): one wavefront per 1024-value vector, kFusedWaves vectors per
+// workgroup (tile), output offsets in vector order from the decoupled look-back of encode_lookback.hpp.  The same kernel body,
 // compiled in two more modes, is the two-pass form (ALPGPU_OPT_ENCODE_TWO_PASS and the recovery route of a stalled single pass):
 // ANALYZE stops after the sizes are known and leaves them in the descriptors, PACK takes its offsets from the scan of those
 // (k_scan_tiles / k_scan_totals of encode_kernels.hip) instead of the look-back.
@@ -23,94 +23,58 @@ namespace alpgpu {
 
 enum FusedMode { kSinglePass = 0, kAnalyze = 1, kPack = 2 };
 constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors per tile of the two-pass scan
-// A float vector is 4 KiB: a wavefront that handles ONE per tile moves half the bytes of the double kernel's wavefront through the
-// same chain of latencies (input load, ordered offset, stores) and the kernel ran at the double kernel's vectors/s, i.e. half
-// its bytes/s.  Each wavefront therefore takes kF32PerWave = 2 consecutive vectors per tile, one after the other up to their
-// packed units (registers) and exception images (LDS), then ONE wait for the tile's offset and the stores of both.
-constexpr int kF32PerWave = 2;
-constexpr int kF32Tile    = kFusedWaves * kF32PerWave; // vectors per tile
 
-// everything of one encoded vector that has to survive until its offsets are known
-struct VectorOutF32 {
-	PackedUnitsF32     units;
+// kSinglePass: `status` = look-back words.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only), `gate` as in
+// encode_kernels.hip, v_first = 0.
+template <int MODE>
+__global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                       alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
+                                                                       uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
+                                                                       uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
+                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order,
+                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate) {
+	if (MODE != kSinglePass && gate != nullptr && *gate == 0) { return; }
+	if (MODE == kPack && totals[2] != 0) { // capacity overflow (reported through alpgpu_column_totals): no stream bytes, descriptors a decoder can follow
+		const uint64_t vo = v_first + static_cast<uint64_t>(blockIdx.x) * kFusedWaves + (threadIdx.x >> 6);
+		if ((threadIdx.x & 63) == 0 && vo < v_first + n_vectors_launch) { descs[vo] = empty_descriptor(); }
+		return;
+	}
+	__shared__ EncodeLdsF32 lds[kFusedWaves];
+	__shared__ uint64_t     s_size[kFusedWaves];
+	__shared__ uint64_t     s_excl;
+	__shared__ uint32_t     s_count;
+	__shared__ uint32_t     s_ready;
+	const int               lane = lane_id();
+	const int               wave = wave_in_wg();
+	const uint64_t          tile = blockIdx.x;
+	if (threadIdx.x == 0) {
+		s_count = 0;
+		s_ready = 0;
+	}
+	__syncthreads();
+
+	EncodeLdsF32&  L    = lds[wave];
+	const uint64_t vl   = tile * kFusedWaves + wave;
+	const bool     live = vl < n_vectors_launch;
+	const uint64_t v    = v_first + vl;
+	VecInF             x;
 	alpgpu_vector_desc d;
-	uint64_t           lacc[4]; // ALP_RD: packed left streams of this lane's four lane64 columns
-	uint64_t           my_p, my_e;
-	uint32_t           val_bytes, staged_bytes;
-	int                cnt;
-	bool               pos_staged;
-};
-
-// ALP_RD split of one float vector (rd.hpp:109-147): right parts -> q, left indices -> lacc, exception ballots
-__device__ __forceinline__ void encode_rd_registers_f32(const VecInF& x, const alpgpu_rowgroup_state& rg, const uint16_t* __restrict__ order_rg, int lane, u32x4 (&q)[4],
-                                                        uint64_t (&ballots)[4][4], uint64_t (&lacc)[4], int& cnt) {
-	// Left index streams: value i -> lane64 = i & 63 = 4*(lane & 15) + j, row = i >> 6 = 4*m + (lane >> 4).
-	const int         rbw   = rg.rd_rbw;
-	const int         lbw   = rg.rd_lbw;
-	const int         ds    = rg.rd_dict_size;
-	const uint32_t    rmask = bw_mask32(rbw);
-	const uint64_t    lmask = (1ull << lbw) - 1ull;
-	const RdOrderView order = load_rd_order(order_rg, rg, lane);
-	uint32_t          dict[8]; // read once: left inside the loop, the compiler re-reads the dictionary from memory for every value
-#pragma unroll
-	for (int dd = 0; dd < 8; ++dd) { dict[dd] = rg.rd_dict[dd]; }
-	cnt = 0;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) { lacc[j] = 0; }
-#pragma unroll
-	for (int m = 0; m < 4; ++m) {
-		const int row = 4 * m + (lane >> 4);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t bits = __float_as_uint(x.x[m][j]);
-			q[m][j]             = bits & rmask;
-			const uint32_t left = (bits >> rbw) & 0xFFFFu;
-			int            idx  = ds;
-#pragma unroll
-			for (int dd = 7; dd >= 0; --dd) {
-				if (dd < ds && dict[dd] == left) { idx = dd; }
-			}
-			const bool exc = idx == ds;
-			ballots[m][j]  = __ballot(exc);
-			if (order.valid && ballots[m][j] != 0) { // the reference's index for a left part outside the dictionary
-				const int ridx = rd_exception_index(order, left);
-				idx            = exc ? ridx : idx;
-			}
-			cnt += __builtin_popcountll(ballots[m][j]);
-			lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
-		}
-	}
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 16));
-		lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 32));
-	}
-}
-
-// One vector up to (and without) its offsets: encode, sizes, packed units in registers, exception image in L.vals.  `ballots`
-// is only needed by the caller for records larger than the stage (> 682 exceptions in an ALP vector).
-__device__ __forceinline__ void encode_vector_f32(const float* __restrict__ in, uint64_t v, bool live, const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                  const uint16_t* __restrict__ rd_order, EncodeLdsF32& L, int lane, VectorOutF32& o, uint64_t (&ballots)[4][4]) {
-	o.d.packed_off = o.d.exc_off = 0;
-	o.d.base                     = 0;
-	o.d.bw = o.d.e = o.d.f = o.d.lbw = 0;
-	o.d.exc_cnt = o.d.scheme = 0;
-	o.cnt                    = 0;
-	o.my_p = o.my_e = 0;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) { o.lacc[j] = 0; }
-#pragma unroll
-	for (int m = 0; m < 4; ++m) {
-#pragma unroll
-		for (int j = 0; j < 4; ++j) { ballots[m][j] = 0; }
-	}
-	VecInF x;
+	uint64_t           lacc[4] = {0, 0, 0, 0}; // ALP_RD: packed left streams of this lane's four lane64 columns
+	uint64_t           ballots[4][4];
+	int                cnt = 0;
+	d.packed_off = d.exc_off = 0;
+	d.base                   = 0;
+	d.bw = d.e = d.f = d.lbw = 0;
+	d.exc_cnt = d.scheme = 0;
+	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane); // once, into registers
+	const alpgpu_rowgroup_state* rgp = &st;
+	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
+	// that nothing but the ordered offset stands between the wait and the stores
+	const uint64_t base_p = totals[0], base_e = totals[1];
 	if (live) {
-		const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + v / kRowgroup, lane); // once, into registers
-		const alpgpu_rowgroup_state* rgp = &st;
-		x                                = load_vector_f32(in, v, lane);
-		o.d.scheme                       = rgp->scheme;
-		u32x4* lv                        = reinterpret_cast<u32x4*>(L.vals);
+		x        = load_vector_f32(in, v, lane);
+		d.scheme = rgp->scheme;
+		u32x4* lv = reinterpret_cast<u32x4*>(L.vals);
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
 			if (rgp->k > 1) {
@@ -121,8 +85,8 @@ __device__ __forceinline__ void encode_vector_f32(const float* __restrict__ in, 
 			}
 			AlpEncodedF R;
 			encode_alp_registers_f32(x, e, f, lane, R);
-			o.d.base = R.base, o.d.bw = static_cast<uint8_t>(R.bw), o.d.e = static_cast<uint8_t>(e), o.d.f = static_cast<uint8_t>(f);
-			o.cnt               = R.cnt;
+			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
+			cnt = R.cnt;
 			const uint32_t base = static_cast<uint32_t>(R.base);
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
@@ -135,33 +99,84 @@ __device__ __forceinline__ void encode_vector_f32(const float* __restrict__ in, 
 				lv[64 * m + lane] = q;
 			}
 		} else {
-			u32x4 q[4];
-			encode_rd_registers_f32(x, st, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, lane, q, ballots, o.lacc, o.cnt);
-			o.d.bw = rgp->rd_rbw, o.d.lbw = rgp->rd_lbw;
+			// rd.hpp:109-147: right = bits & mask, left = bits >> rbw; left -> dictionary index, not found = exception.
+			// Left index streams: value i -> lane64 = i & 63 = 4*(lane & 15) + j, row = i >> 6 = 4*m + (lane >> 4).
+			const int      rbw   = rgp->rd_rbw;
+			const int      lbw   = rgp->rd_lbw;
+			const int      ds    = rgp->rd_dict_size;
+			const uint32_t rmask = bw_mask32(rbw);
+			const uint64_t lmask = (1ull << lbw) - 1ull;
+			d.bw = static_cast<uint8_t>(rbw), d.lbw = static_cast<uint8_t>(lbw);
+			const RdOrderView order = load_rd_order(rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, *rgp, lane);
+			uint32_t dict[8]; // read once: left inside the loop, the compiler re-reads the dictionary from memory for every value
 #pragma unroll
-			for (int m = 0; m < 4; ++m) { lv[64 * m + lane] = q[m]; }
+			for (int dd = 0; dd < 8; ++dd) { dict[dd] = rgp->rd_dict[dd]; }
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				u32x4     q;
+				const int row = 4 * m + (lane >> 4);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const uint32_t bits = __float_as_uint(x.x[m][j]);
+					q[j]                = bits & rmask;
+					const uint32_t left = (bits >> rbw) & 0xFFFFu;
+					int            idx  = ds;
+#pragma unroll
+					for (int dd = 7; dd >= 0; --dd) {
+						if (dd < ds && dict[dd] == left) { idx = dd; }
+					}
+					const bool exc = idx == ds;
+					ballots[m][j]  = __ballot(exc);
+					if (order.valid && ballots[m][j] != 0) { // the reference's index for a left part outside the dictionary
+						const int ridx = rd_exception_index(order, left);
+						idx            = exc ? ridx : idx;
+					}
+					cnt += __builtin_popcountll(ballots[m][j]);
+					lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
+				}
+				lv[64 * m + lane] = q;
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 16));
+				lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 32));
+			}
 		}
-		o.d.exc_cnt = static_cast<uint16_t>(o.cnt);
-		record_sizes<4>(o.d, o.my_p, o.my_e);
+		d.exc_cnt = static_cast<uint16_t>(cnt);
 	}
-	// pack into registers (see k_encode_fused)
+	uint64_t my_p = 0, my_e = 0;
+	if (live) { record_sizes<4>(d, my_p, my_e); }
+	if (MODE == kAnalyze) { // the sizes are all the scan needs
+		if (live && lane == 0) { descs[v] = d; }
+		return;
+	}
+	if (MODE == kSinglePass && lane == 0) {
+		s_size[wave]           = status_pack(0, my_p >> 7, my_e >> 3);
+		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (arrived == kFusedWaves - 1) {
+			uint64_t aggregate = 0;
+#pragma unroll
+			for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
+			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
+		}
+	}
+	// pack into registers while the ordered offset is on its way (see k_encode_fused)
+	PackedUnitsF32 packed_units;
 	wave_lds_sync();
-	pack_u32_units(L, o.d.bw, lane, o.units);
+	pack_u32_units(L, d.bw, lane, packed_units);
 	// the exception record's image goes to the (now free) staging area and leaves as contiguous stores after the wait, see
 	// k_encode_fused: values always fit (4 B x 1024), the positions follow them when the whole record does (<= 682 exceptions;
-	// always for ALP_RD), else they are written after the wait.  Pad bytes are zero.
-	const bool alp_rec = o.d.scheme == ALPGPU_SCHEME_ALP;
-	o.val_bytes        = alp_rec ? 4u * static_cast<uint32_t>(o.cnt) : 2u * static_cast<uint32_t>(o.cnt);
-	o.pos_staged       = o.my_e <= sizeof(L.vals);
-	o.staged_bytes     = o.pos_staged ? static_cast<uint32_t>(o.my_e) : o.val_bytes;
-	if (o.cnt > 0) {
+	// always for ALP_RD), else they are written from the ballots after the wait.  Pad bytes are zero.
+	const bool     alp_rec      = d.scheme == ALPGPU_SCHEME_ALP;
+	const uint32_t val_bytes    = alp_rec ? 4u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
+	const bool     pos_staged   = my_e <= sizeof(L.vals);
+	const uint32_t staged_bytes = pos_staged ? static_cast<uint32_t>(my_e) : val_bytes;
+	if (cnt > 0) {
 		uint8_t* img = reinterpret_cast<uint8_t*>(L.vals);
 		wave_lds_sync(); // the pack's reads are issued; one wavefront's LDS operations execute in order
-		if (o.pos_staged && lane == 0) { reinterpret_cast<uint64_t*>(img)[(o.staged_bytes >> 3) - 1] = 0ull; } // the pad lives in the last word
+		if (pos_staged && lane == 0) { reinterpret_cast<uint64_t*>(img)[(staged_bytes >> 3) - 1] = 0ull; } // the pad lives in the last word
 		wave_lds_sync();
-		const int      rbw        = o.d.bw;
-		const uint32_t val_bytes  = o.val_bytes;
-		const bool     pos_staged = o.pos_staged;
+		const int rbw = d.bw;
 		for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
 			const uint32_t bits = __float_as_uint(x.x[m][j]);
 			const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
@@ -174,129 +189,59 @@ __device__ __forceinline__ void encode_vector_f32(const float* __restrict__ in, 
 		});
 		wave_lds_sync();
 	}
-}
-
-// kSinglePass: `status` = look-back words.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only), `gate` as in
-// encode_kernels.hip, v_first = 0.
-template <int MODE>
-__global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                                       alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
-                                                                       uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
-                                                                       uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
-                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order,
-                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate) {
-	if (MODE != kSinglePass && gate != nullptr && *gate == 0) { return; }
-	const int      lane = lane_id();
-	const int      wave = wave_in_wg();
-	const uint64_t tile = blockIdx.x;
-	const uint64_t vl0  = tile * kF32Tile + static_cast<uint64_t>(wave) * kF32PerWave; // this wavefront's first vector inside the launch
-	if (MODE == kPack && totals[2] != 0) { // capacity overflow (reported through alpgpu_column_totals): no stream bytes, descriptors a decoder can follow
-#pragma unroll
-		for (int i = 0; i < kF32PerWave; ++i) {
-			if (lane == 0 && vl0 + i < n_vectors_launch) { descs[v_first + vl0 + i] = empty_descriptor(); }
-		}
-		return;
-	}
-	__shared__ EncodeLdsF32 lds[kFusedWaves][kF32PerWave];
-	__shared__ uint64_t     s_size[kF32Tile]; // per vector: (packed units << 31) | exception units
-	__shared__ uint64_t     s_excl;
-	__shared__ uint32_t     s_count;
-	__shared__ uint32_t     s_ready;
-	if (threadIdx.x == 0) {
-		s_count = 0;
-		s_ready = 0;
-	}
-	__syncthreads();
-
-	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
-	// that nothing but the ordered offset stands between the wait and the stores
-	const uint64_t base_p = totals[0], base_e = totals[1];
-	VectorOutF32   o[kF32PerWave];
-	uint64_t       ballots[4][4]; // of the vector being encoded; afterwards only a record larger than the stage needs them again
-#pragma unroll
-	for (int i = 0; i < kF32PerWave; ++i) {
-		const bool     live = vl0 + i < n_vectors_launch;
-		const uint64_t v    = v_first + (live ? vl0 + i : 0);
-		encode_vector_f32(in, v, live, rgs, rd_order, lds[wave][i], lane, o[i], ballots);
-		if (MODE == kAnalyze) { // the sizes are all the scan needs
-			if (live && lane == 0) { descs[v] = o[i].d; }
-		}
-	}
-	if (MODE == kAnalyze) { return; }
 	if (MODE == kSinglePass) {
-		if (lane == 0) {
-#pragma unroll
-			for (int i = 0; i < kF32PerWave; ++i) { s_size[wave * kF32PerWave + i] = status_pack(0, o[i].my_p >> 7, o[i].my_e >> 3); }
-			const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (arrived == kFusedWaves - 1) {
-				uint64_t aggregate = 0;
-#pragma unroll
-				for (int w = 0; w < kF32Tile; ++w) { aggregate += s_size[w]; }
-				status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
-			}
-		}
-		if (wave == 0) { tile_lookback<kF32Tile>(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
+		if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
 		uint32_t spins = 0;
 		while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
 			if (++spins > 64u * kSpinLimit) { return; }
 			__builtin_amdgcn_s_sleep(2);
 		}
-		if (s_excl == ~0ull) { return; }
+		uint64_t local = 0;
+#pragma unroll
+		for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
+		const uint64_t excl = s_excl;
+		if (excl == ~0ull) { return; }
+		const uint64_t pre = excl + local;
+		d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
+		d.exc_off          = base_e + (pre & 0x7FFFFFFFull) * 8ull;
+	} else if (live) { // kPack: the scan left the offsets inside the vector's scan tile in its descriptor
+		const uint64_t st_ = v / kScanTileF32;
+		d.packed_off       = descs[v].packed_off + status[2 * st_];
+		d.exc_off          = descs[v].exc_off + status[2 * st_ + 1];
 	}
-#pragma unroll
-	for (int i = 0; i < kF32PerWave; ++i) {
-		const bool live = vl0 + i < n_vectors_launch;
-		if (!live) { continue; }
-		const uint64_t     v = v_first + vl0 + i;
-		VectorOutF32&      r = o[i];
-		alpgpu_vector_desc d = r.d;
-		if (MODE == kSinglePass) {
-			uint64_t local = 0;
-#pragma unroll
-			for (int w = 0; w < kF32Tile; ++w) { local += w < wave * kF32PerWave + i ? s_size[w] : 0; }
-			const uint64_t pre = s_excl + local;
-			d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
-			d.exc_off          = base_e + (pre & 0x7FFFFFFFull) * 8ull;
-		} else { // kPack: the scan left the offsets inside the vector's scan tile in its descriptor
-			const uint64_t st_ = v / kScanTileF32;
-			d.packed_off       = descs[v].packed_off + status[2 * st_];
-			d.exc_off          = descs[v].exc_off + status[2 * st_ + 1];
+	if (!live) { return; }
+	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) { // see k_encode_fused
+		if (lane == 0) {
+			__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			descs[v] = empty_descriptor();
 		}
-		if (d.packed_off + r.my_p > packed_capacity || d.exc_off + r.my_e > exc_capacity) { // see k_encode_fused
-			if (lane == 0) {
-				__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				descs[v] = empty_descriptor();
-			}
-			continue;
-		}
-		uint8_t* dst = packed + d.packed_off;
-		uint8_t* rec = excs + d.exc_off;
-		if (r.cnt > 0) {
-			const uint32_t* img32 = reinterpret_cast<const uint32_t*>(lds[wave][i].vals);
-			uint32_t*       rec32 = reinterpret_cast<uint32_t*>(rec);
-			const int       n_w   = static_cast<int>(r.staged_bytes >> 2);
-			for (int w = lane; w < n_w; w += 64) { rec32[w] = img32[w]; }
-			if (!r.pos_staged) { // > 682 exceptions in an ALP vector: the positions (and their pad) from the ballots of a second encode
-				VectorOutF32 again;
-				encode_vector_f32(in, v, true, rgs, rd_order, lds[wave][i], lane, again, ballots);
-				uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + r.val_bytes);
-				for_each_exception_f32(ballots, lane, [&](int rr, int m, int j) { rpos[rr] = static_cast<uint16_t>(256 * m + 4 * lane + j); });
-				const int n_pos = static_cast<int>((r.my_e - r.val_bytes) >> 1);
-				if (r.cnt + lane < n_pos) { rpos[r.cnt + lane] = 0; }
-			}
-		}
-		store_packed_units_f32(r.units, d.bw, reinterpret_cast<u32x4*>(dst), lane);
-		if (d.scheme != ALPGPU_SCHEME_ALP && lane < 16) {
-			uint64_t* out64 = reinterpret_cast<uint64_t*>(dst + 128ull * d.bw);
-			for (int k = 0; k < d.lbw; ++k) { // word k of lane64 columns 4*lane .. 4*lane+3
-				uint64_t w = 0;
-#pragma unroll
-				for (int j = 0; j < 4; ++j) { w |= ((r.lacc[j] >> (16 * k)) & 0xFFFFull) << (16 * j); }
-				out64[16 * k + lane] = w;
-			}
-		}
-		if (lane == 0) { descs[v] = d; }
+		return;
 	}
+	uint8_t* dst = packed + d.packed_off;
+	uint8_t* rec = excs + d.exc_off;
+	if (cnt > 0) {
+		const uint32_t* img32 = reinterpret_cast<const uint32_t*>(L.vals);
+		uint32_t*       rec32 = reinterpret_cast<uint32_t*>(rec);
+		const int       n_w   = static_cast<int>(staged_bytes >> 2);
+		for (int w = lane; w < n_w; w += 64) { rec32[w] = img32[w]; }
+		if (!pos_staged) { // > 682 exceptions in an ALP vector: positions (and their pad) straight from the ballots
+			uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
+			for_each_exception_f32(ballots, lane, [&](int r, int m, int j) { rpos[r] = static_cast<uint16_t>(256 * m + 4 * lane + j); });
+			const int n_pos = static_cast<int>((my_e - val_bytes) >> 1);
+			if (cnt + lane < n_pos) { rpos[cnt + lane] = 0; }
+		}
+	}
+	store_packed_units_f32(packed_units, d.bw, reinterpret_cast<u32x4*>(dst), lane);
+	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 16) {
+		uint64_t* out64 = reinterpret_cast<uint64_t*>(dst + 128ull * d.bw);
+		for (int k = 0; k < d.lbw; ++k) { // word k of lane64 columns 4*lane .. 4*lane+3
+			uint64_t w = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { w |= ((lacc[j] >> (16 * k)) & 0xFFFFull) << (16 * j); }
+			out64[16 * k + lane] = w;
+		}
+	}
+	if (lane == 0) { descs[v] = d; }
 }
 
 __global__ void k_fused_finish_f32(uint64_t* __restrict__ totals) {
@@ -310,7 +255,7 @@ int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const a
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
-		const uint64_t n_tiles  = (n_launch + kF32Tile - 1) / kF32Tile;
+		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		hipLaunchKernelGGL(k_encode_fused_f32<kSinglePass>, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
@@ -331,7 +276,7 @@ int launch_encode_vectors_f32(hipStream_t stream, const float* d_in, uint64_t n_
 		if (gate == nullptr) { (void)hipMemsetAsync(col->d_totals, 0, 64, stream); }
 		return ALPGPU_OK;
 	}
-	const dim3 grid(static_cast<unsigned>((n_vectors + kF32Tile - 1) / kF32Tile)), block(64 * kFusedWaves);
+	const dim3 grid(static_cast<unsigned>((n_vectors + kFusedWaves - 1) / kFusedWaves)), block(64 * kFusedWaves);
 	hipLaunchKernelGGL(k_encode_fused_f32<kAnalyze>, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
 	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate);
 	if (launch_scan_offsets(stream, col, n_vectors, d_workspace, true, gate) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
