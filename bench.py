@@ -391,11 +391,18 @@ def main():
         result = sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev)
     else:
         result = single_gpu_bench(args, ctx, clock, local_rank, dev)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: flush it first so that the JSON line is the LAST line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 def headline(value, world, args, elapsed, kern_ms, alg_bytes, decoded_bytes_rank, workload, scaling, extra_config):

@@ -85,8 +85,19 @@ static int run(size_t n_rowgroups, bool rd) {
 			alp::rd_encoder<PT>::decode(a_out.data() + v * V, a_right.data() + v * V, a_left.data() + v * V, a_rexc.data() + v * V, a_pos.data() + v * V, a_cnt.data() + v, stt);
 		}
 	}
+	// ---- (B) one call per rowgroup; the first call of a process pays the scratch allocation and the lazy load of three
+	// kernels, so rowgroup 0 is run once before the clock starts (the per-vector loop above has warmed its own kernels)
+	{
+		if (!rd) {
+			alp::gpu::rowgroup<PT>::encode(column.data(), R, states[0], b_packed.data(), b_bw.data(), bases_b.data(), b_fac.data(), b_exp.data(), b_exc.data(), b_pos.data(),
+			                               b_cnt.data());
+			alp::gpu::rowgroup<PT>::decode(b_packed.data(), b_bw.data(), bases_b.data(), b_fac.data(), b_exp.data(), b_exc.data(), b_pos.data(), b_cnt.data(), R, b_out.data());
+		} else {
+			alp::gpu::rowgroup<PT>::encode_rd(column.data(), R, states[0], b_right.data(), b_left.data(), b_rexc.data(), b_pos.data(), b_cnt.data());
+			alp::gpu::rowgroup<PT>::decode_rd(b_right.data(), b_left.data(), b_rexc.data(), b_pos.data(), b_cnt.data(), states[0], R, b_out.data());
+		}
+	}
 	auto t2 = std::chrono::steady_clock::now();
-	// ---- (B) one call per rowgroup
 	for (size_t g = 0; g < n_rowgroups; ++g) {
 		const size_t o = g * R * V, ov = g * R;
 		if (!rd) {
