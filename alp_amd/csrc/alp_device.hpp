@@ -110,6 +110,15 @@ constexpr double kLowerLimit = -9223372036854774784.0; // constants.hpp:18
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
 __device__ __forceinline__ int wave_in_wg() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
 
+// A predicate as a wave-uniform lane mask.  __ballot(int) of the HIP headers compares a VGPR with 0; the intrinsic takes the
+// i1 as it is.  Ballot a COMPARE and combine masks as integers: the ballot of a compare is the compare's own SGPR result,
+// while a predicate built from several compares is first materialised per lane (v_cndmask) and compared again.
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// base + number of set bits of `mask` below this lane (v_mbcnt_lo / v_mbcnt_hi: two instructions, the mask stays scalar)
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask, uint32_t base) {
+	return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), base));
+}
+
 // Orders this wave's LDS traffic (and the compiler) around an intra-wave exchange.  The LDS unit executes
 // one wave's DS operations in issue order, so no hardware barrier is needed between lanes of one wave.
 __device__ __forceinline__ void wave_lds_sync() {

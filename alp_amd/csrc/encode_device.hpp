@@ -106,16 +106,17 @@ __device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint
 // 32 samples = input[32*s]; both half-waves evaluate one candidate each per round (lane & 31 = sample).
 // All candidates are evaluated; the reference's early exit (two consecutive non-improvements) only stops
 // evaluating, so replaying its sequential decision over the computed sizes gives the same (e,f).
-__device__ __forceinline__ void second_level_select(const VecIn& in, const alpgpu_rowgroup_state* __restrict__ rgp, EncodeLds& L, int lane,
+// smp: 32 doubles of wavefront-private LDS
+__device__ __forceinline__ void second_level_select(const VecIn& in, const alpgpu_rowgroup_state* __restrict__ rgp, double* smp, int lane,
                                                     int& e_out, int& f_out) {
 	const int k = rgp->k;
 	// sample s lives at index 32*s = 128*(s>>2) + 2*(16*(s&3)): element .x of step s>>2 in lane 16*(s&3)
 	if ((lane & 15) == 0) {
 #pragma unroll
-		for (int m = 0; m < 8; ++m) { L.smp[4 * m + (lane >> 4)] = in.x[m].x; }
+		for (int m = 0; m < 8; ++m) { smp[4 * m + (lane >> 4)] = in.x[m].x; }
 	}
 	wave_lds_sync();
-	const double sv   = L.smp[lane & 31];
+	const double sv   = smp[lane & 31];
 	const int    half = lane >> 5;
 
 	uint32_t sizes[5];
@@ -147,13 +148,13 @@ __device__ __forceinline__ void second_level_select(const VecIn& in, const alpgp
 			const double ap  = __builtin_fabs(p);
 			bool         ok  = (ap < k2p63) & (__double_as_longlong(p * frac_e) == __double_as_longlong(sv));
 			const bool   lit = (ap == k2p63) | ((t > sentinel_from) & (t < k2p64));
-			if (__ballot(lit) != 0) {
+			if (ballot64(lit) != 0) {
 				const int64_t fact = hi ? kFactArr[f_b] : kFactArr[f_a];
 				const int64_t enc  = encode_value_safe(sv, exp10, frac_f);
 				ok                 = decode_value(enc, fact, frac_e) == sv;
 				r                  = static_cast<double>(enc); // the cast of a double, the sentinel 2^63 - 1024 or -2^63: exact
 			}
-			const uint64_t bal  = __ballot(!ok);
+			const uint64_t bal  = ballot64(!ok);
 			const uint32_t excs = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
 			const double   qnan = __longlong_as_double(0x7FF8000000000000ll);
 			double         mn = ok ? r : qnan, mx = mn; // v_min / v_max_f64 ignore the quiet NaN of a failed sample
@@ -195,6 +196,11 @@ __device__ __forceinline__ void second_level_select(const VecIn& in, const alpgp
 	wave_lds_sync();
 }
 
+__device__ __forceinline__ void second_level_select(const VecIn& in, const alpgpu_rowgroup_state* __restrict__ rgp, EncodeLds& L, int lane,
+                                                    int& e_out, int& f_out) {
+	second_level_select(in, rgp, L.smp, lane, e_out, f_out);
+}
+
 // ---- encode_simdized + analyze_ffor for one vector held in registers -------------------------------------
 // Outputs: enc[m][j] with exception slots overwritten by the filler; the exceptions of every (m,j) step as a
 // wave-uniform lane mask (ballot); count; FOR base and bit width.
@@ -216,7 +222,6 @@ struct AlpEncoded {
 // redone for the whole wavefront with the literal arithmetic; |r * 10^f| > 2^63 is an exception outright (argument at the
 // test).  Results are bit-identical by construction.
 __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int f, int lane, AlpEncoded& R) {
-	(void)lane; // every cross-lane step below is a ballot, a DPP move or a readlane
 	const double  exp10  = kExpArr[e];
 	const double  frac_f = kFracArr[f];
 	const int64_t fact   = kFactArr[f];
@@ -251,27 +256,28 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 			// 2^63 while |v| 10^e > 0.96 * 2^64 — so the value is an exception without computing it.  Two-decimal values up to 10^5
 			// land here all the time: the reference's search gives them (e,f) = (14,12), and |v| >= 92 233.72 wraps.  Only
 			// |t| >= 2^51 (incl. Inf), NaN and |prod| == 2^63 exactly (P = -2^63 is representable) take the literal route.
-			const double ap   = __builtin_fabs(prod);
-			const bool   big  = !(ap < 0x1p63);
-			bool         over = false; // the product wraps for sure
-			bool         wide = !(__builtin_fabs(t) < 0x1p51);
-			if (__ballot(big) != 0) {
-				over = ap > 0x1p63;
-				wide = wide | (big & !over);
-			}
-			if (__ballot(wide) != 0) { // wave-uniform, rare: the literal path of alp_device.hpp
+			// Every test goes straight from its compare into a lane mask (ballot of a compare = the compare's own SGPR result) and the
+			// masks are combined as 64-bit integers on the scalar unit; a predicate built from several compares and then balloted
+			// is first materialised per lane (v_cndmask) and compared again.
+			const double   ap     = __builtin_fabs(prod);
+			const uint64_t over_m = ballot64(ap > 0x1p63);                       // the product wraps for sure
+			const uint64_t wide_m = ballot64(!(__builtin_fabs(t) < 0x1p51)) | (ballot64(!(ap < 0x1p63)) & ~over_m); // |t| >= 2^51, NaN, |prod| == 2^63
+			if (__builtin_expect(wide_m != 0, 0)) { // wave-uniform, rare: the literal path of alp_device.hpp (kept out of the fall-through path)
 				enc = cast64_x86(r);
 				dec = decode_value(enc, fact, frac_e);
 			}
-			const bool exc = (dec != vv) | (bits == 0x8000000000000000ull) | over; // IEEE compare: NaN is always an exception
+			// The round trip holds iff the BITS agree: dec is never -0.0 (a product of an integer-valued double, or of a converted
+			// int64, with positive powers of ten that cannot underflow) and never NaN on the literal route, which a NaN input always
+			// takes; so -0.0 (encodes to 0, decodes to +0.0: pass 1 of encoder.hpp:326-338 makes it an exception) and NaN fail the
+			// integer compare exactly where the reference's float compare plus its special-value pass do.
+			const uint64_t exc_m = ballot64(static_cast<uint64_t>(__double_as_longlong(dec)) != bits) | over_m;
 			R.enc[m][j]    = enc;
-			R.ballot[m][j] = __ballot(exc);
-			R.cnt += __builtin_popcountll(R.ballot[m][j]);
-			// a quiet NaN whatever the low word says: only the high word is replaced
-			const uint64_t rb = static_cast<uint64_t>(__double_as_longlong(r));
-			const double   rm = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(exc ? 0x7FF80000u : static_cast<uint32_t>(rb >> 32)) << 32) | (rb & 0xFFFFFFFFull)));
-			rmin            = fmin_num(rmin, rm);
-			rmax            = fmax_num(rmax, rm);
+			R.ballot[m][j] = exc_m;
+			R.cnt += __builtin_popcountll(exc_m);
+			if (!lane_in(exc_m)) { // lanes of exceptions sit this one out (exec mask) instead of feeding a quiet NaN through a select
+				rmin = fmin_num(rmin, r);
+				rmax = fmax_num(rmax, r);
+			}
 		}
 	}
 	// filler = encoded value at the first non-exception position p (encoder.hpp:382-388); 0 when there is
@@ -321,13 +327,13 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 // (position = 128*m + 2*lane + j), i.e. the slot's index in the ascending exception list.  m and j are compile-time at the call.
 template <class F>
 __device__ __forceinline__ void for_each_exception(const uint64_t (&ballot)[8][2], int lane, F&& emit) {
-	const uint64_t lt   = lanemask_lt(lane);
-	int            soff = 0;
+	(void)lane;
+	int soff = 0;
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
 		const uint64_t b0 = ballot[m][0], b1 = ballot[m][1];
 		if ((b0 | b1) != 0) { // wave-uniform
-			const int  before = soff + __builtin_popcountll(b0 & lt) + __builtin_popcountll(b1 & lt);
+			const int  before = static_cast<int>(mbcnt64(b1, mbcnt64(b0, static_cast<uint32_t>(soff))));
 			const bool e0 = lane_in(b0), e1 = lane_in(b1);
 			if (e0) { emit(before, m, 0); }
 			if (e1) { emit(before + (e0 ? 1 : 0), m, 1); }
@@ -345,8 +351,8 @@ typedef unsigned long long ull2v __attribute__((ext_vector_type(2)));
 struct PackedUnits {
 	ull2v acc[8];
 };
-__device__ __forceinline__ void pack_u64_units(const EncodeLds& L, int bw, int lane, PackedUnits& P) {
-	const ull2v* vals2   = reinterpret_cast<const ull2v*>(L.vals);
+__device__ __forceinline__ void pack_u64_units(const uint64_t* vals, int bw, int lane, PackedUnits& P) {
+	const ull2v* vals2   = reinterpret_cast<const ull2v*>(vals);
 	const int    n_units = 8 * bw;
 	// bit0 / bw without a per-lane division: bit0 <= 4032 and bw <= 64, so with M = floor(2^20 / bw) + 1 the error term
 	// bit0 * (M * bw - 2^20) stays below 2^20 and (bit0 * M) >> 20 is the exact quotient (and fits 32 bits)
@@ -449,7 +455,7 @@ __device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgp
 			}
 			const bool exc = idx == ds;
 			R.left[m][j]   = left;
-			R.ballot[m][j] = __ballot(exc);
+			R.ballot[m][j] = ballot64(exc);
 			if (order.valid && R.ballot[m][j] != 0) { // rare, wave-uniform: the reference's index for a left part outside the dictionary
 				const int ridx = rd_exception_index(order, left);
 				idx            = exc ? ridx : idx;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void second_level_select_f32(const VecInF& in, const 
 			const int32_t  enc   = encode_value_f32(sv, kExpArrF[e], kFracArrF[f]);
 			const float    dec   = decode_value_f32(enc, kFactArrF[f], kFracArrF[e]);
 			const bool     ok    = dec == sv;
-			const uint64_t bal   = __ballot(!ok);
+			const uint64_t bal   = ballot64(!ok);
 			const uint32_t excs  = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
 			int32_t        mx    = ok ? enc : INT32_MIN;
 			int32_t        mn    = ok ? enc : INT32_MAX;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 			const float   dec     = decode_value_f32(enc, fact, frac_e);
 			const bool    exc     = dec != vv;
 			R.enc[m][j]           = enc;
-			R.ballot[m][j]        = __ballot(exc);
+			R.ballot[m][j]        = ballot64(exc);
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
 		}
 	}

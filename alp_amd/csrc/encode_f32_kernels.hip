@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 						if (dd < ds && dict[dd] == left) { idx = dd; }
 					}
 					const bool exc = idx == ds;
-					ballots[m][j]  = __ballot(exc);
+					ballots[m][j]  = ballot64(exc);
 					if (order.valid && ballots[m][j] != 0) { // the reference's index for a left part outside the dictionary
 						const int ridx = rd_exception_index(order, left);
 						idx            = exc ? ridx : idx;

@@ -269,6 +269,17 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void k_encode_pack(const double* 
 // every spin is bounded, a stall sets totals[3] and nothing of a stalled tile is written; the two-pass kernels enqueued behind
 // every single-pass encode (gated on that flag: launch_encode_recovery) then redo the column on the same stream.  The field widths bound one launch to kFusedMaxVectors vectors;
 // longer columns are chained launch by launch through totals[0..1].  Where a wavefront's time goes: profiles/r01_fused_phases.txt.
+#ifdef ALPGPU_FUSED_TIMING // experiment (tools/fused_phases.py): per-wavefront phase marks, 10 ns ticks since the wavefront started
+__device__ int32_t* g_phase_buf = nullptr; // [n_vectors][8]
+#define PHASE_WAIT_MEM() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define PHASE_MARK(k)                                                                                                        \
+	do {                                                                                                                 \
+		if (g_phase_buf != nullptr && lane == 0 && live) { g_phase_buf[8 * vl + (k)] = static_cast<int32_t>(wall_clock64() - phase_t0); } \
+	} while (0)
+#else
+#define PHASE_WAIT_MEM()
+#define PHASE_MARK(k)
+#endif
 __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double* __restrict__ in,
                                                                    const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                    alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
@@ -284,6 +295,9 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	const int            lane = lane_id();
 	const int            wave = wave_in_wg();
 	const uint64_t       tile = blockIdx.x;
+#ifdef ALPGPU_FUSED_TIMING
+	const uint64_t phase_t0 = wall_clock64();
+#endif
 	if (threadIdx.x == 0) {
 		s_count = 0;
 		s_ready = 0;
@@ -313,6 +327,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	const uint64_t base_p = totals[0], base_e = totals[1];
 	if (live) {
 		x        = load_vector(in, v, lane);
+		PHASE_WAIT_MEM();
+		PHASE_MARK(0);
 		d.scheme = rgp->scheme;
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
@@ -322,8 +338,10 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 				e = rgp->combos[0];
 				f = rgp->combos[1];
 			}
+			PHASE_MARK(1);
 			AlpEncoded R;
 			encode_alp_registers(x, e, f, lane, R);
+			PHASE_MARK(2);
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
 			cnt = R.cnt;
 			ulonglong2*    lv   = reinterpret_cast<ulonglong2*>(L.vals);
@@ -373,9 +391,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	// The packed words do not depend on where they will be stored: build them now, in registers, while the ordered offset is
 	// still on its way (a wavefront otherwise idles ~40 % of its life here: profiles/r01_fused_phases.txt); wavefront 0 packs
 	// first as well, its look-back then finds more of its predecessors already posted.
+	PHASE_MARK(3);
 	PackedUnits packed_units;
 	wave_lds_sync(); // this wavefront's staged values
-	pack_u64_units(L, d.bw, lane, packed_units);
+	pack_u64_units(L.vals, d.bw, lane, packed_units);
+	PHASE_MARK(4);
 	// Likewise the exception record: its image is laid out in the (now free) staging area, so that after the wait it leaves as a
 	// few contiguous 8-byte-per-lane stores instead of two one-lane stores per exception step, and the input values need not
 	// stay in registers across the wait.  The values always fit (8 B x 1024); the positions follow them when the whole record
@@ -402,6 +422,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 		});
 		wave_lds_sync();
 	}
+	PHASE_MARK(5);
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
 	{
 		uint32_t spins = 0;
@@ -415,6 +436,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
 	const uint64_t excl = s_excl;
 	if (excl == ~0ull) { return; } // stalled: nothing of this tile is written
+	PHASE_MARK(6);
 
 	// ---- 4. write at the final offsets ----
 	const uint64_t pre    = excl + local;
@@ -458,8 +480,14 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	}
 #endif
 	if (lane == 0) { descs[v] = d; }
+	PHASE_MARK(7);
 }
 
+#ifdef ALPGPU_FUSED_TIMING
+extern "C" __attribute__((visibility("default"))) int alpgpu_debug_fused_phases(void* buf) {
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // publishes the running totals after a fused launch (single thread; keeps totals[0..1] stable while the launch runs) and
 // latches the stall flag into totals[6], the gate of the recovery kernels (k_scan_totals clears totals[3] on its way)

@@ -107,7 +107,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 		for (;;) {
 			const uint64_t st = fresh1 ? first1 : (lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate);
 			fresh1            = false;
-			if (__ballot((st >> 62) == 0) == 0) {
+			if (ballot64((st >> 62) == 0) == 0) {
 				local = wave_sum_u64(st & ~(3ull << 62));
 				break;
 			}
@@ -142,8 +142,8 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 			const uint64_t st         = fresh2 ? first2 : (idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix);
 			fresh2                    = false;
 			const uint64_t fl         = st >> 62;
-			const uint64_t has_prefix = __ballot(fl == 2);
-			const uint64_t invalid    = __ballot(fl == 0);
+			const uint64_t has_prefix = ballot64(fl == 2);
+			const uint64_t invalid    = ballot64(fl == 0);
 			const int      first_p    = has_prefix ? __builtin_ctzll(has_prefix) : 64;
 			const uint64_t upto       = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull); // lanes 0..first_p
 			uint64_t late = 0; // sizes of nearer blocks whose word is not there yet, summed from their 64 tile words
@@ -154,7 +154,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 				for (uint64_t inv = invalid & upto; inv != 0 && ready; inv &= inv - 1) { // wave-uniform
 					const uint64_t blk = static_cast<uint64_t>(look - __builtin_ctzll(inv));
 					const uint64_t w   = status_load(status + blk * kBlockTiles + lane);
-					ready              = __ballot((w >> 62) == 0) == 0;
+					ready              = ballot64((w >> 62) == 0) == 0;
 					late += wave_sum_u64(w & ~(3ull << 62));
 				}
 				if (!ready) {

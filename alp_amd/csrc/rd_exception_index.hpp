@@ -45,7 +45,7 @@ __device__ __forceinline__ RdOrderView load_rd_order(const uint16_t* __restrict_
 	for (int i = 0; i < 8; ++i) { mine = lane == i ? rg.rd_dict[i] : mine; }
 	const bool     bad  = lane < V.ds && V.keys[0] != mine;
 	V.count = D;
-	V.valid = __ballot(bad) == 0;
+	V.valid = ballot64(bad) == 0;
 	return V;
 }
 

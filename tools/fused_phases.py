@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Experiment (needs alp_amd/libalpgpu_timing.so built with -DALPGPU_FUSED_TIMING): average cycles a wavefront of
-k_encode_fused spends in each phase.  usage: ALPGPU_LIB=.../libalpgpu_timing.so python tools/fused_phases.py [kind] [n]"""
+"""Experiment (needs a library built with -DALPGPU_FUSED_TIMING, tools/build_variant.sh timing -DALPGPU_FUSED_TIMING): where a
+wavefront of k_encode_fused spends its life.  Every wavefront leaves 8 marks (10 ns ticks since it started):
+0 input + rowgroup state arrived, 1 (e,f) chosen, 2 encoded, 3 staged + size posted, 4 packed, 5 exception image laid out,
+6 ordered offset known, 7 stores issued.   usage: ALPGPU_LIB=.../libalpgpu_timing.so python tools/fused_phases.py [kind] [n]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,26 +15,27 @@ ctx = capi.Context(0)
 x = synthetic_input(kind, n, torch.device("cuda:0"), seed=42)
 col = capi.DeviceColumn(n, 0)
 ctx.rowgroup_init(x, col)
-ctx.encode_vectors(x, col); ctx.synchronize()
-buf = torch.zeros(n * 4, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    ctx.encode_vectors(x, col)
+ctx.synchronize()
+buf = torch.zeros(n * 8, dtype=torch.int32, device="cuda")
 capi.lib.alpgpu_debug_fused_phases.argtypes = [C.c_void_p]
-capi.lib.alpgpu_debug_fused_phases(C.c_void_p(buf.data_ptr()))
-lb = torch.zeros((n + 3) // 4 * 4, dtype=torch.int32, device="cuda")
-if hasattr(capi.lib, "alpgpu_debug_lookback_phases"):
-    capi.lib.alpgpu_debug_lookback_phases.argtypes = [C.c_void_p]
-    capi.lib.alpgpu_debug_lookback_phases(C.c_void_p(lb.data_ptr()))
+assert capi.lib.alpgpu_debug_fused_phases(C.c_void_p(buf.data_ptr())) == 0
 med, _ = time_launches(lambda: ctx.encode_vectors(x, col), 5, 1)
 ctx.synchronize()
-t = buf.view(n, 4).to(torch.float64)
-names = ["input load", "encode + stage", "ordered offset (look-back / wait)", "records + pack + stores"]
-tot = float(t.sum())
-print(f"{kind}: encode_vectors median {med:.3f} ms for {n} vectors; per-wavefront phase lengths (shader clock ticks):")
-for k in range(4):
-    col_k = t[:, k]
-    print(f"  {names[k]:36s} mean {float(col_k.mean()):9.1f}  median {float(col_k.median()):9.1f}  p95 {float(col_k.kthvalue(int(0.95 * n)).values):9.1f}   {100.0 * float(col_k.sum()) / tot:5.1f} %")
-w0 = t.view(-1, 4, 4)[:, 0, 2]
-print(f"  look-back of wavefront 0 alone: mean {float(w0.mean()):.1f}")
-L = lb.view(-1, 4).to(torch.float64)
-for k, nm in enumerate(["level-1 ticks", "level-1 rounds", "level-2 ticks", "level-2 rounds"]):
-    c = L[:, k]
-    print(f"  look-back {nm:16s} mean {float(c.mean()):9.1f}  median {float(c.median()):9.1f}  p95 {float(c.kthvalue(int(0.95 * c.numel())).values):9.1f}")
+capi.lib.alpgpu_debug_fused_phases(C.c_void_p(0))
+t = buf.view(n, 8).to(torch.float64) * 0.01  # microseconds
+names = ["input + state arrive", "second-level (e,f)", "encode arithmetic", "stage + post size", "pack into registers",
+         "exception image", "wait for ordered offset", "stores issued"]
+print(f"{kind}: encode_vectors median {med:.3f} ms for {n} vectors WITH marks; phase lengths per wavefront, microseconds:")
+prev = torch.zeros(n, dtype=torch.float64, device="cuda")
+life = t[:, 7]
+for k in range(8):
+    d = t[:, k] - prev
+    prev = t[:, k]
+    q = lambda f: float(d.kthvalue(max(1, int(f * n))).values)
+    print(f"  {names[k]:26s} mean {float(d.mean()):7.2f}  p10 {q(0.1):7.2f}  median {q(0.5):7.2f}  p90 {q(0.9):7.2f}   {100.0 * float(d.sum()) / float(life.sum()):5.1f} %")
+print(f"  life of a wavefront        mean {float(life.mean()):7.2f}  median {float(life.median()):7.2f}")
+w = t.view(-1, 8, 8)
+print(f"  wavefront 0 (runs the look-back): wait {float((w[:, 0, 6] - w[:, 0, 5]).mean()):.2f}; others {float((w[:, 1:, 6] - w[:, 1:, 5]).mean()):.2f}")
+print(f"  spread of 'size posted' inside a tile (max - min over its 8 wavefronts): mean {float((w[:, :, 3].max(dim=1).values - w[:, :, 3].min(dim=1).values).mean()):.2f}")
