@@ -332,7 +332,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 		d.scheme = rgp->scheme;
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
+#ifdef ALPGPU_ABLATE_SECOND
+			if (false) {
+#else
 			if (rgp->k > 1) {
+#endif
 				second_level_select(x, rgp, L, lane, e, f);
 			} else {
 				e = rgp->combos[0];
@@ -394,7 +398,12 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	PHASE_MARK(3);
 	PackedUnits packed_units;
 	wave_lds_sync(); // this wavefront's staged values
+#ifdef ALPGPU_ABLATE_PACK
+#pragma unroll
+	for (int t = 0; t < 8; ++t) { packed_units.acc[t] = ull2v{0ull, 0ull}; }
+#else
 	pack_u64_units(L.vals, d.bw, lane, packed_units);
+#endif
 	PHASE_MARK(4);
 	// Likewise the exception record: its image is laid out in the (now free) staging area, so that after the wait it leaves as a
 	// few contiguous 8-byte-per-lane stores instead of two one-lane stores per exception step, and the input values need not
@@ -404,7 +413,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	const uint32_t val_bytes    = alp_rec ? 8u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
 	const bool     pos_staged   = my_e <= sizeof(L.vals);
 	const uint32_t staged_bytes = pos_staged ? static_cast<uint32_t>(my_e) : val_bytes;
+#ifdef ALPGPU_ABLATE_EXC
+	if (false) {
+#else
 	if (cnt > 0) {
+#endif
 		uint8_t* img = reinterpret_cast<uint8_t*>(L.vals);
 		wave_lds_sync(); // the pack's reads of the staging area are issued; the LDS executes one wavefront's operations in order
 		if (lane == 0) { reinterpret_cast<uint64_t*>(img)[(staged_bytes >> 3) - 1] = 0ull; } // the pad lives in the last word
@@ -457,7 +470,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 #ifdef ALPGPU_ABLATE_STORES // timing experiment: everything but the output stores
 	if (packed_capacity == 1) {
 #endif
+#ifdef ALPGPU_ABLATE_EXC
+	if (false) {
+#else
 	if (cnt > 0) {
+#endif
 		const uint64_t* img64 = reinterpret_cast<const uint64_t*>(L.vals);
 		uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
 		const int       n_w   = static_cast<int>(staged_bytes >> 3);
