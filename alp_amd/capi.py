@@ -72,6 +72,7 @@ _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
 OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL = 1, 2, 3, 4
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
+_sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
 _sig("alpgpu_use_own_stream", _int, _vp)
@@ -182,6 +183,10 @@ class Context:
 
     def synchronize(self):
         _check(lib.alpgpu_synchronize(self.h), "alpgpu_synchronize")
+
+    def traffic_probe(self, x, out, n_vectors: int, write_bytes_per_vector: int):
+        """the single-pass encode's loads and stores without its arithmetic (include/alpgpu.h: alpgpu_debug_traffic_probe)"""
+        _check(lib.alpgpu_debug_traffic_probe(self.h, _vp(x.data_ptr()), _vp(out.data_ptr()), n_vectors, write_bytes_per_vector), "alpgpu_debug_traffic_probe")
 
     def decode_vectors_per_wg(self, col: "DeviceColumn") -> int:
         """the launch shape decode() would use for this column now (vectors per decode workgroup)"""

@@ -326,6 +326,17 @@ int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int 
 	return (decode_variant_for(ctx, col) & 1) ? 1 : 2;
 }
 
+// measurement aid: the single-pass encode's loads and stores without its arithmetic (encode_kernels.hip: k_traffic_probe)
+int alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (n_vectors == 0) { return ALPGPU_OK; }
+	if (!d_in || !d_out || write_bytes_per_vector % 16u != 0 || write_bytes_per_vector > 8192u) { return fail(ALPGPU_ERR_INVALID, "bad probe arguments"); }
+	if (alpgpu::launch_traffic_probe(ctx->stream, d_in, d_out, n_vectors, write_bytes_per_vector) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "traffic probe launch failed", hipGetLastError());
+	}
+	return ALPGPU_OK;
+}
+
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }

@@ -514,6 +514,31 @@ __global__ void k_fused_finish(uint64_t* __restrict__ totals) {
 	if (totals[3] != 0) { totals[6] = 1; }
 }
 
+// ---- the single-pass encode's memory traffic and nothing else (alpgpu_debug_traffic_probe) ---------------------------------------
+// Same launch shape (one wavefront per vector, kFusedWaves per workgroup, grid = tiles, in order): every vector is read once and
+// `units` 16-byte units are written at v * units, the stored data depending on everything that was read.  bench.py quotes its
+// rate as the measured ceiling for this read/write mix next to the nominal HBM peak.
+__global__ __launch_bounds__(64 * kFusedWaves) void k_traffic_probe(const ull2v* __restrict__ in, ull2v* __restrict__ out, uint64_t n_vectors, uint32_t units) {
+	const int      lane = lane_id();
+	const uint64_t v    = static_cast<uint64_t>(blockIdx.x) * kFusedWaves + wave_in_wg();
+	if (v >= n_vectors) { return; }
+	ull2v acc = {v, 1ull};
+#pragma unroll
+	for (int m = 0; m < 8; ++m) { acc += in[v * 512 + 64 * m + lane]; }
+	ull2v* dst = out + v * units;
+	for (uint32_t u = lane; u < units; u += 64) {
+		ull2v o = acc;
+		o.x += u;
+		dst[u] = o;
+	}
+}
+int launch_traffic_probe(hipStream_t stream, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes) {
+	const uint64_t n_tiles = (n_vectors + kFusedWaves - 1) / kFusedWaves;
+	hipLaunchKernelGGL(k_traffic_probe, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, static_cast<const ull2v*>(d_in),
+	                   static_cast<ull2v*>(d_out), n_vectors, write_bytes / 16u);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
 uint64_t encode_workspace_bytes(uint64_t n_vectors) {
 	const uint64_t two_pass = ((n_vectors + kScanTile - 1) / kScanTile) * 16 + 16;
 	const uint64_t per_launch = n_vectors < kFusedMaxVectors ? n_vectors : kFusedMaxVectors;

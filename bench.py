@@ -562,6 +562,17 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     fill_gbps = out.numel() * 8 / fmed / 1e6
     extras["measured_fill_ceiling"] = {"GBps_write": round(fill_gbps, 1), "frac_of_nominal_peak": round(fill_gbps / HBM_PEAK_GBPS, 4),
                                        "note": "torch tensor.fill_ of 8 GiB, median of 7 after 10 warm-up fills"}
+    # and one for the ENCODE's read/write mix: the single-pass kernel's loads and stores in its own launch shape with no arithmetic in
+    # between (alpgpu_debug_traffic_probe) — 8 KiB read per vector, the column's average compressed bytes written
+    probe_in = torch.empty(n * VEC, dtype=torch.float64, device=dev).fill_(1.0)
+    for label in ("encode_alp_mixed", "encode_alp_rd"):
+        wb = int(extras[label]["compressed_bits_per_value"] * VEC / 8) // 16 * 16
+        pmed, _ = time_launches(lambda: ctx.traffic_probe(probe_in, out, n, wb), 7, 5)
+        vec_ms = extras[label]["ms"] - extras[label]["rowgroup_init_ms"]
+        extras[label]["traffic_only_probe"] = {"ms": round(pmed, 3), "GBps_read_plus_write": round(n * (8192 + wb) / pmed / 1e6, 1), "written_bytes_per_vector": wb,
+                                               "vector_encode_ms": round(vec_ms, 3), "vector_encode_vs_probe": round(pmed / vec_ms, 4),
+                                               "note": "same launch shape as k_encode_fused, loads + dependent stores only; the encode cannot be faster than this plus the rowgroup search"}
+    del probe_in
     # single precision: alpgpu_encode_f32 / alpgpu_decode_f32 on 1 Mi float vectors (4 GiB decoded)
     fl = {}
     outf = out.view(torch.float32)[: n * VEC]

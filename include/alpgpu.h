@@ -159,6 +159,11 @@ int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
 int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
+/* Measurement aid, not part of the codec: launches the memory traffic of the single-pass encode without its arithmetic — the same
+ * launch shape, every 8 KiB vector of d_in read once, write_bytes_per_vector (a multiple of 16, <= 8192) written per vector at
+ * d_out + v * write_bytes_per_vector, stored data depending on all loaded data.  bench.py times it to put a measured ceiling for the
+ * encode's read/write mix next to the nominal HBM peak. */
+int         alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
 
