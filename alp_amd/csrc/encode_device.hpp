@@ -16,6 +16,10 @@
 
 namespace alpgpu {
 
+#ifndef ALPGPU_ENCODE_GROUP
+#define ALPGPU_ENCODE_GROUP 2
+#endif
+
 struct __attribute__((aligned(16))) EncodeLds {
 	uint64_t vals[kVec]; // (enc - base) or RD right parts, natural index order: 8 KiB
 	double   smp[32];    // second-level samples
@@ -233,50 +237,78 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 	// v_min_f64 / v_max_f64 ignore; exception slots later hold the filler, which is itself a non-exception's value.
 	const double qnan = __longlong_as_double(0x7FF8000000000000ll);
 	double       rmin = qnan, rmax = qnan;
+	// Straight-line groups of kGroup value steps: all their floating-point chains first (independent of each other, so the
+	// scheduler can interleave them), then their lane masks, then ONE wave-uniform test for the rare literal route.  A branch per
+	// value step cuts the code into blocks of one 7-deep dependent chain each, and a wavefront with two or three neighbours on its
+	// SIMD spends most of such a block waiting for its own previous result.
+	constexpr int kGroup = ALPGPU_ENCODE_GROUP; // value steps (of 2 values) per group: 1, 2, 4 or 8
 #pragma unroll
-	for (int m = 0; m < 8; ++m) {
+	for (int m0 = 0; m0 < 8; m0 += kGroup) {
+		double   vv[kGroup][2], tt[kGroup][2], rr[kGroup][2], dec[kGroup][2];
+		int64_t  enc[kGroup][2];
+		uint64_t over_m[kGroup][2], wide_m[kGroup][2];
+		uint64_t any_wide = 0;
 #pragma unroll
-		for (int j = 0; j < 2; ++j) {
-			const double   v    = j == 0 ? in.x[m].x : in.x[m].y;
-			const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(v));
-			// pass 1 (encoder.hpp:326-338): for doubles only -0.0 matches (the mask literal evaluates to 0xFFE0000000000000,
-			// SURVEY.md §8 A6) and is replaced by a value that cannot round-trip; NaN/Inf go through the arithmetic and fail the
-			// compare.  Here -0.0 simply goes through as well (it encodes to 0 and decodes to +0.0, which == would accept) and is
-			// made an exception by its bit pattern below: one compare instead of a compare and two selects per step.
-			const double vv = v;
-			double       t  = vv * exp10;
-			t               = t * frac_f;
-			const double u  = t + kMagic;
-			const double r  = u - kMagic;
-			int64_t      enc = static_cast<int64_t>(static_cast<uint64_t>(__double_as_longlong(u)) - 0x4338000000000000ull);
-			const double prod = r * fact_d;
-			double       dec  = prod * frac_e;
-			// |prod| > 2^63 (prod = fl(P), P = enc * 10^f exactly): the reference's int64 product wraps, and the wrapped value can
-			// never decode to v — for |P| < 2^64 it has the opposite sign of v and is not zero, for larger |P| its magnitude is below
-			// 2^63 while |v| 10^e > 0.96 * 2^64 — so the value is an exception without computing it.  Two-decimal values up to 10^5
-			// land here all the time: the reference's search gives them (e,f) = (14,12), and |v| >= 92 233.72 wraps.  Only
-			// |t| >= 2^51 (incl. Inf), NaN and |prod| == 2^63 exactly (P = -2^63 is representable) take the literal route.
-			// Every test goes straight from its compare into a lane mask (ballot of a compare = the compare's own SGPR result) and the
-			// masks are combined as 64-bit integers on the scalar unit; a predicate built from several compares and then balloted
-			// is first materialised per lane (v_cndmask) and compared again.
-			const double   ap     = __builtin_fabs(prod);
-			const uint64_t over_m = ballot64(ap > 0x1p63);                       // the product wraps for sure
-			const uint64_t wide_m = ballot64(!(__builtin_fabs(t) < 0x1p51)) | (ballot64(!(ap < 0x1p63)) & ~over_m); // |t| >= 2^51, NaN, |prod| == 2^63
-			if (__builtin_expect(wide_m != 0, 0)) { // wave-uniform, rare: the literal path of alp_device.hpp (kept out of the fall-through path)
-				enc = cast64_x86(r);
-				dec = decode_value(enc, fact, frac_e);
+		for (int g = 0; g < kGroup; ++g) {
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+				// pass 1 (encoder.hpp:326-338): for doubles only -0.0 matches (the mask literal evaluates to 0xFFE0000000000000,
+				// SURVEY.md §8 A6) and is replaced by a value that cannot round-trip; NaN/Inf go through the arithmetic and fail the
+				// compare.  Here -0.0 simply goes through as well (it encodes to 0 and decodes to +0.0, which == would accept) and is
+				// made an exception by its bit pattern below.
+				const double v = j == 0 ? in.x[m0 + g].x : in.x[m0 + g].y;
+				double       t = v * exp10;
+				t              = t * frac_f;
+				const double u = t + kMagic;
+				const double r = u - kMagic;
+				const double prod = r * fact_d;
+				vv[g][j]  = v;
+				tt[g][j]  = t;
+				rr[g][j]  = r;
+				dec[g][j] = prod * frac_e;
+				enc[g][j] = static_cast<int64_t>(static_cast<uint64_t>(__double_as_longlong(u)) - 0x4338000000000000ull);
+				// |prod| > 2^63 (prod = fl(P), P = enc * 10^f exactly): the reference's int64 product wraps, and the wrapped value can
+				// never decode to v — for |P| < 2^64 it has the opposite sign of v and is not zero, for larger |P| its magnitude is below
+				// 2^63 while |v| 10^e > 0.96 * 2^64 — so the value is an exception without computing it.  Two-decimal values up to 10^5
+				// land here all the time: the reference's search gives them (e,f) = (14,12), and |v| >= 92 233.72 wraps.  Only
+				// |t| >= 2^51 (incl. Inf), NaN and |prod| == 2^63 exactly (P = -2^63 is representable) take the literal route.
+				// Every test goes straight from its compare into a lane mask (ballot of a compare = the compare's own SGPR result) and
+				// the masks are combined as 64-bit integers on the scalar unit.
+				const double ap = __builtin_fabs(prod);
+				over_m[g][j]    = ballot64(ap > 0x1p63);                                                                   // the product wraps for sure
+				wide_m[g][j]    = ballot64(!(__builtin_fabs(t) < 0x1p51)) | (ballot64(!(ap < 0x1p63)) & ~over_m[g][j]); // |t| >= 2^51, NaN, |prod| == 2^63
+				any_wide |= wide_m[g][j];
 			}
-			// The round trip holds iff the BITS agree: dec is never -0.0 (a product of an integer-valued double, or of a converted
-			// int64, with positive powers of ten that cannot underflow) and never NaN on the literal route, which a NaN input always
-			// takes; so -0.0 (encodes to 0, decodes to +0.0: pass 1 of encoder.hpp:326-338 makes it an exception) and NaN fail the
-			// integer compare exactly where the reference's float compare plus its special-value pass do.
-			const uint64_t exc_m = ballot64(static_cast<uint64_t>(__double_as_longlong(dec)) != bits) | over_m;
-			R.enc[m][j]    = enc;
-			R.ballot[m][j] = exc_m;
-			R.cnt += __builtin_popcountll(exc_m);
-			if (!lane_in(exc_m)) { // lanes of exceptions sit this one out (exec mask) instead of feeding a quiet NaN through a select
-				rmin = fmin_num(rmin, r);
-				rmax = fmax_num(rmax, r);
+		}
+		if (__builtin_expect(any_wide != 0, 0)) { // wave-uniform, rare: the literal path of alp_device.hpp for the steps that need it
+#pragma unroll
+			for (int g = 0; g < kGroup; ++g) {
+#pragma unroll
+				for (int j = 0; j < 2; ++j) {
+					if (wide_m[g][j] != 0) {
+						enc[g][j] = cast64_x86(rr[g][j]);
+						dec[g][j] = decode_value(enc[g][j], fact, frac_e);
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int g = 0; g < kGroup; ++g) {
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+				// The round trip holds iff the BITS agree: dec is never -0.0 (a product of an integer-valued double, or of a
+				// converted int64, with positive powers of ten that cannot underflow) and never NaN on the literal route, which a NaN
+				// input always takes; so -0.0 (encodes to 0, decodes to +0.0: pass 1 makes it an exception) and NaN fail the integer
+				// compare exactly where the reference's float compare plus its special-value pass do.
+				const uint64_t exc_m = ballot64(__double_as_longlong(dec[g][j]) != __double_as_longlong(vv[g][j])) | over_m[g][j];
+				R.enc[m0 + g][j]     = enc[g][j];
+				R.ballot[m0 + g][j]  = exc_m;
+				R.cnt += __builtin_popcountll(exc_m);
+				// min / max over r; a quiet NaN — only the high word is replaced — makes v_min / v_max_f64 skip an exception's lane
+				const uint64_t rb = static_cast<uint64_t>(__double_as_longlong(rr[g][j]));
+				const double   rm = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(lane_in(exc_m) ? 0x7FF80000u : static_cast<uint32_t>(rb >> 32)) << 32) | (rb & 0xFFFFFFFFull)));
+				rmin = fmin_num(rmin, rm);
+				rmax = fmax_num(rmax, rm);
 			}
 		}
 	}
