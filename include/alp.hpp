@@ -20,7 +20,6 @@
 #include "alp/falp.hpp"
 #include "alp/rd.hpp"
 #include "alp/batch.hpp"
-#include "alp/storer.hpp"
 #include "fastlanes/ffor.hpp"
 #include "fastlanes/unffor.hpp"
 
