@@ -33,7 +33,7 @@ int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vec
                           int n_cus, const uint64_t* gate = nullptr);
 int launch_scan_offsets(hipStream_t stream, const alpgpu_column* col, uint64_t n_vectors, uint64_t* d_workspace, bool f32, const uint64_t* gate);
 
-// container.hip
+// pad_kernels.hip
 int launch_pad_tail(hipStream_t stream, double* d_in, uint64_t n_values);
 
 // primitive_kernels.hip
