@@ -4,7 +4,9 @@
 #   dec : python bench.py --steps 20 --warmup 10 --no-extras          (k_decode_column on the benchmark column)
 #   enc : python tools/prof_encode.py mixed 1048576                    (k_rowgroup_init, k_encode_fused)
 #   encf: python tools/prof_encode_f32.py decimal1 1048576             (k_rowgroup_init<f32>, k_encode_fused_f32) + float decode
-# raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_*
+# raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_* (run the summary LOCALLY on the
+# merged directory, and remove a stale local gpurun_out/<tag>_prof first: rocprofv3 names its files after process ids, a second run
+# does not overwrite the first)
 TAG=$1
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${TAG}_prof
