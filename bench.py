@@ -307,8 +307,9 @@ def cpu_encode_baseline(x_gpu: torch.Tensor, ecol, budget_s: float = 10.0):
 class Clock:
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; MAX over ranks."""
 
-    def __init__(self, dist, dev):
+    def __init__(self, dist, dev, reduce_on=None):
         self.dist, self.dev = dist, dev
+        self.reduce_on = reduce_on if reduce_on is not None else dev  # where the reductions' tensors live (the device, for RCCL)
 
     def barrier(self):
         torch.cuda.synchronize()
@@ -330,7 +331,7 @@ class Clock:
         elapsed = time.perf_counter() - t0
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # average step duration (HIP events, launch stream)
         if self.dist is not None:
-            t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=self.dev)
+            t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=self.reduce_on)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed, kern_ms = float(t[0]), float(t[1])
         return elapsed, kern_ms
@@ -338,7 +339,7 @@ class Clock:
     def total(self, x: int) -> int:
         if self.dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.int64, device=self.dev)
+        t = torch.tensor([x], dtype=torch.int64, device=self.reduce_on)
         self.dist.all_reduce(t)
         return int(t[0])
 
@@ -376,15 +377,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Test knob (tests/test_bench_gpu.py): all ranks share GPU 0 and talk over gloo, so that a ONE-GPU box can run the N > 1 code path
+    # end to end (rank > 0 shards, the reductions, rank 0's line).  RCCL refuses two ranks on one device; nothing is measured this way.
+    shared_gpu = bool(os.environ.get("ALPGPU_BENCH_TEST_SHARED_GPU"))
+    if shared_gpu:
+        local_rank = 0
     if world > 1 or os.environ.get("ALPGPU_BENCH_FORCE_DIST"):  # (the env var lets a 1-GPU box exercise the N > 1 code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; alp_amd has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     ctx = capi.Context(local_rank)  # launches on torch's current stream of this device
-    clock = Clock(dist, dev)
+    clock = Clock(dist, dev, reduce_on=torch.device("cpu") if shared_gpu else dev)
 
     sharded = world > 1 or args.column_gb is not None
     if sharded:
