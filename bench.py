@@ -126,9 +126,10 @@ MIX_BLOCK_RG = 640  # rowgroups per generation block of the mixed column: blocks
 #                     seeded by their index, so the column is the same however it is sharded
 
 
-def mixed_block(block: int, device, seed: int) -> torch.Tensor:
+def mixed_block(block: int, device, seed: int, exc_rate: float = 0.01) -> torch.Tensor:
     """rowgroups [block * MIX_BLOCK_RG, (block + 1) * MIX_BLOCK_RG) of the mixed column: round(x, d) with x ~ U(-1e5, 1e5),
-    d cycling 1, 2, 4 by (global) rowgroup; 1 % full-precision values (exceptions); 0.1 % specials (NaN, +-Inf, -0.0)"""
+    d cycling 1, 2, 4 by (global) rowgroup; exc_rate (1 %) full-precision values (injected exceptions, SURVEY.md §8(d) mix 3: rates
+    0 / 1 % / 10 %); 0.1 % specials (NaN, +-Inf, -0.0)"""
     g = torch.Generator(device=device)
     g.manual_seed(seed * 1_000_003 + block)
     n = MIX_BLOCK_RG * RG * VEC
@@ -137,7 +138,7 @@ def mixed_block(block: int, device, seed: int) -> torch.Tensor:
     sc = torch.tensor([10.0, 100.0, 10000.0], dtype=torch.float64, device=device)[rg % 3].repeat_interleave(RG * VEC)
     out = torch.round(x * sc) / sc
     del sc
-    m = torch.rand(n, device=device, generator=g) < 0.01
+    m = torch.rand(n, device=device, generator=g) < exc_rate
     out[m] = x[m] * 3.141592653589793
     del m, x
     sp = torch.rand(n, device=device, generator=g) < 0.001
@@ -146,7 +147,7 @@ def mixed_block(block: int, device, seed: int) -> torch.Tensor:
     return out
 
 
-def mixed_column_shard(first_vector: int, n_vectors: int, device, seed: int, out: torch.Tensor | None = None) -> torch.Tensor:
+def mixed_column_shard(first_vector: int, n_vectors: int, device, seed: int, out: torch.Tensor | None = None, exc_rate: float = 0.01) -> torch.Tensor:
     """vectors [first_vector, first_vector + n_vectors) of the (global) mixed column, block by block"""
     if out is None:
         out = torch.empty(n_vectors * VEC, dtype=torch.float64, device=device)
@@ -154,7 +155,7 @@ def mixed_column_shard(first_vector: int, n_vectors: int, device, seed: int, out
     v = first_vector
     while v < first_vector + n_vectors:
         b = v // per
-        blk = mixed_block(b, device, seed)
+        blk = mixed_block(b, device, seed, exc_rate)
         lo = v - b * per
         hi = min(per, first_vector + n_vectors - b * per)
         out[(v - first_vector) * VEC:(v - first_vector + hi - lo) * VEC] = blk[lo * VEC:hi * VEC]
@@ -169,7 +170,7 @@ def synthetic_input(kind: str, n_vectors: int, device, seed: int):
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         return torch.rand(n_vectors * VEC, dtype=torch.float64, device=device, generator=g)
-    return mixed_column_shard(0, n_vectors, device, seed)
+    return mixed_column_shard(0, n_vectors, device, seed, exc_rate={"mixed": 0.01, "mixed_exc0": 0.0, "mixed_exc10": 0.10}[kind])
 
 
 # ---- the reference's CPU path on this box's host cores (the only place bench.py touches oracle/) ---------------------------
@@ -540,7 +541,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     del sums
     # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
     enc_cpu = None
-    for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd")):
+    for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd"), ("mixed_exc0", "encode_alp_mixed_exc0"), ("mixed_exc10", "encode_alp_mixed_exc10")):
         x = synthetic_input(kind, n, dev, seed=42)
         ecol = capi.DeviceColumn(n, local_rank)
         med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
