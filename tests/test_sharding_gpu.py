@@ -83,3 +83,69 @@ def test_full_size_benchmark_column_decodes_like_the_oracle(ctx, oracle):
     lo_ok = (scaled >= base[:, None] - 0.5).all(dim=1)
     hi_ok = (scaled < (base + span)[:, None] + 0.5).all(dim=1)
     assert bool((lo_ok & hi_ok)[narrow].all())
+
+
+@pytest.mark.parametrize("kind", ["mixed", "rd"])
+def test_full_size_encode_columns(ctx, oracle, kind):
+    """BASELINE.json configs[2] / configs[3] at their real size (1 Mi vectors, bench.py's on-device generator): the size-independent
+    properties — the GPU decode of the GPU encode returns the input bits; the single-pass and the two-pass encoders agree on every
+    byte of every stream; a second encode reproduces the first — and, on rowgroups spread over the whole column, every descriptor,
+    packed word and exception record is the oracle's."""
+    import bench
+    import layout
+    from alp_amd import capi
+    n = 1 << 20
+    dev = torch.device("cuda:0")
+    x = bench.synthetic_input(kind, n, dev, seed=42)
+
+    def encode():
+        col = capi.DeviceColumn(n, 0, packed_capacity=int(n * 8192 * 0.95) + 4096, exc_capacity=int(n * 8192 * 0.25) + 4096)
+        ctx.encode(x, col)
+        ctx.synchronize()
+        pb, eb, ov = ctx.column_totals(col)
+        assert ov == 0
+        return col, pb, eb
+
+    col, pb, eb = encode()
+    out = ctx.decode(col)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64)), "round trip"
+    del out
+
+    def same(a, b, pb, eb):
+        return (torch.equal(a.vectors, b.vectors) and torch.equal(a.rowgroups, b.rowgroups) and torch.equal(a.packed[:pb], b.packed[:pb])
+                and torch.equal(a.exc[:eb], b.exc[:eb]))
+
+    again, pb2, eb2 = encode()
+    assert (pb2, eb2) == (pb, eb) and same(col, again, pb, eb), "run to run"
+    del again
+    try:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 1)
+        two, pb3, eb3 = encode()
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
+    assert (pb3, eb3) == (pb, eb) and same(col, two, pb, eb), "single pass vs two pass"
+    del two
+    # the oracle on every 953rd rowgroup (a rowgroup's encoding depends on nothing outside it)
+    vec_all = col.vectors.cpu().numpy().view(capi.VECTOR_DTYPE)[:n]
+    rg_all = col.rowgroups.cpu().numpy().view(capi.ROWGROUP_DTYPE)[: (n + 99) // 100]
+    for g in range(0, n // 100, 953):
+        v0, v1 = g * 100, g * 100 + 100
+        vec = vec_all[v0:v1].copy()
+        p0, e0 = int(vec["packed_off"][0]), int(vec["exc_off"][0])
+        p1 = int(vec_all["packed_off"][v1]) if v1 < n else pb
+        e1 = int(vec_all["exc_off"][v1]) if v1 < n else eb
+        packed = col.packed[p0:p1].cpu().numpy()
+        exc = col.exc[e0:e1].cpu().numpy()
+        vec["packed_off"] -= p0
+        vec["exc_off"] -= e0
+        got = layout.expand(rg_all[g:g + 1], vec, packed, exc)
+        want = oracle.encode_column(x[v0 * 1024:v1 * 1024].cpu().numpy())
+        for k in ("scheme", "e", "f", "bw", "lbw", "base", "exc_cnt"):
+            assert np.array_equal(got[k], want[k]), (kind, g, k)
+        assert np.array_equal(got["packed"], want["packed"]) and np.array_equal(got["packed_left"], want["packed_left"]), (kind, g, "packed words")
+        for v in range(100):
+            c = int(want["exc_cnt"][v])
+            assert np.array_equal(got["pos"][v, :c], want["pos"][v, :c]), (kind, g, v, "positions")
+            w = np.uint64 if want["scheme"][v] == 2 else np.uint16
+            assert np.array_equal(got["exc"][v].view(w)[:c], want["exc"][v].view(w)[:c]), (kind, g, v, "exception values")
