@@ -319,14 +319,16 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	d.base                   = 0;
 	d.bw = d.e = d.f = d.lbw = 0;
 	d.exc_cnt = d.scheme = 0;
+	// The 8 KiB everything waits for are requested FIRST.  Requested behind the rowgroup state (whose unpacking into scalar
+	// registers makes the compiler wait for it on the spot) and behind the scalar read of the running totals, the vector loads
+	// started two memory round trips late — 20 % of a tile's life.  A wavefront past the end of the column reads the launch's
+	// first vector instead (nothing of it is stored).
+	const uint64_t v_read = live ? v : v_first;
+	x                     = load_vector(in, v_read, lane);
 	// the rowgroup's state, once, into registers (alp_device.hpp); its read is in flight together with the input's
-	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane);
+	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + v_read / kRowgroup, lane);
 	const alpgpu_rowgroup_state* rgp = &st;
-	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
-	// that nothing but the ordered offset stands between the wait and the stores
-	const uint64_t base_p = totals[0], base_e = totals[1];
 	if (live) {
-		x        = load_vector(in, v, lane);
 		PHASE_WAIT_MEM();
 		PHASE_MARK(0);
 		d.scheme = rgp->scheme;
@@ -392,6 +394,9 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
+	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them); read here, so
+	// that the read is neither in front of the vector's loads nor behind the wait for the ordered offset
+	const uint64_t base_p = totals[0], base_e = totals[1];
 	// The packed words do not depend on where they will be stored: build them now, in registers, while the ordered offset is
 	// still on its way (a wavefront otherwise idles ~40 % of its life here: profiles/r01_fused_phases.txt); wavefront 0 packs
 	// first as well, its look-back then finds more of its predecessors already posted.
