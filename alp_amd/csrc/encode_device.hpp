@@ -102,7 +102,15 @@ __device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint
 	const double2* p = reinterpret_cast<const double2*>(in + v * kVec);
 	VecIn          r;
 #pragma unroll
-	for (int m = 0; m < 8; ++m) { r.x[m] = p[64 * m + lane]; }
+	for (int m = 0; m < 8; ++m) {
+#ifdef ALPGPU_ENC_NT_LOAD
+		typedef double d2v __attribute__((ext_vector_type(2)));
+		const d2v q = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p) + 64 * m + lane);
+		r.x[m]      = make_double2(q.x, q.y);
+#else
+		r.x[m] = p[64 * m + lane];
+#endif
+	}
 	return r;
 }
 
@@ -422,7 +430,13 @@ __device__ __forceinline__ void store_packed_units(const PackedUnits& P, int bw,
 #pragma unroll
 	for (int t = 0; t < 8; ++t) {
 		const int u = lane + 64 * t;
-		if (64 * t < n_units && u < n_units) { out[u] = P.acc[t]; }
+		if (64 * t < n_units && u < n_units) {
+#ifndef ALPGPU_ENC_NT_STORE
+			out[u] = P.acc[t];
+#else
+			__builtin_nontemporal_store(P.acc[t], out + u); // written once, read by nobody on this device soon
+#endif
+		}
 	}
 }
 

@@ -483,7 +483,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 		const uint64_t* img64 = reinterpret_cast<const uint64_t*>(L.vals);
 		uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
 		const int       n_w   = static_cast<int>(staged_bytes >> 3);
-		for (int w = lane; w < n_w; w += 64) { rec64[w] = img64[w]; }
+		for (int w = lane; w < n_w; w += 64) {
+#ifndef ALPGPU_ENC_NT_STORE
+			rec64[w] = img64[w];
+#else
+			__builtin_nontemporal_store(img64[w], rec64 + w);
+#endif
+		}
 		if (!pos_staged) { // > 819 exceptions in an ALP vector: positions (and their pad) straight from the ballots
 			uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
 			for_each_exception(ballots, lane, [&](int r, int m, int j) { rpos[r] = static_cast<uint16_t>(128 * m + 2 * lane + j); });
