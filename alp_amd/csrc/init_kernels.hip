@@ -279,8 +279,44 @@ __global__ __launch_bounds__(kInitThreads) void k_rowgroup_init(const typename P
 	if (lane == 0 && wave < kMaxSampledVectors) { best_key[wave] = 0xFFFFFFFFu; }
 	if (wave < n_sv && !force_rd) {
 		uint32_t my_key = 0xFFFFFFFFu;
+		// Float: 66 candidates are one full round of 64 and a tail of TWO — two lanes walking 32 samples while 62 idle, half of
+		// the search's time.  The tail is turned on its side instead: half-wave h takes candidate 64 + h, its lanes one sample each;
+		// one step, then the half-wave's count (a ballot) and min / max (DPP) — the same integers, reduced in another order.
+		constexpr int  kTail       = P::kNumCombos % 64;
+		constexpr bool kTailOnSide = P::kBits == 32 && kTail > 0 && kTail <= 2;
+		constexpr int  kRounds     = kTailOnSide ? P::kNumCombos / 64 : (P::kNumCombos + 63) / 64;
+		if constexpr (kTailOnSide) {
+			const int  half   = lane >> 5, sidx = lane & 31;
+			const int  c      = P::kNumCombos - kTail + (half < kTail ? half : 0);
+			const bool active = half < kTail && sidx < samples_size;
+			const typename P::Coef k = P::coef(P::combos().e[c], P::combos().f[c]);
+			const float   v  = static_cast<float>(smp[wave * 32 + (sidx < samples_size ? sidx : 0)]);
+			const int32_t q  = encode_value_f32(v, k.exp10, k.frac_f);
+			const bool    ok = active & (decode_value_f32(q, k.fact, k.frac_e) == v);
+			const uint64_t bal     = ballot64(ok);
+			const int      non_exc = __builtin_popcount(static_cast<uint32_t>(half ? (bal >> 32) : bal));
+			int32_t        mx = ok ? q : INT32_MIN, mn = ok ? q : INT32_MAX;
+#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
+	{                                                                                                                   \
+		const int32_t omx = __builtin_amdgcn_update_dpp(mx, mx, CTRL, ROWS, 0xf, false);                                \
+		const int32_t omn = __builtin_amdgcn_update_dpp(mn, mn, CTRL, ROWS, 0xf, false);                                \
+		mx                = omx > mx ? omx : mx;                                                                        \
+		mn                = omn < mn ? omn : mn;                                                                        \
+	}
+			ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
+			ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
+			ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
+			ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8
+			ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3: lanes 31 and 63 hold their half's result
+#undef ALPGPU_MINMAX_STEP
+			if (sidx == 31 && half < kTail && non_exc >= 2) { // encoder.hpp:182
+				const uint32_t size = static_cast<uint32_t>(samples_size) * static_cast<uint32_t>(P::bits(mx, mn)) +
+				                      static_cast<uint32_t>(samples_size - non_exc) * (P::kExcBits + 16u);
+				my_key              = (size << 8) | static_cast<uint32_t>(c);
+			}
+		}
 #pragma unroll 1
-		for (int r = 0; r < (P::kNumCombos + 63) / 64; ++r) {
+		for (int r = 0; r < kRounds; ++r) {
 			const int c = lane + 64 * r;
 			if (c < P::kNumCombos) {
 				const typename P::Coef k = P::coef(P::combos().e[c], P::combos().f[c]);
