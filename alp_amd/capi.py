@@ -73,6 +73,7 @@ OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEB
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
+_sig("alpgpu_debug_decode_probe_f64", _int, _vp, C.POINTER(CColumn), _vp)
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)
 _sig("alpgpu_use_own_stream", _int, _vp)
@@ -183,6 +184,10 @@ class Context:
 
     def synchronize(self):
         _check(lib.alpgpu_synchronize(self.h), "alpgpu_synchronize")
+
+    def decode_probe(self, col: "DeviceColumn", out):
+        """decode_sum without the unpack arithmetic (include/alpgpu.h: alpgpu_debug_decode_probe_f64)"""
+        _check(lib.alpgpu_debug_decode_probe_f64(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_debug_decode_probe_f64")
 
     def traffic_probe(self, x, out, n_vectors: int, write_bytes_per_vector: int):
         """the single-pass encode's loads and stores without its arithmetic (include/alpgpu.h: alpgpu_debug_traffic_probe)"""

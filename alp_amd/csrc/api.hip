@@ -326,6 +326,16 @@ int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int 
 	return (decode_variant_for(ctx, col) & 1) ? 1 : 2;
 }
 
+// measurement aid: what alpgpu_decode_sum_f64 costs with its unpack arithmetic left out (decode_kernels.hip: kSinkProbe)
+int alpgpu_debug_decode_probe_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	if (alpgpu::launch_decode_probe(ctx->stream, col, d_out) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode probe launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+
 // measurement aid: the single-pass encode's loads and stores without its arithmetic (encode_kernels.hip: k_traffic_probe)
 int alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector) {
 	ALPGPU_CHECK_CTX(ctx);

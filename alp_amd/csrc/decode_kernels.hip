@@ -115,6 +115,9 @@ __device__ __forceinline__ void store_pair(double2* __restrict__ p, double x, do
 // 8 KiB per vector of decoded doubles ever reaching HBM).
 // kSinkCount: `acc` counts the values v with lo <= v <= hi (a predicate pushed into the decode; NaN never qualifies).
 constexpr int kSinkStore = 0, kSinkSum = 1, kSinkCount = 2;
+// kSinkProbe (alpgpu_debug_decode_probe): the consumers' memory traffic and latency chain without the unpack — descriptors, packed
+// words into LDS, exceptions, the barrier — every thread then just adds up the staged 16-byte units it would have unpacked.
+constexpr int kSinkProbe = 3;
 template <int SINK>
 __device__ __forceinline__ void consume_pair(double ox, double oy, double* acc, double lo, double hi) {
 	if constexpr (SINK == kSinkSum) {
@@ -325,7 +328,15 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		for (int i = 0; i < V; ++i) {
 			double acc = 0.0;
 			if (v0 + i < n_vectors) {
-				decode_staged_vector<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
+				if constexpr (SINK == kSinkProbe) {
+					const int       n_units = 8 * (d[i].bw + (d[i].scheme == ALPGPU_SCHEME_ALP ? 0 : d[i].lbw));
+					const uint64_t* st      = reinterpret_cast<const uint64_t*>(L[i].stage);
+					uint64_t        sum     = 0;
+					for (int c = tid; c < n_units; c += 64 * kDecWaves) { sum += st[2 * c] + st[2 * c + 1]; }
+					acc = static_cast<double>(sum & 0xFFFFFu);
+				} else {
+					decode_staged_vector<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
+				}
 			}
 #pragma unroll
 			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
@@ -389,6 +400,18 @@ int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_su
 		} else {
 			hipLaunchKernelGGL((k_decode_column<1, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
 		}
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// measurement aid: the fused consumers' loads, barrier and reduction with the unpack left out (two vectors per workgroup, like them)
+int launch_decode_probe(hipStream_t stream, const alpgpu_column* col, double* d_sums) {
+	const uint64_t n        = col->n_vectors;
+	const uint64_t n_wg     = (n + 1) / 2;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
+		hipLaunchKernelGGL((k_decode_column<2, false, kSinkProbe>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

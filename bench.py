@@ -538,6 +538,10 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
                                   "roofline_frac_algorithmic": frac(read_bytes, med),
                                   "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector"}
+    # the same kernel with its unpack arithmetic left out (alpgpu_debug_decode_probe_f64): what the chain descriptor -> packed words ->
+    # barrier -> reduction costs on its own, i.e. the floor of this launch shape
+    pmed, _ = time_launches(lambda: ctx.decode_probe(col, sums), 7, 10)
+    extras["decode_sum_fused"]["loads_only_probe"] = {"ms": round(pmed, 3), "roofline_frac_algorithmic": frac(read_bytes, pmed), "sum_vs_probe": round(pmed / med, 4)}
     del sums
     # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
     enc_cpu = None

@@ -164,6 +164,10 @@ int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* c
  * d_out + v * write_bytes_per_vector, stored data depending on all loaded data.  bench.py times it to put a measured ceiling for the
  * encode's read/write mix next to the nominal HBM peak. */
 int         alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector);
+/* Measurement aid, not part of the codec: alpgpu_decode_sum_f64 with the unpack arithmetic left out — the same descriptor and packed-word
+ * loads into LDS, the same barrier and reduction, one double per vector written to d_out (its value means nothing).  bench.py times it
+ * to say how much of the fused consumers' time is their chain of dependent loads. */
+int         alpgpu_debug_decode_probe_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
 /* device properties the bench reports: [0]=CU count, [1]=LDS bytes/CU... see alp_amd/capi.py */
 int         alpgpu_device_info(alpgpu_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
 

@@ -44,3 +44,20 @@ def test_probe_rejects_what_it_cannot_do():
     ctx.traffic_probe(x, out, 0, 4336)  # an empty column is fine
     ctx.traffic_probe(x, out, 1, 0)     # and so is writing nothing
     ctx.synchronize()
+
+
+def test_decode_probe_runs_on_a_real_column_and_touches_only_its_output():
+    import datagen
+    dev = torch.device("cuda:0")
+    ctx = capi.Context(0)
+    x = torch.from_numpy(datagen.mixed_column(230, seed=11, exc_rate=0.02)).to(dev)
+    col = ctx.encode(x)
+    out = torch.full((230 + 8,), -7.0, dtype=torch.float64, device=dev)
+    ctx.decode_probe(col, out)
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert np.all(got[230:] == -7.0), "one double per vector, nothing behind them"
+    assert np.all((got[:230] >= 0) & (got[:230] == np.floor(got[:230]))), "the probe's output is a small non-negative integer per vector"
+    back = ctx.decode(col)
+    ctx.synchronize()
+    assert torch.equal(back.view(torch.int64), x.view(torch.int64)), "the column is untouched"
