@@ -344,8 +344,13 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		}
 		__syncthreads();
 		if (tid < V && v0 + tid < n_vectors) {
+#ifdef ALPGPU_EXPERIMENT_DEC_WAVES // timing experiments with another number of wavefronts per vector: the sums follow another order
+			double total = 0.0;
+			for (int w = 0; w < kDecWaves; ++w) { total += s_part[tid][w]; }
+#else
 			static_assert(kDecWaves == 4, "the documented summation order is for 4 wavefronts per vector");
 			const double total = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+#endif
 			if constexpr (SINK == kSinkCount) {
 				reinterpret_cast<uint32_t*>(out)[v0 + tid] = static_cast<uint32_t>(total);
 			} else {
