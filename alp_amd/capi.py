@@ -73,6 +73,9 @@ OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEB
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
+_sig("alpgpu_malloc_host", _int, _vp, C.POINTER(_vp), _sz)
+_sig("alpgpu_free_host", _int, _vp, _vp)
+_sig("alpgpu_memcpy_h2d_async", _int, _vp, _vp, _vp, _sz)
 _sig("alpgpu_debug_decode_probe_f64", _int, _vp, C.POINTER(CColumn), _vp)
 _sig("alpgpu_packed_capacity", _u64, _u64)
 _sig("alpgpu_exc_capacity", _u64, _u64)

@@ -201,6 +201,27 @@ int alpgpu_memcpy_d2h(alpgpu_ctx* ctx, void* h_dst, const void* d_src, size_t by
 	return ALPGPU_OK;
 }
 
+// page-locked host memory: copies to and from it are DMA transfers the runtime need not stage, and may be left asynchronous
+int alpgpu_malloc_host(alpgpu_ctx* ctx, void** h_ptr, size_t bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!h_ptr) { return fail(ALPGPU_ERR_INVALID, "h_ptr is null"); }
+	ALPGPU_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 8, hipHostMallocDefault));
+	return ALPGPU_OK;
+}
+
+int alpgpu_free_host(alpgpu_ctx* ctx, void* h_ptr) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipHostFree(h_ptr));
+	return ALPGPU_OK;
+}
+
+// enqueued on the context's stream, NOT waited for: h_src must stay untouched until a later synchronous call on this context returns
+int alpgpu_memcpy_h2d_async(alpgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	ALPGPU_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+	return ALPGPU_OK;
+}
+
 int alpgpu_memset(alpgpu_ctx* ctx, void* d_dst, int value, size_t bytes) {
 	ALPGPU_CHECK_CTX(ctx);
 	ALPGPU_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));

@@ -8,12 +8,15 @@
 //         for each vector:  encoder::encode(...); analyze_ffor(...); ffor(...)  test/test_alp_sample.cpp:137-166)
 //
 // replaces the inner loop by ONE call of alp::gpu::rowgroup<PT>::encode (and the decode loop falp + patch_exceptions by
-// ::decode): one upload, three kernels over all vectors of the rowgroup, one download.  The outputs are the per-vector
+// ::decode): one upload, three kernels over all vectors of the rowgroup, one download — literally one copy each way: the arrays of
+// a call lie next to each other in one device buffer and in a page-locked host mirror of it.  The outputs are the per-vector
 // outputs of the reference, at a fixed stride of 1024 elements per vector: the FFOR-packed words (16 * bit_width words
 // used), bit widths, bases, (factor, exponent), exceptions, positions, counts.  Bit-identical to calling the per-vector
 // functions in a loop (tests/cpp/batch_test.cpp checks that on the GPU).  ALP_RD rowgroups have ::encode_rd / ::decode_rd.
 #ifndef ALP_BATCH_HPP
 #define ALP_BATCH_HPP
+#include <cstring>
+
 #include "alp/config.hpp"
 #include "alp/decoder.hpp"
 #include "alp/encoder.hpp"
@@ -21,44 +24,43 @@
 
 namespace alp { namespace gpu {
 
-// per-thread device scratch for n vectors of every array the batched calls touch, grown on demand
+// Per-thread scratch of the batched calls: one device buffer and a page-locked host mirror of it.  Every call lays the arrays it
+// needs out next to each other (sized for ITS n vectors), so that whatever goes up is one contiguous copy and whatever comes
+// down is another; user arrays are copied into / out of the mirror with memcpy.
+//   [ idx: cap x u32 zeros (every vector uses state 0) ][ state: 64 B ][ the call's arrays ... ]
 struct batch_scratch {
-	uint8_t* base {nullptr};
-	size_t   cap {0};    // vectors
-	size_t   vb {0};     // bytes per vector of the value type the scratch was sized for
+	uint8_t* dev {nullptr};
+	uint8_t* host {nullptr};
+	size_t   cap {0};   // vectors the zero index array covers
+	size_t   bytes {0}; // size of both buffers
 	~batch_scratch() {
-		if (base) { alpgpu_free(context(), base); }
+		if (dev) { alpgpu_free(context(), dev); }
+		if (host) { alpgpu_free_host(context(), host); }
 	}
-	// per-vector slices: A, B, C, D = four value-sized arrays; then 2-byte arrays P, L, Q, X; then bytes / small words
-	size_t off_A() const { return 0; }
-	size_t off_B() const { return cap * vb; }
-	size_t off_C() const { return 2 * cap * vb; }
-	size_t off_D() const { return 3 * cap * vb; }
-	size_t off_P() const { return 4 * cap * vb; }
-	size_t off_L() const { return off_P() + cap * 2048; }
-	size_t off_Q() const { return off_L() + cap * 2048; }
-	size_t off_X() const { return off_Q() + cap * 2048; }
-	size_t off_base() const { return off_X() + cap * 2048; }          // cap x 8
-	size_t off_idx() const { return off_base() + cap * 8; }           // cap x 4 (zeros: every vector uses state 0)
-	size_t off_cnt() const { return off_idx() + cap * 4; }            // cap x 2
-	size_t off_bw() const { return off_cnt() + cap * 2; }             // cap
-	size_t off_fac() const { return off_bw() + cap; }                 // cap
-	size_t off_exp() const { return off_fac() + cap; }                // cap
-	size_t off_state() const { return (off_exp() + cap + 63) & ~size_t(63); }
-	size_t total() const { return off_state() + 64; }
-	void   ensure(size_t n, size_t value_bytes) {
-        if (n <= cap && value_bytes * 1024 == vb) { return; }
-        if (base) { check(alpgpu_free(context(), base), "alpgpu_free"); }
-        base = nullptr;
-        cap  = n < 100 ? 100 : n;
-        vb   = value_bytes * 1024;
-        check(alpgpu_malloc(context(), reinterpret_cast<void**>(&base), total()), "alpgpu_malloc");
-        check(alpgpu_memset(context(), base + off_idx(), 0, cap * 4), "alpgpu_memset");
+	size_t off_state() const { return (cap * 4 + 63) & ~size_t(63); }
+	size_t off_arrays() const { return off_state() + 64; }
+	// room for n vectors whose arrays take at most per_vector bytes each
+	void ensure(size_t n, size_t per_vector) {
+		const size_t want_cap = n < 100 ? 100 : n;
+		const size_t need     = ((want_cap * 4 + 63) & ~size_t(63)) + 64 + want_cap * per_vector + 64;
+		if (want_cap <= cap && need <= bytes) { return; }
+		if (dev) { check(alpgpu_free(context(), dev), "alpgpu_free"); }
+		if (host) { check(alpgpu_free_host(context(), host), "alpgpu_free_host"); }
+		dev = host = nullptr;
+		cap   = want_cap > cap ? want_cap : cap;
+		bytes = ((cap * 4 + 63) & ~size_t(63)) + 64 + cap * per_vector + 64;
+		if (bytes < need) { bytes = need; }
+		check(alpgpu_malloc(context(), reinterpret_cast<void**>(&dev), bytes), "alpgpu_malloc");
+		check(alpgpu_malloc_host(context(), reinterpret_cast<void**>(&host), bytes), "alpgpu_malloc_host");
+		check(alpgpu_memset(context(), dev, 0, off_state()), "alpgpu_memset");
 	}
 	template <class T>
-	T* at(size_t off) const {
-		return reinterpret_cast<T*>(base + off);
+	T* d(size_t off) const {
+		return reinterpret_cast<T*>(dev + off);
 	}
+	uint8_t* h(size_t off) const { return host + off; }
+	void     up(size_t off, size_t n) const { check(alpgpu_memcpy_h2d_async(context(), dev + off, host + off, n), "alpgpu_memcpy_h2d_async"); }
+	void     down(size_t off, size_t n) const { check(alpgpu_memcpy_d2h(context(), host + off, dev + off, n), "alpgpu_memcpy_d2h"); } // synchronous
 };
 inline batch_scratch& batch_tls() {
 	static thread_local batch_scratch s;
@@ -69,7 +71,42 @@ template <class PT>
 struct rowgroup {
 	using ST = typename inner_t<PT>::st;
 	using UT = typename inner_t<PT>::ut;
-	static constexpr size_t V = config::VECTOR_SIZE;
+	static constexpr size_t V  = config::VECTOR_SIZE;
+	static constexpr size_t VB = V * sizeof(PT); // bytes of one vector of values / encoded integers / right parts
+
+	// the arrays of the ALP calls, in the order they lie in the buffers (n = vectors of this call)
+	struct alp_layout {
+		size_t in, exc, packed, pos, base, cnt, bw, fac, exp, enc, end;
+		alp_layout(const batch_scratch& s, size_t n) {
+			in     = s.off_arrays();       // n x VB   values in (encode) / out (decode)
+			exc    = in + n * VB;          // n x VB   exception values            -+
+			packed = exc + n * VB;         // n x VB   FFOR words                    |
+			pos    = packed + n * VB;      // n x 2 KiB exception positions         |  one block: encode's output,
+			base   = pos + n * 2048;       // n x 8                                 |  decode's input
+			cnt    = base + n * 8;         // n x 2                                 |
+			bw     = cnt + n * 2;          // n                                     |
+			fac    = bw + n;               // n                                     |
+			exp    = fac + n;              // n                                    -+
+			enc    = (exp + n + 15) & ~size_t(15); // n x VB   encoded integers (device only)
+			end    = enc + n * VB;
+		}
+	};
+	static constexpr size_t kAlpPerVector = 4 * VB + 2048 + 8 + 2 + 3 + 1;
+	// ... and of the ALP_RD calls
+	struct rd_layout {
+		size_t in, right, left, exc, pos, cnt, end;
+		rd_layout(const batch_scratch& s, size_t n) {
+			in    = s.off_arrays();   // n x VB    values in (encode) / out (decode)
+			right = in + n * VB;      // n x VB    right parts          -+
+			left  = right + n * VB;   // n x 2 KiB dictionary indices    |  one block: encode's output, decode's input
+			exc   = left + n * 2048;  // n x 2 KiB exceptions            |
+			pos   = exc + n * 2048;   // n x 2 KiB positions             |
+			cnt   = pos + n * 2048;   // n x 2                          -+
+			end   = cnt + n * 2;
+		}
+	};
+	static constexpr size_t kRdPerVector = 2 * VB + 3 * 2048 + 2 + 1;
+	static constexpr size_t kPerVector   = kAlpPerVector > kRdPerVector ? kAlpPerVector : kRdPerVector;
 
 	//! ALP rowgroup: second-level sampling + encode, analyze_ffor, ffor for n_vectors vectors sharing `stt` (from encoder<PT>::init).
 	//! All outputs are host arrays at a stride of 1024 elements per vector (counts / bit_widths / bases / facs / exps: one per vector).
@@ -77,33 +114,41 @@ struct rowgroup {
 	                   PT* exceptions, exp_p_t* positions, exp_c_t* counts) {
 		if (n_vectors == 0) { return; }
 		auto& s = batch_tls();
-		s.ensure(n_vectors, sizeof(PT));
+		s.ensure(n_vectors, kPerVector);
 		alpgpu_ctx*                 c = context();
 		const alpgpu_rowgroup_state d = to_device_state(stt);
 		const uint64_t              n = n_vectors;
-		h2d(s.at<PT>(s.off_A()), vectors, n * V * sizeof(PT));
-		h2d(s.at<uint8_t>(s.off_state()), &d, sizeof(d));
-		auto* st  = s.at<alpgpu_rowgroup_state>(s.off_state());
-		auto* idx = s.at<uint32_t>(s.off_idx());
+		const alp_layout            L(s, n);
+		std::memcpy(s.h(s.off_state()), &d, sizeof(d));
+		std::memcpy(s.h(L.in), vectors, n * VB);
+		s.up(s.off_state(), L.in + n * VB - s.off_state()); // state + values: one copy
+		auto* st  = s.d<alpgpu_rowgroup_state>(s.off_state());
+		auto* idx = s.d<uint32_t>(0);
 		if constexpr (sizeof(PT) == 8) {
-			check(alpgpu_encode_values_f64(c, s.at<double>(s.off_A()), st, idx, s.at<double>(s.off_C()), s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()),
-			                               s.at<int64_t>(s.off_B()), s.at<uint8_t>(s.off_fac()), s.at<uint8_t>(s.off_exp()), n), "alpgpu_encode_values_f64");
-			check(alpgpu_analyze_ffor_i64(c, s.at<int64_t>(s.off_B()), s.at<uint8_t>(s.off_bw()), s.at<int64_t>(s.off_base()), n), "alpgpu_analyze_ffor_i64");
-			check(alpgpu_ffor_i64(c, s.at<int64_t>(s.off_B()), s.at<int64_t>(s.off_D()), V, s.at<uint8_t>(s.off_bw()), s.at<int64_t>(s.off_base()), n), "alpgpu_ffor_i64");
+			check(alpgpu_encode_values_f64(c, s.d<double>(L.in), st, idx, s.d<double>(L.exc), s.d<uint16_t>(L.pos), V, s.d<uint16_t>(L.cnt), s.d<int64_t>(L.enc),
+			                               s.d<uint8_t>(L.fac), s.d<uint8_t>(L.exp), n), "alpgpu_encode_values_f64");
+			check(alpgpu_analyze_ffor_i64(c, s.d<int64_t>(L.enc), s.d<uint8_t>(L.bw), s.d<int64_t>(L.base), n), "alpgpu_analyze_ffor_i64");
+			check(alpgpu_ffor_i64(c, s.d<int64_t>(L.enc), s.d<int64_t>(L.packed), V, s.d<uint8_t>(L.bw), s.d<int64_t>(L.base), n), "alpgpu_ffor_i64");
 		} else {
-			check(alpgpu_encode_values_f32(c, s.at<float>(s.off_A()), st, idx, s.at<float>(s.off_C()), s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()),
-			                               s.at<int32_t>(s.off_B()), s.at<uint8_t>(s.off_fac()), s.at<uint8_t>(s.off_exp()), n), "alpgpu_encode_values_f32");
-			check(alpgpu_analyze_ffor_i32(c, s.at<int32_t>(s.off_B()), s.at<uint8_t>(s.off_bw()), s.at<int32_t>(s.off_base()), n), "alpgpu_analyze_ffor_i32");
-			check(alpgpu_ffor_i32(c, s.at<int32_t>(s.off_B()), s.at<int32_t>(s.off_D()), V, s.at<uint8_t>(s.off_bw()), s.at<int32_t>(s.off_base()), n), "alpgpu_ffor_i32");
+			check(alpgpu_encode_values_f32(c, s.d<float>(L.in), st, idx, s.d<float>(L.exc), s.d<uint16_t>(L.pos), V, s.d<uint16_t>(L.cnt), s.d<int32_t>(L.enc),
+			                               s.d<uint8_t>(L.fac), s.d<uint8_t>(L.exp), n), "alpgpu_encode_values_f32");
+			check(alpgpu_analyze_ffor_i32(c, s.d<int32_t>(L.enc), s.d<uint8_t>(L.bw), s.d<int32_t>(L.base), n), "alpgpu_analyze_ffor_i32");
+			check(alpgpu_ffor_i32(c, s.d<int32_t>(L.enc), s.d<int32_t>(L.packed), V, s.d<uint8_t>(L.bw), s.d<int32_t>(L.base), n), "alpgpu_ffor_i32");
 		}
-		d2h(ffor_packed, s.at<ST>(s.off_D()), n * V * sizeof(ST));
-		d2h(exceptions, s.at<PT>(s.off_C()), n * V * sizeof(PT));
-		d2h(positions, s.at<uint16_t>(s.off_P()), n * V * 2);
-		d2h(counts, s.at<uint16_t>(s.off_cnt()), n * 2);
-		d2h(bit_widths, s.at<uint8_t>(s.off_bw()), n);
-		d2h(bases, s.at<ST>(s.off_base()), n * sizeof(ST));
-		d2h(facs, s.at<uint8_t>(s.off_fac()), n);
-		d2h(exps, s.at<uint8_t>(s.off_exp()), n);
+		s.down(L.exc, L.exp + n - L.exc); // everything the caller gets back: one copy
+		std::memcpy(exceptions, s.h(L.exc), n * VB);
+		std::memcpy(ffor_packed, s.h(L.packed), n * VB);
+		std::memcpy(positions, s.h(L.pos), n * 2048);
+		// bases travel as 8 bytes per vector; the float API's are int32
+		if constexpr (sizeof(ST) == 8) {
+			std::memcpy(bases, s.h(L.base), n * 8);
+		} else {
+			std::memcpy(bases, s.h(L.base), n * 4);
+		}
+		std::memcpy(counts, s.h(L.cnt), n * 2);
+		std::memcpy(bit_widths, s.h(L.bw), n);
+		std::memcpy(facs, s.h(L.fac), n);
+		std::memcpy(exps, s.h(L.exp), n);
 	}
 
 	//! falp + patch_exceptions for n_vectors vectors (inputs as produced by encode())
@@ -111,27 +156,30 @@ struct rowgroup {
 	                   const exp_p_t* positions, const exp_c_t* counts, size_t n_vectors, PT* out) {
 		if (n_vectors == 0) { return; }
 		auto& s = batch_tls();
-		s.ensure(n_vectors, sizeof(PT));
-		alpgpu_ctx*    c = context();
-		const uint64_t n = n_vectors;
-		h2d(s.at<ST>(s.off_D()), ffor_packed, n * V * sizeof(ST));
-		h2d(s.at<PT>(s.off_C()), exceptions, n * V * sizeof(PT));
-		h2d(s.at<uint16_t>(s.off_P()), positions, n * V * 2);
-		h2d(s.at<uint16_t>(s.off_cnt()), counts, n * 2);
-		h2d(s.at<uint8_t>(s.off_bw()), bit_widths, n);
-		h2d(s.at<ST>(s.off_base()), bases, n * sizeof(ST));
-		h2d(s.at<uint8_t>(s.off_fac()), facs, n);
-		h2d(s.at<uint8_t>(s.off_exp()), exps, n);
+		s.ensure(n_vectors, kPerVector);
+		alpgpu_ctx*      c = context();
+		const uint64_t   n = n_vectors;
+		const alp_layout L(s, n);
+		std::memcpy(s.h(L.exc), exceptions, n * VB);
+		std::memcpy(s.h(L.packed), ffor_packed, n * VB);
+		std::memcpy(s.h(L.pos), positions, n * 2048);
+		std::memcpy(s.h(L.base), bases, n * sizeof(ST));
+		std::memcpy(s.h(L.cnt), counts, n * 2);
+		std::memcpy(s.h(L.bw), bit_widths, n);
+		std::memcpy(s.h(L.fac), facs, n);
+		std::memcpy(s.h(L.exp), exps, n);
+		s.up(L.exc, L.exp + n - L.exc); // one copy
 		if constexpr (sizeof(PT) == 8) {
-			check(alpgpu_falp_f64(c, s.at<int64_t>(s.off_D()), V, s.at<double>(s.off_A()), s.at<uint8_t>(s.off_bw()), s.at<int64_t>(s.off_base()), s.at<uint8_t>(s.off_fac()),
-			                      s.at<uint8_t>(s.off_exp()), n), "alpgpu_falp_f64");
-			check(alpgpu_patch_f64(c, s.at<double>(s.off_A()), s.at<double>(s.off_C()), s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()), n), "alpgpu_patch_f64");
+			check(alpgpu_falp_f64(c, s.d<int64_t>(L.packed), V, s.d<double>(L.in), s.d<uint8_t>(L.bw), s.d<int64_t>(L.base), s.d<uint8_t>(L.fac), s.d<uint8_t>(L.exp), n),
+			      "alpgpu_falp_f64");
+			check(alpgpu_patch_f64(c, s.d<double>(L.in), s.d<double>(L.exc), s.d<uint16_t>(L.pos), V, s.d<uint16_t>(L.cnt), n), "alpgpu_patch_f64");
 		} else {
-			check(alpgpu_falp_f32(c, s.at<int32_t>(s.off_D()), V, s.at<float>(s.off_A()), s.at<uint8_t>(s.off_bw()), s.at<int32_t>(s.off_base()), s.at<uint8_t>(s.off_fac()),
-			                      s.at<uint8_t>(s.off_exp()), n), "alpgpu_falp_f32");
-			check(alpgpu_patch_f32(c, s.at<float>(s.off_A()), s.at<float>(s.off_C()), s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()), n), "alpgpu_patch_f32");
+			check(alpgpu_falp_f32(c, s.d<int32_t>(L.packed), V, s.d<float>(L.in), s.d<uint8_t>(L.bw), s.d<int32_t>(L.base), s.d<uint8_t>(L.fac), s.d<uint8_t>(L.exp), n),
+			      "alpgpu_falp_f32");
+			check(alpgpu_patch_f32(c, s.d<float>(L.in), s.d<float>(L.exc), s.d<uint16_t>(L.pos), V, s.d<uint16_t>(L.cnt), n), "alpgpu_patch_f32");
 		}
-		d2h(out, s.at<PT>(s.off_A()), n * V * sizeof(PT));
+		s.down(L.in, n * VB);
+		std::memcpy(out, s.h(L.in), n * VB);
 	}
 
 	//! ALP_RD rowgroup (rd_encoder<PT>::encode per vector, include/alp/rd.hpp:109-147 upstream): right parts, left dictionary
@@ -140,26 +188,29 @@ struct rowgroup {
 	                      exp_c_t* counts) {
 		if (n_vectors == 0) { return; }
 		auto& s = batch_tls();
-		s.ensure(n_vectors, sizeof(PT));
+		s.ensure(n_vectors, kPerVector);
 		alpgpu_ctx*                 c = context();
 		const alpgpu_rowgroup_state d = to_device_state(stt);
 		const uint64_t              n = n_vectors;
-		h2d(s.at<PT>(s.off_A()), vectors, n * V * sizeof(PT));
-		h2d(s.at<uint8_t>(s.off_state()), &d, sizeof(d));
-		auto* st  = s.at<alpgpu_rowgroup_state>(s.off_state());
-		auto* idx = s.at<uint32_t>(s.off_idx());
+		const rd_layout             L(s, n);
+		std::memcpy(s.h(s.off_state()), &d, sizeof(d));
+		std::memcpy(s.h(L.in), vectors, n * VB);
+		s.up(s.off_state(), L.in + n * VB - s.off_state());
+		auto* st  = s.d<alpgpu_rowgroup_state>(s.off_state());
+		auto* idx = s.d<uint32_t>(0);
 		if constexpr (sizeof(PT) == 8) {
-			check(alpgpu_rd_encode_vectors_f64(c, s.at<double>(s.off_A()), st, idx, s.at<uint16_t>(s.off_Q()), s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()),
-			                                   s.at<uint64_t>(s.off_B()), s.at<uint16_t>(s.off_L()), n), "alpgpu_rd_encode_vectors_f64");
+			check(alpgpu_rd_encode_vectors_f64(c, s.d<double>(L.in), st, idx, s.d<uint16_t>(L.exc), s.d<uint16_t>(L.pos), V, s.d<uint16_t>(L.cnt), s.d<uint64_t>(L.right),
+			                                   s.d<uint16_t>(L.left), n), "alpgpu_rd_encode_vectors_f64");
 		} else {
-			check(alpgpu_rd_encode_vectors_f32(c, s.at<float>(s.off_A()), st, idx, s.at<uint16_t>(s.off_Q()), s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()),
-			                                   s.at<uint32_t>(s.off_B()), s.at<uint16_t>(s.off_L()), n), "alpgpu_rd_encode_vectors_f32");
+			check(alpgpu_rd_encode_vectors_f32(c, s.d<float>(L.in), st, idx, s.d<uint16_t>(L.exc), s.d<uint16_t>(L.pos), V, s.d<uint16_t>(L.cnt), s.d<uint32_t>(L.right),
+			                                   s.d<uint16_t>(L.left), n), "alpgpu_rd_encode_vectors_f32");
 		}
-		d2h(right_parts, s.at<UT>(s.off_B()), n * V * sizeof(UT));
-		d2h(left_parts, s.at<uint16_t>(s.off_L()), n * V * 2);
-		d2h(exceptions, s.at<uint16_t>(s.off_Q()), n * V * 2);
-		d2h(positions, s.at<uint16_t>(s.off_P()), n * V * 2);
-		d2h(counts, s.at<uint16_t>(s.off_cnt()), n * 2);
+		s.down(L.right, L.cnt + n * 2 - L.right);
+		std::memcpy(right_parts, s.h(L.right), n * VB);
+		std::memcpy(left_parts, s.h(L.left), n * 2048);
+		std::memcpy(exceptions, s.h(L.exc), n * 2048);
+		std::memcpy(positions, s.h(L.pos), n * 2048);
+		std::memcpy(counts, s.h(L.cnt), n * 2);
 	}
 
 	//! rd_encoder<PT>::decode per vector (rd.hpp:152-178 upstream) for n_vectors vectors
@@ -167,26 +218,30 @@ struct rowgroup {
 	                      const state<PT>& stt, size_t n_vectors, PT* out) {
 		if (n_vectors == 0) { return; }
 		auto& s = batch_tls();
-		s.ensure(n_vectors, sizeof(PT));
+		s.ensure(n_vectors, kPerVector);
 		alpgpu_ctx*                 c = context();
 		const alpgpu_rowgroup_state d = to_device_state(stt);
 		const uint64_t              n = n_vectors;
-		h2d(s.at<UT>(s.off_B()), right_parts, n * V * sizeof(UT));
-		h2d(s.at<uint16_t>(s.off_L()), left_parts, n * V * 2);
-		h2d(s.at<uint16_t>(s.off_Q()), exceptions, n * V * 2);
-		h2d(s.at<uint16_t>(s.off_P()), positions, n * V * 2);
-		h2d(s.at<uint16_t>(s.off_cnt()), counts, n * 2);
-		h2d(s.at<uint8_t>(s.off_state()), &d, sizeof(d));
-		auto* st  = s.at<alpgpu_rowgroup_state>(s.off_state());
-		auto* idx = s.at<uint32_t>(s.off_idx());
+		const rd_layout             L(s, n);
+		std::memcpy(s.h(s.off_state()), &d, sizeof(d));
+		std::memcpy(s.h(L.right), right_parts, n * VB);
+		std::memcpy(s.h(L.left), left_parts, n * 2048);
+		std::memcpy(s.h(L.exc), exceptions, n * 2048);
+		std::memcpy(s.h(L.pos), positions, n * 2048);
+		std::memcpy(s.h(L.cnt), counts, n * 2);
+		s.up(s.off_state(), 64);
+		s.up(L.right, L.cnt + n * 2 - L.right);
+		auto* st  = s.d<alpgpu_rowgroup_state>(s.off_state());
+		auto* idx = s.d<uint32_t>(0);
 		if constexpr (sizeof(PT) == 8) {
-			check(alpgpu_rd_decode_vectors_f64(c, s.at<double>(s.off_A()), s.at<uint64_t>(s.off_B()), s.at<uint16_t>(s.off_L()), st, idx, s.at<uint16_t>(s.off_Q()),
-			                                   s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()), n), "alpgpu_rd_decode_vectors_f64");
+			check(alpgpu_rd_decode_vectors_f64(c, s.d<double>(L.in), s.d<uint64_t>(L.right), s.d<uint16_t>(L.left), st, idx, s.d<uint16_t>(L.exc), s.d<uint16_t>(L.pos), V,
+			                                   s.d<uint16_t>(L.cnt), n), "alpgpu_rd_decode_vectors_f64");
 		} else {
-			check(alpgpu_rd_decode_vectors_f32(c, s.at<float>(s.off_A()), s.at<uint32_t>(s.off_B()), s.at<uint16_t>(s.off_L()), st, idx, s.at<uint16_t>(s.off_Q()),
-			                                   s.at<uint16_t>(s.off_P()), V, s.at<uint16_t>(s.off_cnt()), n), "alpgpu_rd_decode_vectors_f32");
+			check(alpgpu_rd_decode_vectors_f32(c, s.d<float>(L.in), s.d<uint32_t>(L.right), s.d<uint16_t>(L.left), st, idx, s.d<uint16_t>(L.exc), s.d<uint16_t>(L.pos), V,
+			                                   s.d<uint16_t>(L.cnt), n), "alpgpu_rd_decode_vectors_f32");
 		}
-		d2h(out, s.at<PT>(s.off_A()), n * V * sizeof(PT));
+		s.down(L.in, n * VB);
+		std::memcpy(out, s.h(L.in), n * VB);
 	}
 };
 

@@ -177,6 +177,12 @@ int alpgpu_free(alpgpu_ctx* ctx, void* d_ptr);
 int alpgpu_memcpy_h2d(alpgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int alpgpu_memcpy_d2h(alpgpu_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int alpgpu_memset(alpgpu_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* page-locked host memory (copies to and from it are plain DMA) and a host-to-device copy that is enqueued but not waited for:
+ * h_src must stay untouched until a later synchronous call on this context (alpgpu_memcpy_d2h, alpgpu_synchronize) has returned.
+ * include/alp/batch.hpp moves a whole rowgroup's arrays with one copy each way through such a buffer. */
+int alpgpu_malloc_host(alpgpu_ctx* ctx, void** h_ptr, size_t bytes);
+int alpgpu_free_host(alpgpu_ctx* ctx, void* h_ptr);
+int alpgpu_memcpy_h2d_async(alpgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 
 /* worst-case stream capacities for n_vectors (bytes) */
 uint64_t alpgpu_packed_capacity(uint64_t n_vectors);
