@@ -74,6 +74,9 @@ _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTE
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
 _sig("alpgpu_malloc_host", _int, _vp, C.POINTER(_vp), _sz)
+for _t in ("f64", "f32"):
+    _sig("alpgpu_compress_host_" + _t, _int, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64))
+    _sig("alpgpu_decompress_host_" + _t, _int, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64))
 _sig("alpgpu_free_host", _int, _vp, _vp)
 _sig("alpgpu_memcpy_h2d_async", _int, _vp, _vp, _vp, _sz)
 _sig("alpgpu_debug_decode_probe_f64", _int, _vp, C.POINTER(CColumn), _vp)
@@ -187,6 +190,27 @@ class Context:
 
     def synchronize(self):
         _check(lib.alpgpu_synchronize(self.h), "alpgpu_synchronize")
+
+    def compress_host(self, x_host, blob_host=None):
+        """host tensor (CPU, float64 / float32, any length; page-locked for speed) -> uint8 CPU tensor holding the serialized column
+        (include/alpgpu.h: alpgpu_compress_host_*).  blob_host: a CPU uint8 tensor to write into (e.g. page-locked), else one is made."""
+        t = self._sfx(x_host)
+        n = (x_host.numel() + VECTOR_SIZE - 1) // VECTOR_SIZE
+        if blob_host is None:
+            cap = int(lib.alpgpu_blob_size(n, lib.alpgpu_packed_capacity(n), lib.alpgpu_exc_capacity(n)))
+            blob_host = torch.empty(cap, dtype=torch.uint8)
+        w = _u64()
+        _check(getattr(lib, "alpgpu_compress_host_" + t)(self.h, _vp(x_host.data_ptr()), x_host.numel(), _vp(blob_host.data_ptr()), blob_host.numel(), C.byref(w)),
+               "alpgpu_compress_host_" + t)
+        return blob_host[: w.value]
+
+    def decompress_host(self, blob_host, out_host):
+        """serialized column (CPU uint8 tensor) -> out_host (CPU tensor of the column's type, at least as long as the column); returns the value count"""
+        t = self._sfx(out_host)
+        nv = _u64()
+        _check(getattr(lib, "alpgpu_decompress_host_" + t)(self.h, _vp(blob_host.data_ptr()), blob_host.numel(), _vp(out_host.data_ptr()), out_host.numel(), C.byref(nv)),
+               "alpgpu_decompress_host_" + t)
+        return int(nv.value)
 
     def decode_probe(self, col: "DeviceColumn", out):
         """decode_sum without the unpack arithmetic (include/alpgpu.h: alpgpu_debug_decode_probe_f64)"""

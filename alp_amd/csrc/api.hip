@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/alpgpu.h"
 #include "launch.hpp"
@@ -551,29 +552,30 @@ int alpgpu_column_to_blob_f32(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_
 	return column_to_blob(ctx, col, n_values, h_blob, capacity, written, 4);
 }
 
-static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values, uint64_t value_bytes) {
-	ALPGPU_CHECK_CTX(ctx);
-	if (!h_blob || !col) { return fail(ALPGPU_ERR_INVALID, "null blob or column"); }
+// header of a serialized column: identity, value type, consistent counts, not truncated
+static int validate_blob_header(const void* h_blob, uint64_t size, uint64_t value_bytes, alpgpu_blob_header& h) {
 	if (size < sizeof(alpgpu_blob_header)) { return fail(ALPGPU_ERR_INVALID, "blob shorter than its header"); }
-	alpgpu_blob_header h;
 	std::memcpy(&h, h_blob, sizeof(h));
 	if (std::memcmp(h.magic, "ALPGPU1", 8) != 0 || h.version != 1 || h.header_bytes != sizeof(h)) { return fail(ALPGPU_ERR_INVALID, "not an ALPGPU v1 blob"); }
 	if ((h.reserved == 0 ? 8ull : h.reserved) != value_bytes) { return fail(ALPGPU_ERR_INVALID, "blob holds a column of the other value type"); }
-	const unsigned vbits = static_cast<unsigned>(8 * value_bytes); // 64 or 32
-	const unsigned max_e = value_bytes == 8 ? 18u : 10u;
 	if (h.n_rowgroups != (h.n_vectors + 99) / 100 || h.n_values > h.n_vectors * 1024ull || (h.n_vectors && h.n_values + 1024ull <= h.n_vectors * 1024ull)) {
 		return fail(ALPGPU_ERR_INVALID, "inconsistent blob header");
 	}
 	if (h.packed_bytes > (1ull << 56) || h.exc_bytes > (1ull << 56) || size < alpgpu_blob_size(h.n_vectors, h.packed_bytes, h.exc_bytes)) {
 		return fail(ALPGPU_ERR_INVALID, "blob truncated");
 	}
-	if (col->n_vectors != h.n_vectors || col->n_rowgroups != h.n_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column was allocated for a different vector count"); }
-	if (col->packed_capacity < h.packed_bytes || col->exc_capacity < h.exc_bytes) { return fail(ALPGPU_ERR_CAPACITY, "column streams too small for the blob"); }
+	return ALPGPU_OK;
+}
+
+// vectors [v_begin, v_end) of a blob whose header passed: every extent a kernel will dereference is checked here, so a corrupt
+// blob cannot make the decoder read out of bounds
+static int validate_blob_vectors(const void* h_blob, const alpgpu_blob_header& h, uint64_t value_bytes, uint64_t v_begin, uint64_t v_end) {
+	const unsigned vbits = static_cast<unsigned>(8 * value_bytes); // 64 or 32
+	const unsigned max_e = value_bytes == 8 ? 18u : 10u;
 	const uint8_t* p   = static_cast<const uint8_t*>(h_blob) + sizeof(h);
 	const auto*    rgs = reinterpret_cast<const alpgpu_rowgroup_state*>(p);
 	const auto*    vds = reinterpret_cast<const alpgpu_vector_desc*>(p + 32ull * h.n_rowgroups);
-	// every extent a kernel will dereference is checked here, so a corrupt blob cannot make the decoder read out of bounds
-	for (uint64_t v = 0; v < h.n_vectors; ++v) {
+	for (uint64_t v = v_begin; v < v_end; ++v) {
 		alpgpu_vector_desc d;
 		std::memcpy(&d, vds + v, sizeof(d));
 		alpgpu_rowgroup_state rg;
@@ -593,13 +595,33 @@ static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 		if (d.exc_cnt) { // positions must be < 1024
 			const uint8_t*  rec = p + 32ull * h.n_rowgroups + 32ull * h.n_vectors + align8(h.packed_bytes) + d.exc_off;
 			const uint16_t* pos = reinterpret_cast<const uint16_t*>(rec + (alp ? value_bytes : 2ull) * d.exc_cnt);
+			uint32_t        any = 0; // positions are 16-bit: OR them and look at the bits above 1023 once
 			for (uint32_t j = 0; j < d.exc_cnt; ++j) {
 				uint16_t q;
 				std::memcpy(&q, pos + j, 2);
-				if (q >= 1024) { return fail(ALPGPU_ERR_INVALID, "blob: exception position out of range"); }
+				any |= q;
 			}
+			if (any >= 1024) { return fail(ALPGPU_ERR_INVALID, "blob: exception position out of range"); }
 		}
 	}
+	return ALPGPU_OK;
+}
+
+static int validate_blob(const void* h_blob, uint64_t size, uint64_t value_bytes, alpgpu_blob_header& h) {
+	if (int rc = validate_blob_header(h_blob, size, value_bytes, h)) { return rc; }
+	return validate_blob_vectors(h_blob, h, value_bytes, 0, h.n_vectors);
+}
+
+static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values, uint64_t value_bytes) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!h_blob || !col) { return fail(ALPGPU_ERR_INVALID, "null blob or column"); }
+	alpgpu_blob_header h;
+	if (int rc = validate_blob(h_blob, size, value_bytes, h)) { return rc; }
+	if (col->n_vectors != h.n_vectors || col->n_rowgroups != h.n_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column was allocated for a different vector count"); }
+	if (col->packed_capacity < h.packed_bytes || col->exc_capacity < h.exc_bytes) { return fail(ALPGPU_ERR_CAPACITY, "column streams too small for the blob"); }
+	const uint8_t* p   = static_cast<const uint8_t*>(h_blob) + sizeof(h);
+	const auto*    rgs = reinterpret_cast<const alpgpu_rowgroup_state*>(p);
+	const auto*    vds = reinterpret_cast<const alpgpu_vector_desc*>(p + 32ull * h.n_rowgroups);
 	if (h.n_vectors) {
 		ALPGPU_HIP(hipMemcpyAsync(col->d_rowgroups, rgs, 32ull * h.n_rowgroups, hipMemcpyHostToDevice, ctx->stream));
 		ALPGPU_HIP(hipMemcpyAsync(col->d_vectors, vds, 32ull * h.n_vectors, hipMemcpyHostToDevice, ctx->stream));
@@ -788,6 +810,250 @@ int alpgpu_rd_decode_vectors_f32(alpgpu_ctx* ctx, float* d_out, const uint32_t* 
 	ALPGPU_PRIM(d_out && d_right && d_left && d_states && d_exc && d_pos && d_cnt,
 	            alpgpu::launch_rd_decode_f32(ctx->stream, ctx->n_cus, d_out, d_right, d_left, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt,
 	                                         n_vectors));
+}
+
+// ==== host-resident columns ============================================================================================
+// alpgpu_compress_host_* / alpgpu_decompress_host_*: the column AND its serialized form live in host memory (the reference's callers,
+// publication/source_code/bench_compression_ratio/alp.cpp:198-229, hold both there).  Two streams, two chunk slots of whole rowgroups:
+// while chunk i is copied up on one stream, chunk i-1 is encoded on the other.  A chunk is encoded into its slot's column by the
+// ordinary (self-healing) encode, then appended to the column's streams in HBM at the running offsets; its descriptors go straight to
+// their place in the blob and are shifted by those offsets on the host at the end (a column cut at rowgroup boundaries is the sum of
+// its parts: tests/test_sharding*.py).  The streams come down in one copy each when the last chunk is done.  Decompression mirrors it:
+// the streams go up chunk by chunk, each chunk is decoded from a view of the column (descriptors hold absolute offsets), the doubles
+// come down on the chunk's stream while the next chunk is on its way up.
+extern "C++" {
+namespace {
+
+constexpr uint64_t kHostChunkVectors = 12800; // 128 rowgroups: 100 MiB of doubles per copy
+
+struct HostPipe { // everything a call allocates, released on every return path
+	hipStream_t stream[2] = {nullptr, nullptr};
+	void*       d_in[2]   = {nullptr, nullptr};
+	void*       dev[16]   = {nullptr};
+	int         n_dev     = 0;
+	hipStream_t saved     = nullptr;
+	alpgpu_ctx* ctx       = nullptr;
+	~HostPipe() {
+		if (ctx) { ctx->stream = saved; }
+		for (int k = 0; k < 2; ++k) {
+			if (stream[k]) { (void)hipStreamSynchronize(stream[k]); }
+		}
+		for (int i = 0; i < n_dev; ++i) { (void)hipFree(dev[i]); }
+		for (int k = 0; k < 2; ++k) {
+			if (d_in[k]) { (void)hipFree(d_in[k]); }
+			if (stream[k]) { (void)hipStreamDestroy(stream[k]); }
+		}
+	}
+	int alloc(void** p, uint64_t bytes) {
+		if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess) { return fail(ALPGPU_ERR_HIP, "hipMalloc (host pipeline)", hipGetLastError()); }
+		dev[n_dev++] = *p;
+		return ALPGPU_OK;
+	}
+};
+
+template <int VALUE_BYTES>
+int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	ALPGPU_CHECK_CTX(ctx);
+	if ((!h_in && n_values) || !h_blob) { return fail(ALPGPU_ERR_INVALID, "null input or blob"); }
+	const uint64_t n   = (n_values + 1023) / 1024;
+	const uint64_t nrg = (n + 99) / 100;
+	const uint64_t VB  = 1024ull * VALUE_BYTES;
+	// the blob must at least hold its fixed part before anything is produced
+	if (capacity < alpgpu_blob_size(n, 0, 0)) {
+		if (written) { // nothing has been encoded yet: the size that always suffices
+			*written = VALUE_BYTES == 8 ? alpgpu_blob_size(n, alpgpu_packed_capacity(n), alpgpu_exc_capacity(n)) : alpgpu_blob_size(n, alpgpu_packed_capacity_f32(n), alpgpu_exc_capacity_f32(n));
+		}
+		return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small for the column's descriptors");
+	}
+	uint8_t* blob     = static_cast<uint8_t*>(h_blob);
+	uint8_t* blob_rg  = blob + sizeof(alpgpu_blob_header);
+	uint8_t* blob_vec = blob_rg + 32ull * nrg;
+	uint8_t* blob_str = blob_vec + 32ull * n;
+	HostPipe P;
+	P.ctx   = ctx;
+	P.saved = ctx->stream;
+	uint64_t total_p = 0, total_e = 0;
+	std::vector<uint64_t> chunk_p, chunk_e; // bytes in front of every chunk
+	void *   d_packed_all = nullptr, *d_exc_all = nullptr;
+	uint64_t cap_p_all = 0, cap_e_all = 0;
+	if (n) {
+		const uint64_t chunk   = n < kHostChunkVectors ? n : kHostChunkVectors;
+		const uint64_t c_nrg   = (chunk + 99) / 100;
+		const uint64_t c_cap_p = VALUE_BYTES == 8 ? alpgpu_packed_capacity(chunk) : alpgpu_packed_capacity_f32(chunk);
+		const uint64_t c_cap_e = VALUE_BYTES == 8 ? alpgpu_exc_capacity(chunk) : alpgpu_exc_capacity_f32(chunk);
+		alpgpu_column col[2];
+		for (int k = 0; k < 2; ++k) {
+			ALPGPU_HIP(hipStreamCreateWithFlags(&P.stream[k], hipStreamNonBlocking));
+			if (hipMalloc(&P.d_in[k], chunk * VB) != hipSuccess) { return fail(ALPGPU_ERR_HIP, "hipMalloc (chunk buffer)", hipGetLastError()); }
+			std::memset(&col[k], 0, sizeof(col[k]));
+			col[k].packed_capacity = c_cap_p, col[k].exc_capacity = c_cap_e;
+			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_rowgroups), 32ull * c_nrg)) { return rc; }
+			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_vectors), 32ull * chunk)) { return rc; }
+			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_packed), c_cap_p)) { return rc; }
+			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_exc), c_cap_e)) { return rc; }
+			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_totals), 64)) { return rc; }
+			// the reference's sorted order per rowgroup: ALP_RD streams byte-identical to the reference's even at exception slots
+			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_rd_order), 2ull * ALPGPU_RD_ORDER_STRIDE * c_nrg)) { return rc; }
+		}
+		// the column's streams in HBM: the packed stream's worst case is 1.04 x the input and is taken whole; the exception
+		// stream's (1.25 x) is taken when it is a small part of the free memory, else a quarter of the input (an error, not an
+		// overrun, if a column ever needs more)
+		size_t free_b = 0, total_b = 0;
+		ALPGPU_HIP(hipMemGetInfo(&free_b, &total_b));
+		cap_p_all = n * (VALUE_BYTES == 8 ? 8448ull : 4352ull) + 1024;
+		cap_e_all = n * (VALUE_BYTES == 8 ? 10240ull : 6144ull) + 64;
+		if (cap_e_all > free_b / 4) { cap_e_all = n * VB / 4 + 4096; }
+		if (int rc = P.alloc(&d_packed_all, cap_p_all)) { return rc; }
+		if (int rc = P.alloc(&d_exc_all, cap_e_all)) { return rc; }
+		const uint64_t n_chunks = (n + chunk - 1) / chunk;
+		for (uint64_t i = 0; i < n_chunks; ++i) {
+			const int      k   = static_cast<int>(i & 1);
+			const uint64_t v0  = i * chunk;
+			const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
+			const uint64_t val = (v0 + cnt) * 1024 <= n_values ? cnt * 1024 : n_values - v0 * 1024; // values of this chunk present in h_in
+			ctx->stream        = P.stream[k];
+			ALPGPU_HIP(hipMemcpyAsync(P.d_in[k], static_cast<const uint8_t*>(h_in) + v0 * VB, val * VALUE_BYTES, hipMemcpyHostToDevice, P.stream[k]));
+			if (val != cnt * 1024) { // the column's last vector is incomplete: padded with its first value (alpgpu_pad_tail_*)
+				const int rc = VALUE_BYTES == 8 ? alpgpu::launch_pad_tail(P.stream[k], static_cast<double*>(P.d_in[k]), val)
+				                                : alpgpu::launch_pad_tail_f32(P.stream[k], static_cast<float*>(P.d_in[k]), val);
+				if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "pad launch failed", hipGetLastError()); }
+			}
+			col[k].n_vectors = cnt, col[k].n_rowgroups = (cnt + 99) / 100;
+			const int rc = VALUE_BYTES == 8 ? alpgpu_encode_f64(ctx, static_cast<const double*>(P.d_in[k]), cnt, &col[k])
+			                                : alpgpu_encode_f32(ctx, static_cast<const float*>(P.d_in[k]), cnt, &col[k]);
+			if (rc != ALPGPU_OK) { return rc; }
+			uint64_t pb = 0, eb = 0;
+			int      ov = 0;
+			if (int rc2 = alpgpu_column_totals(ctx, &col[k], &pb, &eb, &ov)) { return rc2; } // waits for this chunk; the other stream keeps copying
+			if (total_p + pb > cap_p_all || total_e + eb > cap_e_all) { return fail(ALPGPU_ERR_CAPACITY, "the column's exception stream exceeds the pipeline's reserve"); }
+			chunk_p.push_back(total_p);
+			chunk_e.push_back(total_e);
+			if (pb) { ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(d_packed_all) + total_p, col[k].d_packed, pb, hipMemcpyDeviceToDevice, P.stream[k])); }
+			if (eb) { ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(d_exc_all) + total_e, col[k].d_exc, eb, hipMemcpyDeviceToDevice, P.stream[k])); }
+			ALPGPU_HIP(hipMemcpyAsync(blob_rg + 32ull * (v0 / 100), col[k].d_rowgroups, 32ull * col[k].n_rowgroups, hipMemcpyDeviceToHost, P.stream[k]));
+			ALPGPU_HIP(hipMemcpyAsync(blob_vec + 32ull * v0, col[k].d_vectors, 32ull * cnt, hipMemcpyDeviceToHost, P.stream[k]));
+			total_p += pb;
+			total_e += eb;
+		}
+		ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
+		ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
+	}
+	const uint64_t need = alpgpu_blob_size(n, total_p, total_e);
+	if (written) { *written = need; }
+	if (capacity < need) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
+	if (n) {
+		if (total_p) { ALPGPU_HIP(hipMemcpyAsync(blob_str, d_packed_all, total_p, hipMemcpyDeviceToHost, P.stream[0])); }
+		if (total_e) { ALPGPU_HIP(hipMemcpyAsync(blob_str + align8(total_p), d_exc_all, total_e, hipMemcpyDeviceToHost, P.stream[1])); }
+		// meanwhile: the chunks' descriptors become the column's (offsets continue where the chunks before ended)
+		const uint64_t chunk = n < kHostChunkVectors ? n : kHostChunkVectors;
+		for (uint64_t v = chunk; v < n; ++v) { // chunk 0 is in place already
+			alpgpu_vector_desc d;
+			std::memcpy(&d, blob_vec + 32ull * v, sizeof(d));
+			d.packed_off += chunk_p[v / chunk];
+			d.exc_off += chunk_e[v / chunk];
+			std::memcpy(blob_vec + 32ull * v, &d, sizeof(d));
+		}
+		if (total_p != align8(total_p)) { std::memset(blob_str + total_p, 0, align8(total_p) - total_p); }
+		ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
+		ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
+	}
+	alpgpu_blob_header h;
+	std::memset(&h, 0, sizeof(h));
+	std::memcpy(h.magic, "ALPGPU1", 8);
+	h.version = 1, h.header_bytes = sizeof(h), h.n_values = n_values, h.n_vectors = n, h.n_rowgroups = nrg;
+	h.packed_bytes = total_p, h.exc_bytes = total_e;
+	h.reserved     = VALUE_BYTES == 8 ? 0 : VALUE_BYTES;
+	std::memcpy(blob, &h, sizeof(h));
+	return ALPGPU_OK;
+}
+
+template <int VALUE_BYTES>
+int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!h_blob) { return fail(ALPGPU_ERR_INVALID, "null blob"); }
+	alpgpu_blob_header h;
+	if (int rc = validate_blob_header(h_blob, size, VALUE_BYTES, h)) { return rc; } // the vectors are validated chunk by chunk, while the chunk before is in flight
+	if (n_values) { *n_values = h.n_values; }
+	if (h.n_values > out_capacity_values) { return fail(ALPGPU_ERR_CAPACITY, "output buffer too small (value count returned in *n_values)"); }
+	if (!h_out && h.n_values) { return fail(ALPGPU_ERR_INVALID, "null output"); }
+	const uint64_t n = h.n_vectors;
+	if (n == 0) { return ALPGPU_OK; }
+	const uint64_t VB       = 1024ull * VALUE_BYTES;
+	const uint8_t* blob_rg  = static_cast<const uint8_t*>(h_blob) + sizeof(h);
+	const uint8_t* blob_vec = blob_rg + 32ull * h.n_rowgroups;
+	const uint8_t* blob_p   = blob_vec + 32ull * n;
+	const uint8_t* blob_e   = blob_p + align8(h.packed_bytes);
+	HostPipe P;
+	P.ctx   = ctx;
+	P.saved = ctx->stream;
+	alpgpu_column col;
+	std::memset(&col, 0, sizeof(col));
+	col.n_vectors = n, col.n_rowgroups = h.n_rowgroups, col.packed_capacity = h.packed_bytes, col.exc_capacity = h.exc_bytes;
+	col.packed_bytes_hint = h.packed_bytes, col.exc_bytes_hint = h.exc_bytes;
+	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_rowgroups), 32ull * h.n_rowgroups)) { return rc; }
+	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_vectors), 32ull * n)) { return rc; }
+	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_packed), h.packed_bytes + 128)) { return rc; }
+	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_exc), h.exc_bytes + 64)) { return rc; }
+	const uint64_t chunk = n < kHostChunkVectors ? n : kHostChunkVectors;
+	for (int k = 0; k < 2; ++k) {
+		ALPGPU_HIP(hipStreamCreateWithFlags(&P.stream[k], hipStreamNonBlocking));
+		if (hipMalloc(&P.d_in[k], chunk * VB) != hipSuccess) { return fail(ALPGPU_ERR_HIP, "hipMalloc (chunk buffer)", hipGetLastError()); }
+	}
+	// the descriptors and rowgroup states first (small), then stream by stream, chunk by chunk
+	ALPGPU_HIP(hipMemcpyAsync(col.d_rowgroups, blob_rg, 32ull * h.n_rowgroups, hipMemcpyHostToDevice, P.stream[0]));
+	ALPGPU_HIP(hipMemcpyAsync(col.d_vectors, blob_vec, 32ull * n, hipMemcpyHostToDevice, P.stream[0]));
+	ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
+	auto desc_at = [&](uint64_t v) {
+		alpgpu_vector_desc d;
+		std::memcpy(&d, blob_vec + 32ull * v, sizeof(d));
+		return d;
+	};
+	const uint64_t n_chunks = (n + chunk - 1) / chunk;
+	for (uint64_t i = 0; i < n_chunks; ++i) {
+		const int      k   = static_cast<int>(i & 1);
+		const uint64_t v0  = i * chunk;
+		const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
+		if (int rc = validate_blob_vectors(h_blob, h, VALUE_BYTES, v0, v0 + cnt)) { return rc; } // nothing of a chunk is launched before it passed
+		// the chunk's bytes: offsets ascend with the vector index (the streams are exclusive scans), so its ranges end where the next chunk's begin
+		const uint64_t p0 = desc_at(v0).packed_off, e0 = desc_at(v0).exc_off;
+		const uint64_t p1 = v0 + cnt < n ? desc_at(v0 + cnt).packed_off : h.packed_bytes;
+		const uint64_t e1 = v0 + cnt < n ? desc_at(v0 + cnt).exc_off : h.exc_bytes;
+		if (p1 < p0 || e1 < e0 || p1 > h.packed_bytes || e1 > h.exc_bytes) { return fail(ALPGPU_ERR_INVALID, "blob: stream offsets do not ascend with the vector index"); }
+		if (p1 > p0) { ALPGPU_HIP(hipMemcpyAsync(col.d_packed + p0, blob_p + p0, p1 - p0, hipMemcpyHostToDevice, P.stream[k])); }
+		if (e1 > e0) { ALPGPU_HIP(hipMemcpyAsync(col.d_exc + e0, blob_e + e0, e1 - e0, hipMemcpyHostToDevice, P.stream[k])); }
+		alpgpu_column view = col; // descriptors hold absolute stream offsets: a view of whole rowgroups decodes on its own
+		view.n_vectors     = cnt;
+		view.n_rowgroups   = (cnt + 99) / 100;
+		view.d_vectors     = col.d_vectors + v0;
+		view.d_rowgroups   = col.d_rowgroups + v0 / 100;
+		view.packed_bytes_hint = p1 - p0, view.exc_bytes_hint = e1 - e0;
+		ctx->stream        = P.stream[k];
+		const int rc = VALUE_BYTES == 8 ? alpgpu_decode_f64(ctx, &view, static_cast<double*>(P.d_in[k])) : alpgpu_decode_f32(ctx, &view, static_cast<float*>(P.d_in[k]));
+		if (rc != ALPGPU_OK) { return rc; }
+		const uint64_t val = (v0 + cnt) * 1024 <= h.n_values ? cnt * 1024 : h.n_values - v0 * 1024;
+		ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(h_out) + v0 * VB, P.d_in[k], val * VALUE_BYTES, hipMemcpyDeviceToHost, P.stream[k]));
+		// slot k is reused two chunks on: its copy down must have left by then
+		if (i + 2 < n_chunks) { /* same stream: stream order already guarantees it */ }
+	}
+	ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
+	ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
+	return ALPGPU_OK;
+}
+
+} // namespace
+} // extern "C++"
+
+int alpgpu_compress_host_f64(alpgpu_ctx* ctx, const double* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	return compress_host<8>(ctx, h_in, n_values, h_blob, capacity, written);
+}
+int alpgpu_compress_host_f32(alpgpu_ctx* ctx, const float* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	return compress_host<4>(ctx, h_in, n_values, h_blob, capacity, written);
+}
+int alpgpu_decompress_host_f64(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, double* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
+	return decompress_host<8>(ctx, h_blob, size, h_out, out_capacity_values, n_values);
+}
+int alpgpu_decompress_host_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, float* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
+	return decompress_host<4>(ctx, h_blob, size, h_out, out_capacity_values, n_values);
 }
 
 } // extern "C"

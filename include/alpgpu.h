@@ -159,6 +159,23 @@ int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
 int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
+/* ---- host-resident columns -----------------------------------------------------------------------------------------------
+ * The reference's callers (publication/source_code/bench_compression_ratio/alp.cpp:198-229) hold the column and what they
+ * compress it into in host memory.  These entry points take it from there: n_values values at h_in (the last vector may be
+ * incomplete: it is padded as alpgpu_pad_tail_* does) become a serialized column at h_blob — byte for byte the blob that
+ * alpgpu_encode_* + alpgpu_column_to_blob produce for the same values — and back.  Inside, chunks of whole rowgroups travel up on
+ * one stream while the previous chunk is encoded on another, the compressed streams collect in HBM and come down in one piece
+ * (decompression: streams up chunk by chunk, each chunk decoded from a view of the column, doubles down on the chunk's stream).
+ * Page-locked h_in / h_blob / h_out (alpgpu_malloc_host) give the link's rate (measured host to host: ~40 GB/s of doubles each
+ * way); pageable memory works, at the runtime's staging rate.  Synchronous: everything has arrived when the call returns.
+ * Capacity: alpgpu_blob_size(n_vectors, alpgpu_packed_capacity(n_vectors), alpgpu_exc_capacity(n_vectors)) always suffices; a
+ * smaller buffer returns ALPGPU_ERR_CAPACITY with the needed size in *written.  The context's stream is left as it was. */
+int alpgpu_compress_host_f64(alpgpu_ctx* ctx, const double* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);
+int alpgpu_compress_host_f32(alpgpu_ctx* ctx, const float* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);
+/* *n_values receives the column's value count (also when h_out is too small: ALPGPU_ERR_CAPACITY); the blob is validated first */
+int alpgpu_decompress_host_f64(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, double* h_out, uint64_t out_capacity_values, uint64_t* n_values);
+int alpgpu_decompress_host_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, float* h_out, uint64_t out_capacity_values, uint64_t* n_values);
+
 /* Measurement aid, not part of the codec: launches the memory traffic of the single-pass encode without its arithmetic — the same
  * launch shape, every 8 KiB vector of d_in read once, write_bytes_per_vector (a multiple of 16, <= 8192) written per vector at
  * d_out + v * write_bytes_per_vector, stored data depending on all loaded data.  bench.py times it to put a measured ceiling for the

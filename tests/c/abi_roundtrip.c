@@ -91,6 +91,35 @@ static int roundtrip_f64(alpgpu_ctx* ctx) {
 	}
 	printf("ok   f64: %llu vectors, %.2f bits/value, blob %llu bytes\n", (unsigned long long)n, (double)(pb + eb + 32 * n) * 8.0 / (double)values,
 	       (unsigned long long)written);
+	/* the host-to-host entry points: page-locked buffers, the same blob byte for byte, and back */
+	{
+		double*  p_in = NULL;
+		double*  p_out = NULL;
+		void*    p_blob = NULL;
+		uint64_t w2 = 0, nv2 = 0;
+		CHECK(alpgpu_malloc_host(ctx, (void**)&p_in, values * 8));
+		CHECK(alpgpu_malloc_host(ctx, (void**)&p_out, values * 8));
+		CHECK(alpgpu_malloc_host(ctx, &p_blob, size));
+		memcpy(p_in, h_in, values * 8);
+		CHECK(alpgpu_compress_host_f64(ctx, p_in, values, p_blob, size, &w2));
+		if (w2 != written || memcmp(p_blob, blob, written) != 0) {
+			printf("FAIL f64: alpgpu_compress_host_f64 does not reproduce the column's blob\n");
+			return 1;
+		}
+		CHECK(alpgpu_decompress_host_f64(ctx, p_blob, w2, p_out, values, &nv2));
+		if (nv2 != values || memcmp(p_in, p_out, values * 8) != 0) {
+			printf("FAIL f64: host round trip\n");
+			return 1;
+		}
+		if (alpgpu_compress_host_f64(ctx, p_in, values, p_blob, 4096, &w2) != ALPGPU_ERR_CAPACITY || w2 == 0) {
+			printf("FAIL f64: a short blob buffer must be refused with the needed size\n");
+			return 1;
+		}
+		CHECK(alpgpu_free_host(ctx, p_in));
+		CHECK(alpgpu_free_host(ctx, p_out));
+		CHECK(alpgpu_free_host(ctx, p_blob));
+		printf("ok   f64: host-to-host compress / decompress reproduce the blob and the values\n");
+	}
 	free(blob);
 	free_column(ctx, &col);
 	free_column(ctx, &col2);

@@ -142,6 +142,24 @@ static int run(size_t n_rowgroups, bool rd) {
 	return failures;
 }
 
+// alp::gpu::column<PT>: a whole host column to its serialized form and back (the column ends inside a vector on purpose)
+template <class PT>
+static int whole_column(size_t n_values) {
+	std::vector<PT> col = make_column<PT>(n_values + 1024, false, 777 + sizeof(PT));
+	col.resize(n_values);
+	const auto t0   = std::chrono::steady_clock::now();
+	const auto blob = alp::gpu::column<PT>::compress(col.data(), col.size());
+	const auto t1   = std::chrono::steady_clock::now();
+	const auto back = alp::gpu::column<PT>::decompress(blob.data(), blob.size());
+	const auto t2   = std::chrono::steady_clock::now();
+	const bool ok   = back.size() == col.size() && std::memcmp(back.data(), col.data(), col.size() * sizeof(PT)) == 0;
+	auto       sec  = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+	std::printf("%s column of %zu values: %.2f bits/value, compress %.2f GB/s, decompress %.2f GB/s (pageable std::vector) | %s\n", sizeof(PT) == 8 ? "f64" : "f32",
+	            n_values, 8.0 * static_cast<double>(blob.size()) / static_cast<double>(n_values), n_values * sizeof(PT) / sec(t0, t1) / 1e9,
+	            n_values * sizeof(PT) / sec(t1, t2) / 1e9, ok ? "round trip ok" : "FAIL");
+	return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
 	const size_t n_rg = argc > 1 ? static_cast<size_t>(std::atoi(argv[1])) : 3;
 	int          f    = 0;
@@ -149,6 +167,8 @@ int main(int argc, char** argv) {
 	f += run<double>(n_rg, true);
 	f += run<float>(n_rg, false);
 	f += run<float>(n_rg, true);
+	f += whole_column<double>(30000 * 1024 + 517); // three chunks of the host pipeline
+	f += whole_column<float>(13000 * 1024 + 3);
 	std::printf("batch_test: %d failures\n", f);
 	return f ? 1 : 0;
 }

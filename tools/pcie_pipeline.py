@@ -105,3 +105,16 @@ def copy_down():
             host_out[v0 * 1024: v1 * 1024].copy_(bufs[k][: (v1 - v0) * 1024], non_blocking=True)
     torch.cuda.synchronize()
 print(f"plain page-locked copies of the doubles: up {gb / timed(copy_up):.1f} GB/s, down {gb / timed(copy_down):.1f} GB/s")
+
+# the library's own pipeline (include/alpgpu.h: alpgpu_compress_host_f64 / alpgpu_decompress_host_f64) on the same column
+nv = n * 1024
+cap = int(capi.lib.alpgpu_blob_size(n, capi.lib.alpgpu_packed_capacity(n), capi.lib.alpgpu_exc_capacity(n)))
+blob_buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+blob = ctx.compress_host(host_in, blob_buf)
+tc = timed(lambda: ctx.compress_host(host_in, blob_buf))
+td2 = timed(lambda: ctx.decompress_host(blob, host_out))
+ok2 = bool(torch.equal(host_out.view(torch.int64), host_in.view(torch.int64)))
+print(f"alpgpu_compress_host_f64: {gb / tc:.1f} GB/s of doubles into a {blob.numel() / 1e9:.2f} GB blob; alpgpu_decompress_host_f64: {gb / td2:.1f} GB/s; round trip bit-exact: {ok2}")
+pageable = host_in.clone()
+tcp = timed(lambda: ctx.compress_host(pageable, torch.empty(cap, dtype=torch.uint8)), reps=1)
+print(f"the same from and to pageable memory: compress {gb / tcp:.1f} GB/s")
