@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/alpgpu.h"
@@ -816,9 +818,10 @@ int alpgpu_rd_decode_vectors_f32(alpgpu_ctx* ctx, float* d_out, const uint32_t* 
 // alpgpu_compress_host_* / alpgpu_decompress_host_*: the column AND its serialized form live in host memory (the reference's callers,
 // publication/source_code/bench_compression_ratio/alp.cpp:198-229, hold both there).  Two streams, two chunk slots of whole rowgroups:
 // while chunk i is copied up on one stream, chunk i-1 is encoded on the other.  A chunk is encoded into its slot's column by the
-// ordinary (self-healing) encode, then appended to the column's streams in HBM at the running offsets; its descriptors go straight to
-// their place in the blob and are shifted by those offsets on the host at the end (a column cut at rowgroup boundaries is the sum of
-// its parts: tests/test_sharding*.py).  The streams come down in one copy each when the last chunk is done.  Decompression mirrors it:
+// ordinary (self-healing) encode; its packed bytes come straight down to their place in the blob (known chunk by chunk), its exception
+// bytes are appended to the column's exception stream in HBM (its place in the blob depends on the packed stream's final size) and come
+// down in one copy at the end; its descriptors go straight to their place in the blob and are shifted by the bytes of the chunks
+// before on the host (a column cut at rowgroup boundaries is the sum of its parts: tests/test_sharding*.py).  Decompression mirrors it:
 // the streams go up chunk by chunk, each chunk is decoded from a view of the column (descriptors hold absolute offsets), the doubles
 // come down on the chunk's stream while the next chunk is on its way up.
 extern "C++" {
@@ -873,9 +876,10 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 	P.ctx   = ctx;
 	P.saved = ctx->stream;
 	uint64_t total_p = 0, total_e = 0;
+	bool     blob_full = false;
 	std::vector<uint64_t> chunk_p, chunk_e; // bytes in front of every chunk
-	void *   d_packed_all = nullptr, *d_exc_all = nullptr;
-	uint64_t cap_p_all = 0, cap_e_all = 0;
+	void*    d_exc_all = nullptr;
+	uint64_t cap_e_all = 0;
 	if (n) {
 		const uint64_t chunk   = n < kHostChunkVectors ? n : kHostChunkVectors;
 		const uint64_t c_nrg   = (chunk + 99) / 100;
@@ -895,18 +899,16 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 			// the reference's sorted order per rowgroup: ALP_RD streams byte-identical to the reference's even at exception slots
 			if (int rc = P.alloc(reinterpret_cast<void**>(&col[k].d_rd_order), 2ull * ALPGPU_RD_ORDER_STRIDE * c_nrg)) { return rc; }
 		}
-		// the column's streams in HBM: the packed stream's worst case is 1.04 x the input and is taken whole; the exception
-		// stream's (1.25 x) is taken when it is a small part of the free memory, else a quarter of the input (an error, not an
-		// overrun, if a column ever needs more)
+		// the column's exception stream in HBM: its worst case (1.25 x the input) is taken when that is a small part of the free
+		// memory, else a quarter of the input (an error, not an overrun, if a column ever needs more)
 		size_t free_b = 0, total_b = 0;
 		ALPGPU_HIP(hipMemGetInfo(&free_b, &total_b));
-		cap_p_all = n * (VALUE_BYTES == 8 ? 8448ull : 4352ull) + 1024;
 		cap_e_all = n * (VALUE_BYTES == 8 ? 10240ull : 6144ull) + 64;
 		if (cap_e_all > free_b / 4) { cap_e_all = n * VB / 4 + 4096; }
-		if (int rc = P.alloc(&d_packed_all, cap_p_all)) { return rc; }
 		if (int rc = P.alloc(&d_exc_all, cap_e_all)) { return rc; }
 		const uint64_t n_chunks = (n + chunk - 1) / chunk;
-		for (uint64_t i = 0; i < n_chunks; ++i) {
+		// chunk i: copy up, (pad,) encode — everything that needs nothing from the host
+		auto send_up = [&](uint64_t i) -> int {
 			const int      k   = static_cast<int>(i & 1);
 			const uint64_t v0  = i * chunk;
 			const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
@@ -919,16 +921,34 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 				if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "pad launch failed", hipGetLastError()); }
 			}
 			col[k].n_vectors = cnt, col[k].n_rowgroups = (cnt + 99) / 100;
-			const int rc = VALUE_BYTES == 8 ? alpgpu_encode_f64(ctx, static_cast<const double*>(P.d_in[k]), cnt, &col[k])
-			                                : alpgpu_encode_f32(ctx, static_cast<const float*>(P.d_in[k]), cnt, &col[k]);
-			if (rc != ALPGPU_OK) { return rc; }
+			return VALUE_BYTES == 8 ? alpgpu_encode_f64(ctx, static_cast<const double*>(P.d_in[k]), cnt, &col[k])
+			                        : alpgpu_encode_f32(ctx, static_cast<const float*>(P.d_in[k]), cnt, &col[k]);
+		};
+		if (int rc = send_up(0)) { return rc; }
+		for (uint64_t i = 0; i < n_chunks; ++i) {
+			const int      k   = static_cast<int>(i & 1);
+			const uint64_t v0  = i * chunk;
+			const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
+			// The next chunk is on its way BEFORE the host blocks on this one's sizes: the link never waits for the host.  (Its slot
+			// was last used by chunk i - 1, whose copies down are ahead of it on the same stream.)
+			if (i + 1 < n_chunks) {
+				if (int rc = send_up(i + 1)) { return rc; }
+			}
+			ctx->stream = P.stream[k];
 			uint64_t pb = 0, eb = 0;
 			int      ov = 0;
-			if (int rc2 = alpgpu_column_totals(ctx, &col[k], &pb, &eb, &ov)) { return rc2; } // waits for this chunk; the other stream keeps copying
-			if (total_p + pb > cap_p_all || total_e + eb > cap_e_all) { return fail(ALPGPU_ERR_CAPACITY, "the column's exception stream exceeds the pipeline's reserve"); }
+			if (int rc2 = alpgpu_column_totals(ctx, &col[k], &pb, &eb, &ov)) { return rc2; } // waits for this chunk only
+			if (total_e + eb > cap_e_all) { return fail(ALPGPU_ERR_CAPACITY, "the column's exception stream exceeds the pipeline's reserve"); }
 			chunk_p.push_back(total_p);
 			chunk_e.push_back(total_e);
-			if (pb) { ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(d_packed_all) + total_p, col[k].d_packed, pb, hipMemcpyDeviceToDevice, P.stream[k])); }
+			// the packed stream's place in the blob is known chunk by chunk: it comes down at once, under the next chunk's copy up and
+			// encode; the exception stream's place depends on the packed stream's final size, so it collects in HBM
+			const uint64_t fixed = static_cast<uint64_t>(blob_str - blob);
+			if (fixed + total_p + pb <= capacity) {
+				if (pb) { ALPGPU_HIP(hipMemcpyAsync(blob_str + total_p, col[k].d_packed, pb, hipMemcpyDeviceToHost, P.stream[k])); }
+			} else {
+				blob_full = true; // keep counting: the caller learns the size it needs
+			}
 			if (eb) { ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(d_exc_all) + total_e, col[k].d_exc, eb, hipMemcpyDeviceToDevice, P.stream[k])); }
 			ALPGPU_HIP(hipMemcpyAsync(blob_rg + 32ull * (v0 / 100), col[k].d_rowgroups, 32ull * col[k].n_rowgroups, hipMemcpyDeviceToHost, P.stream[k]));
 			ALPGPU_HIP(hipMemcpyAsync(blob_vec + 32ull * v0, col[k].d_vectors, 32ull * cnt, hipMemcpyDeviceToHost, P.stream[k]));
@@ -940,9 +960,8 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 	}
 	const uint64_t need = alpgpu_blob_size(n, total_p, total_e);
 	if (written) { *written = need; }
-	if (capacity < need) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
+	if (capacity < need || blob_full) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
 	if (n) {
-		if (total_p) { ALPGPU_HIP(hipMemcpyAsync(blob_str, d_packed_all, total_p, hipMemcpyDeviceToHost, P.stream[0])); }
 		if (total_e) { ALPGPU_HIP(hipMemcpyAsync(blob_str + align8(total_p), d_exc_all, total_e, hipMemcpyDeviceToHost, P.stream[1])); }
 		// meanwhile: the chunks' descriptors become the column's (offsets continue where the chunks before ended)
 		const uint64_t chunk = n < kHostChunkVectors ? n : kHostChunkVectors;
@@ -1008,12 +1027,50 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 		std::memcpy(&d, blob_vec + 32ull * v, sizeof(d));
 		return d;
 	};
+	// is the output page-locked memory the device can address?
+	uint8_t* out_dev = nullptr;
+	{
+		hipPointerAttribute_t attr;
+		std::memset(&attr, 0, sizeof(attr));
+		if (hipPointerGetAttributes(&attr, h_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr) {
+			out_dev = static_cast<uint8_t*>(attr.devicePointer);
+		} else {
+			(void)hipGetLastError(); // pageable memory: not an error
+		}
+	}
 	const uint64_t n_chunks = (n + chunk - 1) / chunk;
+	// Validation (every descriptor, every exception position: a pass over ~15 % of the blob) runs ahead of the pipeline on a few host
+	// threads, chunk by chunk; nothing of a chunk is launched before that chunk has passed.  A worker that finds a fault stops at it;
+	// the main thread validates that chunk again itself, for the error code and text.
+	std::vector<std::atomic<int>> verdict(n_chunks); // 0 pending, 1 passed, 2 failed
+	for (auto& f : verdict) { f.store(0, std::memory_order_relaxed); }
+	const unsigned          n_workers = n_chunks >= 4 ? 4u : 1u;
+	std::vector<std::thread> workers;
+	struct Joiner {
+		std::vector<std::thread>& t;
+		~Joiner() {
+			for (auto& w : t) {
+				if (w.joinable()) { w.join(); }
+			}
+		}
+	} joiner {workers};
+	for (unsigned w = 0; w < n_workers; ++w) {
+		workers.emplace_back([&, w]() {
+			for (uint64_t c = w; c < n_chunks; c += n_workers) {
+				const uint64_t b = c * chunk, e = n - b < chunk ? n : b + chunk;
+				const int      rc = validate_blob_vectors(h_blob, h, VALUE_BYTES, b, e);
+				verdict[c].store(rc == ALPGPU_OK ? 1 : 2, std::memory_order_release);
+				if (rc != ALPGPU_OK) { return; }
+			}
+		});
+	}
 	for (uint64_t i = 0; i < n_chunks; ++i) {
 		const int      k   = static_cast<int>(i & 1);
 		const uint64_t v0  = i * chunk;
 		const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
-		if (int rc = validate_blob_vectors(h_blob, h, VALUE_BYTES, v0, v0 + cnt)) { return rc; } // nothing of a chunk is launched before it passed
+		int            vd;
+		while ((vd = verdict[i].load(std::memory_order_acquire)) == 0) { std::this_thread::yield(); }
+		if (vd != 1) { return validate_blob_vectors(h_blob, h, VALUE_BYTES, v0, v0 + cnt); }
 		// the chunk's bytes: offsets ascend with the vector index (the streams are exclusive scans), so its ranges end where the next chunk's begin
 		const uint64_t p0 = desc_at(v0).packed_off, e0 = desc_at(v0).exc_off;
 		const uint64_t p1 = v0 + cnt < n ? desc_at(v0 + cnt).packed_off : h.packed_bytes;
@@ -1028,12 +1085,16 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 		view.d_rowgroups   = col.d_rowgroups + v0 / 100;
 		view.packed_bytes_hint = p1 - p0, view.exc_bytes_hint = e1 - e0;
 		ctx->stream        = P.stream[k];
-		const int rc = VALUE_BYTES == 8 ? alpgpu_decode_f64(ctx, &view, static_cast<double*>(P.d_in[k])) : alpgpu_decode_f32(ctx, &view, static_cast<float*>(P.d_in[k]));
-		if (rc != ALPGPU_OK) { return rc; }
 		const uint64_t val = (v0 + cnt) * 1024 <= h.n_values ? cnt * 1024 : h.n_values - v0 * 1024;
-		ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(h_out) + v0 * VB, P.d_in[k], val * VALUE_BYTES, hipMemcpyDeviceToHost, P.stream[k]));
-		// slot k is reused two chunks on: its copy down must have left by then
-		if (i + 2 < n_chunks) { /* same stream: stream order already guarantees it */ }
+		// Page-locked output the device can address: the decode kernel stores straight into it — the doubles cross the link as the
+		// kernel's own (non-temporal) stores while the copy engine brings the next chunk's bytes up, so the two directions overlap;
+		// through the chunk buffer and a copy down they take turns on this system.  (A chunk that ends inside a vector goes through the
+		// buffer: the kernel writes whole vectors.)
+		void* const direct = (out_dev != nullptr && val == cnt * 1024) ? static_cast<void*>(out_dev + v0 * VB) : nullptr;
+		void* const target = direct ? direct : P.d_in[k];
+		const int   rc     = VALUE_BYTES == 8 ? alpgpu_decode_f64(ctx, &view, static_cast<double*>(target)) : alpgpu_decode_f32(ctx, &view, static_cast<float*>(target));
+		if (rc != ALPGPU_OK) { return rc; }
+		if (!direct) { ALPGPU_HIP(hipMemcpyAsync(static_cast<uint8_t*>(h_out) + v0 * VB, P.d_in[k], val * VALUE_BYTES, hipMemcpyDeviceToHost, P.stream[k])); }
 	}
 	ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
 	ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));

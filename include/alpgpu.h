@@ -164,7 +164,7 @@ int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* c
  * compress it into in host memory.  These entry points take it from there: n_values values at h_in (the last vector may be
  * incomplete: it is padded as alpgpu_pad_tail_* does) become a serialized column at h_blob — byte for byte the blob that
  * alpgpu_encode_* + alpgpu_column_to_blob produce for the same values — and back.  Inside, chunks of whole rowgroups travel up on
- * one stream while the previous chunk is encoded on another, the compressed streams collect in HBM and come down in one piece
+ * one stream while the previous chunk is encoded on another and its packed bytes come down; the exception stream collects in HBM and follows at the end
  * (decompression: streams up chunk by chunk, each chunk decoded from a view of the column, doubles down on the chunk's stream).
  * Page-locked h_in / h_blob / h_out (alpgpu_malloc_host) give the link's rate (measured host to host: ~40 GB/s of doubles each
  * way); pageable memory works, at the runtime's staging rate.  Synchronous: everything has arrived when the call returns.
