@@ -69,7 +69,7 @@ _sig("alpgpu_ctx_destroy", None, _vp)
 _sig("alpgpu_set_stream", _int, _vp, _vp)
 _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
-OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL = 1, 2, 3, 4
+OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL, OPT_DEBUG_LEGACY_CONSUMER = 1, 2, 3, 4, 5
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
@@ -86,6 +86,10 @@ _sig("alpgpu_use_own_stream", _int, _vp)
 _sig("alpgpu_decode_f64", _int, _vp, C.POINTER(CColumn), _vp)
 _sig("alpgpu_decode_sum_f64", _int, _vp, C.POINTER(CColumn), _vp)
 _sig("alpgpu_decode_count_range_f64", _int, _vp, C.POINTER(CColumn), C.c_double, C.c_double, _vp)
+_sig("alpgpu_column_sum_f64", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_column_sum_f32", _int, _vp, C.POINTER(CColumn), _vp)
+_sig("alpgpu_tree_sum_f64", _int, _vp, _vp, _u64, _vp)
+_sig("alpgpu_column_validate", _int, _vp, C.POINTER(CColumn), _int, C.POINTER(_u64))
 _sig("alpgpu_rowgroup_init_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_vectors_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
 _sig("alpgpu_encode_f64", _int, _vp, _vp, _u64, C.POINTER(CColumn))
@@ -364,6 +368,33 @@ class Context:
         fn = lib.alpgpu_decode_count_range_f64 if col.dtype == "f64" else lib.alpgpu_decode_count_range_f32
         _check(fn(self.h, C.byref(col.c), lo, hi, _vp(out.data_ptr())), "alpgpu_decode_count_range")
         return out
+
+    def column_sum(self, col: "DeviceColumn", out=None):
+        """the whole column's total in the documented tree order (alpgpu_column_sum_f64 / _f32): a 1-element float64 tensor"""
+        import torch
+        if out is None:
+            out = torch.empty(1, dtype=torch.float64, device=col.vectors.device)
+        fn = lib.alpgpu_column_sum_f64 if col.dtype == "f64" else lib.alpgpu_column_sum_f32
+        _check(fn(self.h, C.byref(col.c), _vp(out.data_ptr())), "alpgpu_column_sum")
+        return out
+
+    def tree_sum(self, x, out=None):
+        """alpgpu_tree_sum_f64 over a float64 device tensor"""
+        import torch
+        if out is None:
+            out = torch.empty(1, dtype=torch.float64, device=x.device)
+        _check(lib.alpgpu_tree_sum_f64(self.h, _vp(x.data_ptr()), x.numel(), _vp(out.data_ptr())), "alpgpu_tree_sum_f64")
+        return out
+
+    def column_validate(self, col: "DeviceColumn"):
+        """alpgpu_column_validate: None when every descriptor is well-formed, else the index of the first bad vector"""
+        bad = _u64(0)
+        rc = lib.alpgpu_column_validate(self.h, C.byref(col.c), 8 if col.dtype == "f64" else 4, C.byref(bad))
+        if rc == 0:
+            return None
+        if rc != -2:
+            _check(rc, "alpgpu_column_validate")
+        return int(bad.value)
 
     def decode_sum(self, col: "DeviceColumn", out=None):
         """per-vector sums (float64) of the decoded values without materialising them (alpgpu_decode_sum_f64 / _f32)"""

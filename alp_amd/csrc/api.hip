@@ -26,6 +26,7 @@ struct alpgpu_ctx {
 	uint64_t    hbm_bytes;
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
 	int         force_stall;     // debug: the single pass gives up in its look-back, the recovery route re-encodes
+	int         legacy_consumer; // debug / A-B timing: decode_sum through the round-2 launch shape (one workgroup per two vectors; another summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
 	hipEvent_t  ws_event;        // recorded behind the last encode that used the workspace ...
@@ -96,6 +97,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_vpw      = 0;
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
+	ctx->legacy_consumer = 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	ctx->ws_stream       = nullptr;
@@ -157,6 +159,9 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DEBUG_FORCE_STALL:
 		ctx->force_stall = value ? 1 : 0;
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DEBUG_LEGACY_CONSUMER:
+		ctx->legacy_consumer = value ? 1 : 0;
 		return ALPGPU_OK;
 	default:
 		return fail(ALPGPU_ERR_INVALID, "unknown option");
@@ -376,10 +381,42 @@ int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_s
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	if (alpgpu::launch_decode_sum(ctx->stream, col, d_sums, ctx->decode_vpw ? ctx->decode_vpw : 2) != ALPGPU_OK) {
-		return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError());
-	}
+	const int rc = ctx->legacy_consumer ? alpgpu::launch_decode_sum(ctx->stream, col, d_sums, 2) : alpgpu::launch_consume_sum(ctx->stream, col, d_sums, ctx->n_cus);
+	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
+}
+
+// The whole column's total (the reference's consumer keeps ONE accumulator across vectors, q1.cpp:91-100): per-vector sums into the
+// context's workspace, then the documented tree over them.  Everything stays on the stream; *d_total is device memory.
+static int column_sum(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total, bool f32) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || !d_total) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	const uint64_t n = col->n_vectors;
+	if (n == 0) {
+		ALPGPU_HIP(hipMemsetAsync(d_total, 0, sizeof(double), ctx->stream));
+		return ALPGPU_OK;
+	}
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	const uint64_t l1 = (n + 1023) / 1024;
+	if (int rc = ensure_workspace(ctx, 8ull * (n + 2 * l1) + 64)) { return rc; }
+	double* sums = static_cast<double*>(ctx->workspace);
+	int     rc   = f32 ? alpgpu::launch_decode_sum_f32(ctx->stream, col, sums) : alpgpu::launch_consume_sum(ctx->stream, col, sums, ctx->n_cus);
+	if (rc == ALPGPU_OK) { rc = alpgpu::launch_tree_sum(ctx->stream, sums, n, sums + n, d_total); }
+	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "column-sum launch failed", hipGetLastError()); }
+	return workspace_used(ctx);
+}
+int alpgpu_column_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total) { return column_sum(ctx, col, d_total, false); }
+int alpgpu_column_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total) { return column_sum(ctx, col, d_total, true); }
+// the same tree over any device array of doubles (e.g. the per-vector sums a caller already has)
+int alpgpu_tree_sum_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n, double* d_total) {
+	ALPGPU_CHECK_CTX(ctx);
+	if ((!d_in && n) || !d_total) { return fail(ALPGPU_ERR_INVALID, "null input or output"); }
+	const uint64_t l1 = (n + 1023) / 1024;
+	if (int rc = ensure_workspace(ctx, 16ull * l1 + 64)) { return rc; }
+	if (alpgpu::launch_tree_sum(ctx->stream, d_in, n, static_cast<double*>(ctx->workspace), d_total) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "tree-sum launch failed", hipGetLastError());
+	}
+	return workspace_used(ctx);
 }
 
 int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts) {
@@ -387,7 +424,7 @@ int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, dou
 	if (!col || (!d_counts && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	if (alpgpu::launch_decode_count_range(ctx->stream, col, lo, hi, d_counts) != ALPGPU_OK) {
+	if (alpgpu::launch_consume_count_range(ctx->stream, col, lo, hi, d_counts, ctx->n_cus) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;
@@ -571,7 +608,10 @@ static int validate_blob_header(const void* h_blob, uint64_t size, uint64_t valu
 
 // vectors [v_begin, v_end) of a blob whose header passed: every extent a kernel will dereference is checked here, so a corrupt
 // blob cannot make the decoder read out of bounds
-static int validate_blob_vectors(const void* h_blob, const alpgpu_blob_header& h, uint64_t value_bytes, uint64_t v_begin, uint64_t v_end) {
+// window (optional) = {p0, p1, e0, e1}: the byte ranges of the two streams that will be resident when these vectors are decoded (the
+// chunked host route uploads [p0, p1) / [e0, e1) only) — every record must lie inside them, not merely inside the whole streams.
+static int validate_blob_vectors(const void* h_blob, const alpgpu_blob_header& h, uint64_t value_bytes, uint64_t v_begin, uint64_t v_end,
+                                 const uint64_t* window = nullptr) {
 	const unsigned vbits = static_cast<unsigned>(8 * value_bytes); // 64 or 32
 	const unsigned max_e = value_bytes == 8 ? 18u : 10u;
 	const uint8_t* p   = static_cast<const uint8_t*>(h_blob) + sizeof(h);
@@ -593,6 +633,10 @@ static int validate_blob_vectors(const void* h_blob, const alpgpu_blob_header& h
 		if ((d.packed_off & 127ull) || (d.exc_off & 7ull) || d.packed_off > h.packed_bytes || psz > h.packed_bytes - d.packed_off || d.exc_off > h.exc_bytes ||
 		    esz > h.exc_bytes - d.exc_off) {
 			return fail(ALPGPU_ERR_INVALID, "blob: descriptor extent outside its stream");
+		}
+		if (window != nullptr && ((psz != 0 && (d.packed_off < window[0] || d.packed_off + psz > window[1])) ||
+		                          (esz != 0 && (d.exc_off < window[2] || d.exc_off + esz > window[3])))) {
+			return fail(ALPGPU_ERR_INVALID, "blob: a vector's record lies outside its chunk's stream range (offsets must ascend with the vector index)");
 		}
 		if (d.exc_cnt) { // positions must be < 1024
 			const uint8_t*  rec = p + 32ull * h.n_rowgroups + 32ull * h.n_vectors + align8(h.packed_bytes) + d.exc_off;
@@ -645,6 +689,27 @@ int alpgpu_column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 }
 int alpgpu_column_from_blob_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, alpgpu_column* col, uint64_t* n_values) {
 	return column_from_blob(ctx, h_blob, size, col, n_values, 4);
+}
+
+int alpgpu_column_validate(alpgpu_ctx* ctx, const alpgpu_column* col, int value_bytes, uint64_t* first_bad) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (value_bytes != 8 && value_bytes != 4)) { return fail(ALPGPU_ERR_INVALID, "null column, or value_bytes not 8 / 4"); }
+	if (first_bad) { *first_bad = ~0ull; }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (col->n_rowgroups != (col->n_vectors + 99) / 100 || !col->d_vectors || !col->d_rowgroups || (!col->d_exc && col->exc_capacity)) {
+		return fail(ALPGPU_ERR_INVALID, "column has no descriptors, or n_rowgroups != ceil(n_vectors / 100)");
+	}
+	if (int rc = ensure_workspace(ctx, 64)) { return rc; }
+	unsigned long long* d_bad = static_cast<unsigned long long*>(ctx->workspace);
+	ALPGPU_HIP(hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+	if (alpgpu::launch_validate_column(ctx->stream, col, static_cast<uint32_t>(value_bytes), d_bad) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "validate launch failed", hipGetLastError());
+	}
+	unsigned long long bad = 0;
+	ALPGPU_HIP(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	if (first_bad) { *first_bad = bad; }
+	return bad == ~0ull ? ALPGPU_OK : fail(ALPGPU_ERR_INVALID, "column: a descriptor is malformed or points outside its stream (index in *first_bad)");
 }
 
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
@@ -938,7 +1003,28 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 			uint64_t pb = 0, eb = 0;
 			int      ov = 0;
 			if (int rc2 = alpgpu_column_totals(ctx, &col[k], &pb, &eb, &ov)) { return rc2; } // waits for this chunk only
-			if (total_e + eb > cap_e_all) { return fail(ALPGPU_ERR_CAPACITY, "the column's exception stream exceeds the pipeline's reserve"); }
+			if (total_e + eb > cap_e_all) {
+				// The reserve was a guess (a quarter of the input when the worst case does not fit comfortably): grow it to what the rest of
+				// the column can need at most, keep what has been collected.  Only when even that cannot be had does the call fail — with
+				// its own text, and *written = the size that always suffices, so that a caller's "retry with a larger blob" stops here.
+				const uint64_t rest = n - v0 - cnt;
+				const uint64_t want = total_e + eb + rest * (VALUE_BYTES == 8 ? 10240ull : 6144ull) + 64;
+				void*          grown = nullptr;
+				ALPGPU_HIP(hipStreamSynchronize(P.stream[0])); // copies into the old reserve
+				ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
+				if (hipMalloc(&grown, want) != hipSuccess) {
+					(void)hipGetLastError();
+					if (written) { *written = alpgpu_blob_size(n, total_p + pb, want); }
+					return fail(ALPGPU_ERR_HIP, "the column's exception stream outgrew the pipeline's reserve and HBM has no room for a larger one (encode the column in pieces)");
+				}
+				if (total_e) { ALPGPU_HIP(hipMemcpy(grown, d_exc_all, total_e, hipMemcpyDeviceToDevice)); }
+				for (int q = 0; q < P.n_dev; ++q) {
+					if (P.dev[q] == d_exc_all) { P.dev[q] = grown; }
+				}
+				(void)hipFree(d_exc_all);
+				d_exc_all = grown;
+				cap_e_all = want;
+			}
 			chunk_p.push_back(total_p);
 			chunk_e.push_back(total_e);
 			// the packed stream's place in the blob is known chunk by chunk: it comes down at once, under the next chunk's copy up and
@@ -1054,11 +1140,27 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 			}
 		}
 	} joiner {workers};
+	// the byte ranges a chunk's decode will find in HBM: from its first vector's offsets to the next chunk's (the streams are exclusive
+	// scans in vector order); every record of the chunk is checked against them
+	struct Window {
+		uint64_t w[4];
+		bool     ok;
+	};
+	auto window_of = [&](uint64_t c) {
+		const uint64_t v0 = c * chunk, v1 = n - v0 < chunk ? n : v0 + chunk;
+		Window W;
+		W.w[0] = desc_at(v0).packed_off, W.w[2] = desc_at(v0).exc_off;
+		W.w[1] = v1 < n ? desc_at(v1).packed_off : h.packed_bytes;
+		W.w[3] = v1 < n ? desc_at(v1).exc_off : h.exc_bytes;
+		W.ok   = W.w[0] <= W.w[1] && W.w[2] <= W.w[3] && W.w[1] <= h.packed_bytes && W.w[3] <= h.exc_bytes;
+		return W;
+	};
 	for (unsigned w = 0; w < n_workers; ++w) {
 		workers.emplace_back([&, w]() {
 			for (uint64_t c = w; c < n_chunks; c += n_workers) {
 				const uint64_t b = c * chunk, e = n - b < chunk ? n : b + chunk;
-				const int      rc = validate_blob_vectors(h_blob, h, VALUE_BYTES, b, e);
+				const Window   W = window_of(c);
+				const int      rc = W.ok ? validate_blob_vectors(h_blob, h, VALUE_BYTES, b, e, W.w) : ALPGPU_ERR_INVALID;
 				verdict[c].store(rc == ALPGPU_OK ? 1 : 2, std::memory_order_release);
 				if (rc != ALPGPU_OK) { return; }
 			}
@@ -1070,12 +1172,11 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 		const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
 		int            vd;
 		while ((vd = verdict[i].load(std::memory_order_acquire)) == 0) { std::this_thread::yield(); }
-		if (vd != 1) { return validate_blob_vectors(h_blob, h, VALUE_BYTES, v0, v0 + cnt); }
-		// the chunk's bytes: offsets ascend with the vector index (the streams are exclusive scans), so its ranges end where the next chunk's begin
-		const uint64_t p0 = desc_at(v0).packed_off, e0 = desc_at(v0).exc_off;
-		const uint64_t p1 = v0 + cnt < n ? desc_at(v0 + cnt).packed_off : h.packed_bytes;
-		const uint64_t e1 = v0 + cnt < n ? desc_at(v0 + cnt).exc_off : h.exc_bytes;
-		if (p1 < p0 || e1 < e0 || p1 > h.packed_bytes || e1 > h.exc_bytes) { return fail(ALPGPU_ERR_INVALID, "blob: stream offsets do not ascend with the vector index"); }
+		const Window W = window_of(i);
+		if (!W.ok) { return fail(ALPGPU_ERR_INVALID, "blob: stream offsets do not ascend with the vector index"); }
+		if (vd != 1) { return validate_blob_vectors(h_blob, h, VALUE_BYTES, v0, v0 + cnt, W.w); }
+		// the chunk's bytes: its ranges end where the next chunk's begin, and every record of the chunk lies inside them (validated above)
+		const uint64_t p0 = W.w[0], p1 = W.w[1], e0 = W.w[2], e1 = W.w[3];
 		if (p1 > p0) { ALPGPU_HIP(hipMemcpyAsync(col.d_packed + p0, blob_p + p0, p1 - p0, hipMemcpyHostToDevice, P.stream[k])); }
 		if (e1 > e0) { ALPGPU_HIP(hipMemcpyAsync(col.d_exc + e0, blob_e + e0, e1 - e0, hipMemcpyHostToDevice, P.stream[k])); }
 		alpgpu_column view = col; // descriptors hold absolute stream offsets: a view of whole rowgroups decodes on its own

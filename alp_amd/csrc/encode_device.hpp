@@ -308,7 +308,10 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 				// converted int64, with positive powers of ten that cannot underflow) and never NaN on the literal route, which a NaN
 				// input always takes; so -0.0 (encodes to 0, decodes to +0.0: pass 1 makes it an exception) and NaN fail the integer
 				// compare exactly where the reference's float compare plus its special-value pass do.
-				const uint64_t exc_m = ballot64(__double_as_longlong(dec[g][j]) != __double_as_longlong(vv[g][j])) | over_m[g][j];
+				// (over_m decides only for lanes on the shortcut route: a lane of wide_m had enc / dec recomputed literally — wrap included
+				//  — and is judged by the compare alone; with f = 0 and t = -2^63 - 2048 the reference's cast gives INT64_MIN, which
+				//  decodes to -2^63 * 10^-e and CAN equal v)
+				const uint64_t exc_m = ballot64(__double_as_longlong(dec[g][j]) != __double_as_longlong(vv[g][j])) | (over_m[g][j] & ~wide_m[g][j]);
 				R.enc[m0 + g][j]     = enc[g][j];
 				R.ballot[m0 + g][j]  = exc_m;
 				R.cnt += __builtin_popcountll(exc_m);

@@ -1,0 +1,45 @@
+// guard_kernels.hip — opt-in validation of a device-resident column's descriptors (alpgpu_column_validate, include/alpgpu.h).
+//
+// The decode kernels follow the descriptors as they find them, like the reference's decoder follows the bit width, exception count and
+// positions its caller hands it (include/alp/decoder.hpp:141-149 writes out[pos[i]] unchecked; src/falp.cpp reads 16*bw words).  Columns
+// from alpgpu_encode_* are well-formed by construction and blobs are validated on the host (api.hip: validate_blob_vectors); this kernel
+// is the same set of checks for descriptors that reached HBM some other way.  One thread per vector.
+#include "alp_device.hpp"
+#include "launch.hpp"
+
+namespace alpgpu {
+
+__global__ __launch_bounds__(256) void k_validate_column(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                         const uint8_t* __restrict__ excs, uint64_t n_vectors, uint64_t packed_capacity, uint64_t exc_capacity,
+                                                         uint32_t value_bytes, unsigned long long* __restrict__ first_bad) {
+	const uint64_t v = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+	if (v >= n_vectors) { return; }
+	const alpgpu_vector_desc    d  = descs[v];
+	const alpgpu_rowgroup_state rg = rgs[v / kRowgroup];
+	const uint32_t vbits = 8u * value_bytes;
+	const uint32_t max_e = value_bytes == 8 ? 18u : 10u;
+	const bool     alp = d.scheme == ALPGPU_SCHEME_ALP, rd = d.scheme == ALPGPU_SCHEME_ALP_RD;
+	bool           ok  = (alp || rd) && rg.scheme == d.scheme;
+	const uint64_t psz = 128ull * (d.bw + (rd ? d.lbw : 0));
+	const uint64_t esz = ((alp ? value_bytes + 2ull : 4ull) * d.exc_cnt + 7ull) & ~7ull;
+	ok = ok && d.bw <= vbits && d.exc_cnt <= 1024 && (!alp || (d.e <= max_e && d.f <= d.e)) &&
+	     (!rd || (d.lbw >= 1 && d.lbw <= 3 && d.bw <= vbits - 1 && d.bw == rg.rd_rbw && d.lbw == rg.rd_lbw));
+	ok = ok && (d.packed_off & 127ull) == 0 && (d.exc_off & 7ull) == 0 && d.packed_off <= packed_capacity && psz <= packed_capacity - d.packed_off &&
+	     d.exc_off <= exc_capacity && esz <= exc_capacity - d.exc_off;
+	if (ok && d.exc_cnt) { // only now is the record known to lie inside the stream
+		const uint16_t* pos = reinterpret_cast<const uint16_t*>(excs + d.exc_off + static_cast<uint64_t>(alp ? value_bytes : 2u) * d.exc_cnt);
+		uint32_t        any = 0;
+		for (uint32_t j = 0; j < d.exc_cnt; ++j) { any |= pos[j]; }
+		ok = any < 1024;
+	}
+	if (!ok) { atomicMin(first_bad, static_cast<unsigned long long>(v)); }
+}
+
+int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_t value_bytes, unsigned long long* d_first_bad) {
+	const uint64_t n = col->n_vectors;
+	hipLaunchKernelGGL(k_validate_column, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, col->d_vectors, col->d_rowgroups, col->d_exc, n,
+	                   col->packed_capacity, col->exc_capacity, value_bytes, d_first_bad);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+} // namespace alpgpu

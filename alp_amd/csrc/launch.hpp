@@ -14,6 +14,14 @@ int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, doub
 int launch_decode_sum_f32(hipStream_t stream, const alpgpu_column* col, double* d_sums);
 int launch_decode_count_range_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
 
+// consume_kernels.hip: decode fused into SUM / COUNT consumers (persistent, software-pipelined), and the column total's tree
+int launch_consume_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int n_cus);
+int launch_consume_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts, int n_cus);
+int launch_tree_sum(hipStream_t stream, const double* d_in, uint64_t n, double* d_scratch, double* d_total);
+
+// guard_kernels.hip
+int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_t value_bytes, unsigned long long* d_first_bad);
+
 // init_kernels.hip
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first = 0,
                          uint64_t rg_count = 0);

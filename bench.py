@@ -3,8 +3,10 @@
 decoded doubles per GPU and fraction of the HBM roofline, with encode GB/s and the reference's CPU path next to it.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W [--column-gb 100]      (starts its own N local ranks when no launcher did)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--column-gb 100]
+(--gpus must equal the launcher's WORLD_SIZE; a mismatch, or fewer visible GPUs than ranks, exits non-zero.)
 
 N = 1 (BASELINE.json configs[1]): 1 Mi vectors (1024 doubles each, 8 GiB decoded) of synthetic decimal doubles,
 ALP-encoded, bit widths sweeping 1..53 across rowgroups (rowgroup r has bw = 1 + r mod 53), per-vector
@@ -364,6 +366,72 @@ def traffic_from_profile(result, n):
         pass
 
 
+def launch_plan(gpus: int, environ, visible_gpus: int):
+    """What `python bench.py --gpus N` has to do before it measures anything:
+      ("run",)          this process is the (or a) rank: --gpus 1 alone, or a rank of an external launcher whose WORLD_SIZE == N
+      ("spawn", N)      --gpus N > 1 and no launcher around it: start N local ranks (one per GPU) and relay rank 0's line
+      ("error", text)   the launcher's world size and --gpus disagree, or the box has fewer GPUs than ranks: exit non-zero, loudly
+    (The driver launches N > 1 under torch.distributed.run itself; the self-launch is for everybody who types the N = 1 form with
+    another N — which used to run the 1-GPU bench and print n_gpus 1.)"""
+    if gpus < 1:
+        return ("error", f"--gpus must be >= 1, got {gpus}")
+    shared = bool(environ.get("ALPGPU_BENCH_TEST_SHARED_GPU")) or bool(environ.get("ALPGPU_BENCH_DRY_RUN"))
+    world_env = environ.get("WORLD_SIZE")
+    if world_env is None:
+        if gpus == 1:
+            return ("run",)
+        if not shared and visible_gpus < gpus:
+            return ("error", f"--gpus {gpus} but only {visible_gpus} GPU(s) are visible on this node: one rank per GPU, no oversubscription")
+        return ("spawn", gpus)
+    if int(world_env) != gpus:
+        return ("error", f"launcher WORLD_SIZE={world_env} but --gpus {gpus}: they must agree (value and n_gpus are whole-job figures)")
+    return ("run",)
+
+
+def ensure_launcher(args):
+    plan = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if plan[0] == "run":
+        return
+    if plan[0] == "error":
+        print(f"bench.py: {plan[1]}", file=sys.stderr, flush=True)
+        sys.exit(2)
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={plan[1]}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    sys.exit(subprocess.run(cmd, env=env).returncode)  # the ranks inherit stdout: rank 0's JSON line is the last line printed
+
+
+def dry_run(args):
+    """Test knob ALPGPU_BENCH_DRY_RUN (tests/test_bench_cpu.py): the launcher, rendezvous, barrier / max-over-ranks clock and rank 0's
+    single line of the N > 1 path on a box WITHOUT a GPU (gloo on the CPU).  Nothing is decoded and the line says so."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    total = int(2e9 / 8192) // RG * RG
+    first, n = rowgroup_shard(total, rank, world)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0, float(n)], dtype=torch.float64)
+    cover = torch.tensor([n], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cover)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: no GPU work", "value": 0.0, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "data": "none (ALPGPU_BENCH_DRY_RUN)", "config": {"column_vectors": total, "vectors_covered_by_the_shards": int(cover[0])}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,7 +441,10 @@ def main():
     ap.add_argument("--column-gb", type=float, default=None, help="configs[4]: size of the ONE column that is sharded over the ranks (default 100 when N > 1)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the per-bit-width sweep, the encode legs and the CPU baselines")
     args = ap.parse_args()
+    ensure_launcher(args)
 
+    if os.environ.get("ALPGPU_BENCH_DRY_RUN"):
+        return dry_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

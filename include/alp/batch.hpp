@@ -275,11 +275,14 @@ struct column {
 		return blob;
 	}
 	static std::vector<PT> decompress(const uint8_t* blob, size_t size) {
-		if (size < sizeof(alpgpu_blob_header)) { throw std::runtime_error("alp::gpu::column::decompress: blob shorter than its header"); }
-		alpgpu_blob_header h;
-		std::memcpy(&h, blob, sizeof(h));
-		std::vector<PT> out(h.n_values);
-		uint64_t        n_values = 0;
+		// the value count comes from the library AFTER it has validated the header (a call with no output capacity returns it with
+		// ALPGPU_ERR_CAPACITY): nothing is allocated on the word of a corrupt or hostile blob
+		uint64_t n_values = 0;
+		const int probe   = sizeof(PT) == 8 ? alpgpu_decompress_host_f64(context(), blob, size, nullptr, 0, &n_values)
+		                                    : alpgpu_decompress_host_f32(context(), blob, size, nullptr, 0, &n_values);
+		if (probe != ALPGPU_OK && probe != ALPGPU_ERR_CAPACITY) { check(probe, "alpgpu_decompress_host (header)"); }
+		std::vector<PT> out(n_values);
+		if (n_values == 0) { return out; }
 		if constexpr (sizeof(PT) == 8) {
 			check(alpgpu_decompress_host_f64(context(), blob, size, out.data(), out.size(), &n_values), "alpgpu_decompress_host_f64");
 		} else {

@@ -114,8 +114,9 @@ typedef struct alpgpu_column {
 	uint64_t               packed_capacity; /* bytes; worst case n_vectors * 8448 */
 	uint8_t*               d_exc;           /* exception stream, 8-byte aligned */
 	uint64_t               exc_capacity;    /* bytes; worst case n_vectors * 10240 */
-	uint64_t*              d_totals;        /* [8]: packed bytes used, exception bytes used, overflow flag, encode stall flag (always 0 after
-	                                           alpgpu_encode_*), 4 scratch words */
+	uint64_t*              d_totals;        /* [8]: [0] packed bytes used, [1] exception bytes used, [2] overflow flag, [3] look-back stall flag of the
+	                                           single-pass encode (always 0 once alpgpu_encode_* has drained: the recovery route clears it),
+	                                           [4..5] running totals of the encode launch in flight, [6] recovery gate (latched from [3]), [7] unused */
 	/* host-side hints (0 = unknown): stream sizes as last seen by the host.  Filled by alpgpu_column_totals and
 	 * alpgpu_column_from_blob; decode uses them only to pick its launch shape (ALPGPU_OPT_DECODE_VECTORS_PER_WG = 0 "auto") */
 	uint64_t               packed_bytes_hint;
@@ -155,6 +156,9 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* ALPGPU_OPT_DEBUG_FORCE_STALL: 1 = every look-back of the single pass that has to wait gives up at once (tests of the
  * recovery route; the result is still a complete, byte-identical column). */
 #define ALPGPU_OPT_DEBUG_FORCE_STALL 4
+/* ALPGPU_OPT_DEBUG_LEGACY_CONSUMER: 1 = alpgpu_decode_sum_f64 through the round-2 launch shape (one short-lived workgroup per two
+ * vectors, the storing decode's kernel with a SUM sink) — for A/B timing only: its summation order is another one. */
+#define ALPGPU_OPT_DEBUG_LEGACY_CONSUMER 5
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
@@ -230,19 +234,41 @@ int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col);
 
 /* Fused decode of the whole column: ALP vectors = falp (unFFOR + int->double) + patch_exceptions;
- * ALP_RD vectors = unFFOR(right,left) + dictionary glue + patch.  d_out receives n_vectors*1024 doubles. */
+ * ALP_RD vectors = unFFOR(right,left) + dictionary glue + patch.  d_out receives n_vectors*1024 doubles.
+ * TRUST: alpgpu_decode_* / alpgpu_decode_sum_* / alpgpu_decode_count_range_* / alpgpu_column_sum_* follow col->d_vectors as they
+ * find it — offsets, widths and exception counts are NOT checked by the kernels (a descriptor with a bad packed_off reads out of
+ * bounds).  Columns written by alpgpu_encode_* and columns loaded by alpgpu_column_from_blob / alpgpu_decompress_host_* (which
+ * validate every descriptor on the host) are safe; for descriptors from anywhere else call alpgpu_column_validate first. */
 int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
 
 /* Decode fused into a consumer (the SCAN/SUM shape of the reference's end-to-end bench,
  * publication/source_code/bench_end_to_end/src/benchmarks/alp/queries/q1.cpp:63-104): d_sums[v] = sum of the 1024 decoded
- * values of vector v, exceptions patched in; the doubles themselves never reach HBM.  Summation order (so that the
- * result can be reproduced bit for bit): wavefront q of 4 owns values 256q..256q+255; lane L adds its values
- * 256q+2L, +1, 256q+128+2L, +1 in that order starting from 0; lanes combine by a butterfly (partner L^32, ^16, .., ^1);
- * the four wavefront sums combine as (w0 + w1) + (w2 + w3). */
+ * values of vector v, exceptions patched in; the doubles themselves never reach HBM.  A persistent, software-pipelined kernel
+ * (alp_amd/csrc/consume_kernels.hip): one wavefront per vector, packed words and exception records prefetched into an LDS ring.
+ * Summation order (so that the result can be reproduced bit for bit; changed in round 3 with the kernel's shape): lane L of 64
+ * adds its 16 values 128m + 2L, 128m + 2L + 1 (m = 0..7) in ascending index order starting from +0.0; the 64 lane sums combine
+ * by a balanced binary tree over ADJACENT lanes — (0,1), (2,3), ...; then (0..1, 2..3), ...; six levels. */
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 /* The other consumer named there, a predicate pushed into the scan: d_counts[v] = number of decoded values x of vector v with
  * lo <= x <= hi (exceptions patched in; NaN never qualifies; -0.0 == 0.0 as in C).  Nothing but 4 bytes per vector is written. */
 int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
+
+/* The column's total (the reference's consumer adds every vector into ONE accumulator, q1.cpp:91-100): *d_total (device memory,
+ * one double) = the per-vector sums of alpgpu_decode_sum_* combined by a balanced binary tree over adjacent elements, absent
+ * elements counting as +0.0: level by level, s'[i] = s[2i] + s[2i+1] over the array padded with +0.0 to a multiple of 1024, ten
+ * levels per kernel launch, until one element is left.  (A chain of a million dependent adds has no parallel form with the same
+ * rounding; this order is the documented replacement, reproduced on the host by tests/test_decode_sum_gpu.py.)  0.0 for an
+ * empty column.  alpgpu_tree_sum_f64 is that tree over any device array of n doubles.  Asynchronous on the context's stream. */
+int alpgpu_column_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total);
+int alpgpu_column_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total);
+int alpgpu_tree_sum_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n, double* d_total);
+
+/* Opt-in guard for device-resident columns of unknown origin: one pass over the descriptors on the device checks, for every vector,
+ * scheme (and that it is its rowgroup's), widths, exponent / factor, exception count, alignment, that its packed words and its
+ * exception record lie inside packed_capacity / exc_capacity, and that every exception position is < 1024.  value_bytes = 8
+ * (double column) or 4 (float column).  Synchronises the stream; ALPGPU_OK, or ALPGPU_ERR_INVALID with *first_bad = the lowest
+ * offending vector index (optional). */
+int alpgpu_column_validate(alpgpu_ctx* ctx, const alpgpu_column* col, int value_bytes, uint64_t* first_bad);
 
 /* host copy of d_totals after the stream has drained: packed bytes, exception bytes, overflow flag */
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow);

@@ -31,3 +31,21 @@ def test_two_ranks_shard_one_column_and_rank0_prints_one_line():
     assert r["value"] > 0 and r["roofline"]["frac"] > 0
     enc = r["encode"]
     assert enc["roundtrip_bit_exact_all_ranks"] is True and enc["overflow"] == 0 and enc["value"] > 0
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 --steps 3 --warmup 1 --column-gb 2` as typed — no torch.distributed.run around it: bench.py starts the
+    two ranks itself (shared-GPU knob on this one-GPU box) and rank 0's line says n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(ALPGPU_BENCH_TEST_SHARED_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--column-gb", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and p.stdout.rstrip().splitlines()[-1] == lines[0]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["encode"]["roundtrip_bit_exact_all_ranks"] is True
+    # and a launcher whose world size disagrees with --gpus is refused before anything runs
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         env=dict(env, WORLD_SIZE="4", RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=4" in bad.stderr

@@ -10,20 +10,39 @@ import layout
 pytestmark = pytest.mark.gpu
 
 
+def pairwise_tree(p):
+    """[..., 2^k] -> [...]: balanced binary tree over adjacent elements (s'[i] = s[2i] + s[2i+1], level by level)"""
+    while p.shape[-1] > 1:
+        p = p[..., 0::2] + p[..., 1::2]
+    return p[..., 0]
+
+
 def host_sums(values):
-    """values [n, 1024] -> the documented order: lane partials, butterfly over lanes, (w0 + w1) + (w2 + w3)"""
+    """values [n, 1024] -> the order documented in include/alpgpu.h (round 3): lane L of 64 adds its 16 values 128m + 2L, 128m + 2L + 1
+    (m = 0..7) in ascending index order starting from +0.0; the lane sums combine by a balanced tree over adjacent lanes"""
     n = values.shape[0]
-    v = values.reshape(n, 4, 2, 64, 2)  # vector, wavefront q, step mm, lane L, pair element
-    p = np.zeros((n, 4, 64))
+    v = values.reshape(n, 8, 64, 2)  # vector, step m, lane L, pair element
+    p = np.zeros((n, 64))
     with np.errstate(invalid="ignore", over="ignore"):
-        for mm in range(2):
-            p = p + v[:, :, mm, :, 0]
-            p = p + v[:, :, mm, :, 1]
-        idx = np.arange(64)
-        for d in (32, 16, 8, 4, 2, 1):
-            p = p + p[:, :, idx ^ d]
-        w = p[:, :, 0]
-        return (w[:, 0] + w[:, 1]) + (w[:, 2] + w[:, 3])
+        for m in range(8):
+            p = p + v[:, m, :, 0]
+            p = p + v[:, m, :, 1]
+        return pairwise_tree(p)
+
+
+def host_column_total(sums):
+    """alpgpu_column_sum_*: levels of 1024-element blocks (padded with +0.0), each reduced by the adjacent-pair tree"""
+    s = np.asarray(sums, dtype=np.float64)
+    if s.size == 0:
+        return np.float64(0.0)
+    with np.errstate(invalid="ignore", over="ignore"):
+        while True:
+            blocks = (s.size + 1023) // 1024
+            pad = np.zeros(blocks * 1024)
+            pad[: s.size] = s
+            s = pairwise_tree(pad.reshape(blocks, 1024))
+            if blocks == 1:
+                return s[0]
 
 
 COLUMNS = {
@@ -34,20 +53,21 @@ COLUMNS = {
 }
 
 
-@pytest.mark.parametrize("vectors_per_wg", [1, 2])
+def _same_bits(got, want):
+    got, want = np.asarray(got, dtype=np.float64).reshape(-1), np.asarray(want, dtype=np.float64).reshape(-1)
+    return (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+
+
 @pytest.mark.parametrize("name", list(COLUMNS.keys()))
-def test_decode_sum_matches_documented_order(ctx, oracle, name, vectors_per_wg):
+def test_decode_sum_matches_documented_order(ctx, oracle, name):
     from alp_amd import capi
     col = COLUMNS[name]()
     enc = oracle.encode_column(col)
     dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
-    try:
-        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vectors_per_wg)
-        got = ctx.decode_sum(dcol)
-        dec = ctx.decode(dcol)
-        ctx.synchronize()
-    finally:
-        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+    got = ctx.decode_sum(dcol)
+    dec = ctx.decode(dcol)
+    total = ctx.column_sum(dcol)
+    ctx.synchronize()
     dec = dec.cpu().numpy()
     assert np.array_equal(dec.view(np.uint64), col.view(np.uint64))
     want = host_sums(dec.reshape(-1, 1024))
@@ -56,6 +76,79 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name, vectors_per_wg):
     assert same.all(), f"{name}: {np.nonzero(~same)[0][:5]} {got[~same][:3]} {want[~same][:3]}"
     finite = np.isfinite(want)
     assert np.allclose(got[finite], col.reshape(-1, 1024)[finite].sum(axis=1), rtol=1e-12, atol=0)
+    # the column's total: the documented tree over the per-vector sums
+    assert _same_bits(total.cpu().numpy(), host_column_total(want)).all(), name
+
+
+def test_many_vectors_per_wavefront_ring_wraps_and_every_width(ctx, oracle):
+    """A column long enough that every wavefront of the persistent kernel consumes many vectors (its LDS ring wraps, its prefetch queue
+    fills and drains), with bit widths 0..52, exception-free and exception-carrying vectors, ALP and ALP_RD rowgroups interleaved."""
+    from alp_amd import capi
+    parts = [datagen.decimal_column(100, d, seed=40 + d) for d in (0, 1, 3, 6, 9)]
+    parts += [datagen.mixed_column(100, seed=50, exc_rate=0.05), datagen.rd_column(100, seed=51), datagen.drifting_column(100, seed=52)]
+    rng = np.random.default_rng(7)
+    for bits in (1, 7, 20, 33, 47, 52):  # integers of that many bits: (e, f) = (0, 0), width = bits
+        parts.append(rng.integers(0, 1 << bits, 100 * 1024).astype(np.float64))
+    col = np.concatenate(parts * 4)  # 5600 vectors: > 2 per wavefront of a 256-CU x 8-wavefront grid, many more on the tail wavefronts
+    enc = oracle.encode_column(col)
+    dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
+    got = ctx.decode_sum(dcol).cpu().numpy()
+    want = host_sums(col.reshape(-1, 1024))
+    assert _same_bits(got, want).all(), np.nonzero(~_same_bits(got, want))[0][:8]
+    assert _same_bits(ctx.column_sum(dcol).cpu().numpy(), host_column_total(want)).all()
+    v = col.reshape(-1, 1024)
+    cnt = ctx.decode_count_range(dcol, -1000.0, 1000.0).cpu().numpy().astype(np.int64)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(cnt, ((v >= -1000.0) & (v <= 1000.0)).sum(axis=1))
+
+
+def test_vectors_with_more_exceptions_than_the_ring_stages(ctx, oracle):
+    """exception records larger than the 1 KiB that travels with the packed words (ALP: > 102 exceptions; > 128: values past the stage),
+    up to all 1024 values being exceptions"""
+    from alp_amd import capi
+    rng = np.random.default_rng(11)
+    col = datagen.decimal_column(40, 2, seed=77).reshape(-1, 1024)
+    for v, n_exc in enumerate((103, 127, 128, 129, 200, 513, 1023, 1024, 1, 102)):
+        pos = rng.choice(1024, n_exc, replace=False)
+        col[3 * v, pos] = rng.standard_normal(n_exc) * np.pi * 1e-3
+    col = col.reshape(-1)
+    enc = oracle.encode_column(col)
+    assert enc["exc_cnt"].max() >= 1000
+    dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
+    got = ctx.decode_sum(dcol).cpu().numpy()
+    want = host_sums(col.reshape(-1, 1024))
+    assert _same_bits(got, want).all(), np.nonzero(~_same_bits(got, want))[0][:8]
+
+
+def test_tree_sum_is_the_documented_tree(ctx):
+    import torch
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 1023, 1024, 1025, 5000, 1024 * 1024 + 17):
+        x = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)
+        got = ctx.tree_sum(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert _same_bits(got, host_column_total(x)).all(), n
+
+
+def test_column_validate_flags_malformed_descriptors(ctx, oracle):
+    """alpgpu_column_validate: the opt-in guard for descriptors of unknown origin (the decode kernels trust what they find)"""
+    from alp_amd import capi
+    col = np.concatenate([datagen.mixed_column(100, seed=3, exc_rate=0.02), datagen.rd_column(100, seed=5)])  # rowgroup 0: ALP, rowgroup 1: ALP_RD
+    enc = oracle.encode_column(col)
+    rg, vec, packed, exc = layout.compact(enc)
+    assert (vec["scheme"][:100] == capi.SCHEME_ALP).all() and (vec["scheme"][100:] != capi.SCHEME_ALP).all()
+    assert ctx.column_validate(capi.DeviceColumn.from_host(rg, vec, packed, exc)) is None
+    for field, value, at in (("packed_off", np.uint64(1 << 40), 17), ("packed_off", np.uint64(64), 5), ("bw", 65, 44), ("exc_off", np.uint64(1 << 50), 60),
+                             ("exc_cnt", 1025, 3), ("scheme", 7, 150), ("e", 19, 9), ("lbw", 5, 130)):
+        bad = vec.copy()
+        if field == "exc_cnt" and bad[at]["exc_cnt"] == 0:
+            at = int(np.nonzero(bad["exc_cnt"])[0][0])
+        bad[field][at] = value
+        assert ctx.column_validate(capi.DeviceColumn.from_host(rg, bad, packed, exc)) == at, field
+    # an exception position past the vector
+    v = int(np.nonzero((vec["exc_cnt"] > 0) & (vec["scheme"] == capi.SCHEME_ALP))[0][0])
+    e2 = exc.copy()
+    e2.view(np.uint8)[int(vec[v]["exc_off"]) + 8 * int(vec[v]["exc_cnt"]) + 1] = 0x7F  # high byte of the first position
+    assert ctx.column_validate(capi.DeviceColumn.from_host(rg, vec, packed, e2)) == v
 
 
 @pytest.mark.parametrize("name", list(COLUMNS.keys()))

@@ -89,3 +89,25 @@ def test_empty_column_and_refusals():
     back = ctx.decode(col)
     ctx.synchronize()
     assert torch.equal(back.view(torch.int64), y.view(torch.int64))
+
+
+def test_a_record_outside_its_chunks_stream_range_is_refused():
+    """the chunked route uploads only the byte range between a chunk's first offsets and the next chunk's; a descriptor
+    that points into ANOTHER chunk's range (inside the whole stream, so alpgpu_column_from_blob decodes it deterministically) must not be
+    decoded from bytes that have not been uploaded — the chunked route refuses the blob."""
+    ctx = capi.Context(0)
+    n = CHUNK + 300  # two chunks
+    x = torch.from_numpy(datagen.decimal_column(n, 2, seed=17))
+    blob = ctx.compress_host(x)
+    out = torch.empty(x.numel(), dtype=torch.float64)
+    assert ctx.decompress_host(blob, out) == x.numel()
+    nrg = (n + 99) // 100
+    vec = blob.numpy()[64 + 32 * nrg: 64 + 32 * nrg + 32 * n].view(capi.VECTOR_DTYPE)
+    twin = int(np.nonzero(vec["bw"][:CHUNK] == vec[CHUNK + 50]["bw"])[0][0])  # same record size: the whole-stream check cannot see the swap
+    bad = blob.clone()
+    bvec = bad.numpy()[64 + 32 * nrg: 64 + 32 * nrg + 32 * n].view(capi.VECTOR_DTYPE)
+    bvec[CHUNK + 50]["packed_off"] = vec[twin]["packed_off"]  # a vector of chunk 1 reads chunk 0's bytes
+    col, n_values = ctx.from_blob(bad.numpy())  # the one-piece route holds the whole stream: accepted, deterministic
+    assert n_values == x.numel()
+    with pytest.raises(capi.AlpGpuError, match="chunk"):
+        ctx.decompress_host(bad, out)
