@@ -141,6 +141,29 @@ __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
 	return static_cast<uint32_t>(v);
 }
 
+// 64 lane partials -> their sum at a balanced binary tree over adjacent lanes (DPP: row_shr 1, 2, 4, 8, then row broadcasts); the value
+// of lane 63 is returned wave-uniform.  Lane 63's operands are, level by level, the sums of lanes {62,63}, {60..63}, {56..63}, {48..63},
+// {32..63}, {0..63}: each level adds two neighbouring subtrees of equal size.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take_f64(double v) {
+	const uint64_t b  = static_cast<uint64_t>(__double_as_longlong(v));
+	int            lo = static_cast<int>(static_cast<uint32_t>(b)), hi = static_cast<int>(static_cast<uint32_t>(b >> 32));
+	lo                = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+	hi                = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
+}
+__device__ __forceinline__ double wave_tree_sum_f64(double v) {
+	v = v + dpp_take_f64<0x111, 0xf>(v); // row_shr:1
+	v = v + dpp_take_f64<0x112, 0xf>(v); // row_shr:2
+	v = v + dpp_take_f64<0x114, 0xf>(v); // row_shr:4
+	v = v + dpp_take_f64<0x118, 0xf>(v); // row_shr:8   -> lane 15 of every row: the row's tree
+	v = v + dpp_take_f64<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+	v = v + dpp_take_f64<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> lane 63
+	const uint64_t b  = static_cast<uint64_t>(__double_as_longlong(v));
+	const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), 63), hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), 63);
+	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+
 __device__ __forceinline__ uint64_t bw_mask(int bw) { return bw >= 64 ? ~0ULL : ((1ULL << bw) - 1ULL); }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t x) {

@@ -26,7 +26,7 @@ struct alpgpu_ctx {
 	uint64_t    hbm_bytes;
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
 	int         force_stall;     // debug: the single pass gives up in its look-back, the recovery route re-encodes
-	int         legacy_consumer; // debug / A-B timing: decode_sum through the round-2 launch shape (one workgroup per two vectors; another summation order)
+	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
 	hipEvent_t  ws_event;        // recorded behind the last encode that used the workspace ...
@@ -97,7 +97,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_vpw      = 0;
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
-	ctx->legacy_consumer = 0;
+	ctx->pipelined_consumer = 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	ctx->ws_stream       = nullptr;
@@ -160,8 +160,8 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_DEBUG_FORCE_STALL:
 		ctx->force_stall = value ? 1 : 0;
 		return ALPGPU_OK;
-	case ALPGPU_OPT_DEBUG_LEGACY_CONSUMER:
-		ctx->legacy_consumer = value ? 1 : 0;
+	case ALPGPU_OPT_CONSUMER_PIPELINED:
+		ctx->pipelined_consumer = value ? 1 : 0;
 		return ALPGPU_OK;
 	default:
 		return fail(ALPGPU_ERR_INVALID, "unknown option");
@@ -381,7 +381,7 @@ int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_s
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	const int rc = ctx->legacy_consumer ? alpgpu::launch_decode_sum(ctx->stream, col, d_sums, 2) : alpgpu::launch_consume_sum(ctx->stream, col, d_sums, ctx->n_cus);
+	const int rc = ctx->pipelined_consumer ? alpgpu::launch_consume_sum(ctx->stream, col, d_sums, ctx->n_cus) : alpgpu::launch_decode_sum(ctx->stream, col, d_sums, 2);
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
@@ -400,7 +400,8 @@ static int column_sum(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total
 	const uint64_t l1 = (n + 1023) / 1024;
 	if (int rc = ensure_workspace(ctx, 8ull * (n + 2 * l1) + 64)) { return rc; }
 	double* sums = static_cast<double*>(ctx->workspace);
-	int     rc   = f32 ? alpgpu::launch_decode_sum_f32(ctx->stream, col, sums) : alpgpu::launch_consume_sum(ctx->stream, col, sums, ctx->n_cus);
+	int     rc   = f32 ? alpgpu::launch_decode_sum_f32(ctx->stream, col, sums)
+	                   : (ctx->pipelined_consumer ? alpgpu::launch_consume_sum(ctx->stream, col, sums, ctx->n_cus) : alpgpu::launch_decode_sum(ctx->stream, col, sums, 2));
 	if (rc == ALPGPU_OK) { rc = alpgpu::launch_tree_sum(ctx->stream, sums, n, sums + n, d_total); }
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "column-sum launch failed", hipGetLastError()); }
 	return workspace_used(ctx);
@@ -424,9 +425,9 @@ int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, dou
 	if (!col || (!d_counts && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	if (alpgpu::launch_consume_count_range(ctx->stream, col, lo, hi, d_counts, ctx->n_cus) != ALPGPU_OK) {
-		return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError());
-	}
+	const int rc = ctx->pipelined_consumer ? alpgpu::launch_consume_count_range(ctx->stream, col, lo, hi, d_counts, ctx->n_cus)
+	                                       : alpgpu::launch_decode_count_range(ctx->stream, col, lo, hi, d_counts);
+	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
 

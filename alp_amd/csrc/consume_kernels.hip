@@ -30,25 +30,31 @@ namespace alpgpu {
 #define ALPGPU_CONS_WAVES 8
 #endif
 #ifndef ALPGPU_CONS_RING
-#define ALPGPU_CONS_RING 16
+#define ALPGPU_CONS_RING 8
 #endif
 #ifndef ALPGPU_CONS_PREFETCH
 #define ALPGPU_CONS_PREFETCH 4
 #endif
 #ifndef ALPGPU_CONS_WG_PER_CU
-#define ALPGPU_CONS_WG_PER_CU 1
+#define ALPGPU_CONS_WG_PER_CU 2
 #endif
 constexpr int      kConsWaves     = ALPGPU_CONS_WAVES;    // wavefronts per workgroup (no cooperation between them: LDS bookkeeping only)
-constexpr int      kRingPieces    = ALPGPU_CONS_RING;     // 1-KiB pieces per wavefront ring (a power of two, >= 10 = the largest vector + its record)
+constexpr int      kRingPieces    = ALPGPU_CONS_RING;     // 1-KiB pieces per wavefront ring (a power of two).  A vector whose packed words + exception
+                                                          // record need more pieces than the ring has (8: ALP wider than 56 bits with exceptions, a few
+                                                          // ALP_RD shapes) is unpacked straight from HBM, without the ring — rare, correct, not fast
 constexpr uint32_t kRingBytes     = 1024u * kRingPieces;
 constexpr int      kPrefetchMax   = ALPGPU_CONS_PREFETCH; // vectors in flight behind the one being unpacked (ring space permitting)
 constexpr uint32_t kExcStageBytes = 1024; // of a vector's exception record that travels with its packed words (ALP: the values of <= 128
                                           // exceptions, the whole record up to 102; ALP_RD: whole records up to 256 exceptions)
-static_assert((kRingPieces & (kRingPieces - 1)) == 0 && kRingPieces >= 16, "ring = power of two, room for a 9 + 1 piece vector and a successor");
+static_assert((kRingPieces & (kRingPieces - 1)) == 0 && kRingPieces >= 4, "ring = power of two");
+constexpr int kConsWavesPerSimd = kConsWaves * ALPGPU_CONS_WG_PER_CU / 4; // the occupancy the register budget is sized for
 
+constexpr int kDescBatch = 8;  // descriptors requested together (one 32-byte LDS-DMA load each)
+constexpr int kDescSlots = 32; // descriptor ring: the batch in use, the two ahead of it, and the one being replaced
 struct __attribute__((aligned(16))) ConsumeLds {
 	uint8_t  ring[kRingBytes];
 	uint32_t mask[32];
+	uint32_t dring[kDescSlots][8]; // descriptors of this wavefront's next vectors, brought in like the data: no scalar load in the loop
 };
 
 // ---- LDS access of the main loop: inline assembly on purpose ---------------------------------------------------------------------
@@ -56,7 +62,7 @@ struct __attribute__((aligned(16))) ConsumeLds {
 // see it waits for ALL outstanding LDS-DMA loads (s_waitcnt vmcnt(0)), which would drain the prefetch queue once per vector.  Accesses
 // written as inline assembly carry no memory operand for that pass; their ordering is ours to keep: the LDS unit executes one
 // wavefront's operations in issue order, every asm here is volatile with a memory clobber (program order among them is kept), and a
-// read's result is used only behind an s_waitcnt lgkmcnt(0) that names it as an operand.
+// read's s_waitcnt lgkmcnt(0) sits INSIDE the statement that issues it.
 typedef unsigned long long                           ull2v_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint8_t    lds_byte_t;
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const lds_byte_t*)p)); }
@@ -77,17 +83,24 @@ __device__ __forceinline__ uint64_t lds_read_b64_now(uint32_t addr) {
 	asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
 	return r;
 }
-__device__ __forceinline__ ull2v_t lds_read_b128_async(uint32_t addr) {
-	ull2v_t r;
-	asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-	return r;
+// Eight reads and the wait for them in ONE statement: a result leaves the statement only when it has arrived.  (Reads and wait as
+// separate statements were wrong: the compiler may copy a read's destination registers before the statement that waits — it did, into
+// the registers the wait's tied operands were assigned — and such a copy takes whatever the registers held.  The younger wavefront of
+// a SIMD, whose LDS returns come later, then summed garbage now and then.)
+__device__ __forceinline__ void lds_read8_b128(ull2v_t (&r)[8], const uint32_t (&a)[8]) {
+	asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+	             "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+	             : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+	             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+	             : "memory");
 }
-__device__ __forceinline__ uint32_t lds_read_b32_async(uint32_t addr) {
-	uint32_t r;
-	asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-	return r;
+__device__ __forceinline__ void lds_read8_b32(uint32_t (&r)[8], const uint32_t (&a)[8]) {
+	asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+	             "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+	             : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+	             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+	             : "memory");
 }
-
 // s_waitcnt vmcnt(N) for a wave-uniform N known at run time (the instruction takes an immediate).  N = loads issued after the ones
 // waited for; a smaller immediate than N is always safe (it waits for more).
 __device__ __forceinline__ void wait_vmcnt_le(uint32_t n) {
@@ -122,27 +135,19 @@ __device__ __forceinline__ void wait_vmcnt_le(uint32_t n) {
 #undef ALPGPU_WAIT_CASE
 }
 
-// 64 lane partials -> their sum at a balanced binary tree over adjacent lanes (DPP: row_shr 1, 2, 4, 8, then row broadcasts); the value
-// of lane 63 is returned wave-uniform.  Lane 63's operands are, level by level, the sums of lanes {62,63}, {60..63}, {56..63}, {48..63},
-// {32..63}, {0..63}: each level adds two neighbouring subtrees of equal size.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_take_f64(double v) {
-	const uint64_t b  = static_cast<uint64_t>(__double_as_longlong(v));
-	int            lo = static_cast<int>(static_cast<uint32_t>(b)), hi = static_cast<int>(static_cast<uint32_t>(b >> 32));
-	lo                = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-	hi                = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
-}
-__device__ __forceinline__ double wave_tree_sum_f64(double v) {
-	v = v + dpp_take_f64<0x111, 0xf>(v); // row_shr:1
-	v = v + dpp_take_f64<0x112, 0xf>(v); // row_shr:2
-	v = v + dpp_take_f64<0x114, 0xf>(v); // row_shr:4
-	v = v + dpp_take_f64<0x118, 0xf>(v); // row_shr:8   -> lane 15 of every row: the row's tree
-	v = v + dpp_take_f64<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
-	v = v + dpp_take_f64<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> lane 63
-	const uint64_t b  = static_cast<uint64_t>(__double_as_longlong(v));
-	const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), 63), hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), 63);
-	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+// the same with few cases (waits for somewhat more than asked): for waits that are almost never waits
+__device__ __forceinline__ void wait_vmcnt_coarse(uint32_t n) {
+	if (n >= 32) {
+		asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+	} else if (n >= 16) {
+		asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+	} else if (n >= 8) {
+		asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+	} else if (n >= 4) {
+		asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+	} else {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
 }
 
 constexpr int kConsumeSum = 1, kConsumeCount = 2;
@@ -200,6 +205,23 @@ __device__ __forceinline__ alpgpu_vector_desc load_desc_scalar(const alpgpu_vect
 	d.scheme     = static_cast<uint16_t>(w[7] >> 16);
 	return d;
 }
+// the same record from LDS: lane l < 8 (every lane l & 7, in fact) holds its dword l & 7
+__device__ __forceinline__ alpgpu_vector_desc desc_from_lanes(uint32_t mine) {
+	uint32_t w[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { w[i] = __builtin_amdgcn_readlane(mine, i); }
+	alpgpu_vector_desc d;
+	d.packed_off = (static_cast<uint64_t>(w[1]) << 32) | w[0];
+	d.exc_off    = (static_cast<uint64_t>(w[3]) << 32) | w[2];
+	d.base       = static_cast<int64_t>((static_cast<uint64_t>(w[5]) << 32) | w[4]);
+	d.bw         = static_cast<uint8_t>(w[6]);
+	d.e          = static_cast<uint8_t>(w[6] >> 8);
+	d.f          = static_cast<uint8_t>(w[6] >> 16);
+	d.lbw        = static_cast<uint8_t>(w[6] >> 24);
+	d.exc_cnt    = static_cast<uint16_t>(w[7]);
+	d.scheme     = static_cast<uint16_t>(w[7] >> 16);
+	return d;
+}
 static_assert(offsetof(alpgpu_vector_desc, bw) == 24 && offsetof(alpgpu_vector_desc, exc_cnt) == 28 && sizeof(alpgpu_vector_desc) == 32, "descriptor layout");
 __device__ __forceinline__ RdDict load_rd_dict_scalar(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, bool is_rd) {
 	RdDict dict {0ull, 0ull};
@@ -220,7 +242,7 @@ __device__ __forceinline__ U64Pair unpack_pair_words(const ull2v_t& w0, const ul
 }
 
 template <int SINK>
-__global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu_vector_desc* __restrict__ descs,
+__global__ __launch_bounds__(64 * kConsWaves, kConsWavesPerSimd) void k_consume_column(const alpgpu_vector_desc* __restrict__ descs,
                                                                     const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                     const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs,
                                                                     void* __restrict__ out, uint64_t n_vectors, double lo, double hi) {
@@ -255,7 +277,42 @@ __global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu
 	uint32_t      q_start[Q], q_end[Q];
 #pragma unroll
 	for (int i = 0; i < Q; ++i) { q_start[i] = q_end[i] = 0; }
-	alpgpu_vector_desc d_issue = load_desc_scalar(descs, gw);
+	// Descriptors travel like the data: HBM -> LDS by LDS-DMA, kDescBatch at a time, two batches ahead of the one in use.  (As scalar
+	// loads they cost a cold miss per vector on the critical path: scalar loads return out of order, so every s_waitcnt lgkmcnt — the
+	// LDS reads' included — waited for the descriptor requested last: 2.4 us per vector, whatever its width.)
+	const uint32_t desc_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(L.dring));
+	uint32_t       issued_batches = 0, confirmed_batches = 0; // descriptor batches requested / known to have landed
+	uint32_t       bend[3]        = {0u, 0u, 0u};             // `issued` behind each batch that is requested but not yet confirmed, oldest first
+	auto issue_desc_batch = [&]() {
+		const uint32_t j0 = issued_batches * kDescBatch;
+#pragma unroll
+		for (int i = 0; i < kDescBatch; ++i) {
+			const uint32_t j = j0 + static_cast<uint32_t>(i);
+			if (j < my_cnt) { // wave-uniform
+				const uint32_t* gd = reinterpret_cast<const uint32_t*>(descs + (gw + static_cast<uint64_t>(j) * stride));
+				if (lane < 8) { __builtin_amdgcn_global_load_lds(gd + lane, &L.dring[j & (kDescSlots - 1)][0], 4, 0, 0); }
+				++issued;
+			}
+		}
+		const uint32_t slot = issued_batches - confirmed_batches;
+#pragma unroll
+		for (int i = 0; i < 3; ++i) { bend[i] = slot == static_cast<uint32_t>(i) ? issued : bend[i]; }
+		++issued_batches;
+	};
+	auto ensure_desc = [&](uint32_t j) { // descriptor j is readable from the ring
+		while (j / kDescBatch >= confirmed_batches) {
+			wait_vmcnt_coarse(issued - bend[0]); // requested two batches (>= 8 vectors) ago: landed long since
+			bend[0] = bend[1], bend[1] = bend[2];
+			++confirmed_batches;
+		}
+	};
+	auto read_desc = [&](uint32_t j) {
+		ensure_desc(j);
+		return desc_from_lanes(lds_read_b32_now(desc_lds + 32u * (j & (kDescSlots - 1)) + 4u * static_cast<uint32_t>(lane & 7)));
+	};
+	issue_desc_batch();
+	if (issued_batches * kDescBatch < my_cnt) { issue_desc_batch(); }
+	alpgpu_vector_desc d_issue = read_desc(0);
 
 	auto pieces_of = [](const alpgpu_vector_desc& d, uint32_t& pk_pieces, uint32_t& exc_loads) {
 		const bool     is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
@@ -268,17 +325,24 @@ __global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu
 	};
 
 	for (uint32_t k = 0; k < my_cnt; ++k) {
+		// descriptors: two batches ahead of the batch vector k is in
+		while (issued_batches * kDescBatch < my_cnt && issued_batches < k / kDescBatch + 3u) { issue_desc_batch(); }
 		// keep the ring full: vectors k .. k + kPrefetchMax, ring space permitting (vector k itself always fits an empty ring)
 		while (next_issue < my_cnt && next_issue - k <= static_cast<uint32_t>(kPrefetchMax)) {
 			uint32_t       pk_pieces, exc_loads;
 			const uint32_t n_units = pieces_of(d_issue, pk_pieces, exc_loads);
-			const uint32_t pieces  = pk_pieces + (exc_loads ? 1u : 0u);
+			uint32_t       pieces  = pk_pieces + (exc_loads ? 1u : 0u);
+			if (pieces > static_cast<uint32_t>(kRingPieces)) { pieces = pk_pieces = exc_loads = 0u; } // does not fit the ring at all: read directly when its turn comes
 			if (head + pieces - tail > static_cast<uint32_t>(kRingPieces)) { break; }
 			const ull2* g = reinterpret_cast<const ull2*>(packed + d_issue.packed_off);
 			for (uint32_t j = 0; j < pk_pieces; ++j) { // wave-uniform trip count
 				const uint32_t c   = 64u * j + static_cast<uint32_t>(lane);
 				uint8_t*       dst = L.ring + (((head + j) & (kRingPieces - 1u)) << 10); // wave-uniform base; the hardware adds 16 * lane
+#ifdef ALPGPU_CONS_NO_DMA // experiment: through registers
+				if (c < n_units) { reinterpret_cast<ull2*>(dst)[lane] = g[c]; }
+#else
 				if (c < n_units) { __builtin_amdgcn_global_load_lds(g + c, reinterpret_cast<ull2*>(dst), 16, 0, 0); }
+#endif
 			}
 			if (exc_loads) {
 				const bool      is_alp = d_issue.scheme == ALPGPU_SCHEME_ALP;
@@ -288,7 +352,11 @@ __global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu
 				uint8_t*        dst    = L.ring + (((head + pk_pieces) & (kRingPieces - 1u)) << 10);
 				for (uint32_t q = 0; q < exc_loads; ++q) {
 					const uint32_t c = 64u * q + static_cast<uint32_t>(lane);
+#ifdef ALPGPU_CONS_NO_DMA
+					if (c < dwords) { reinterpret_cast<uint32_t*>(dst + 256u * q)[lane] = ge[c]; }
+#else
 					if (c < dwords) { __builtin_amdgcn_global_load_lds(ge + c, reinterpret_cast<uint32_t*>(dst + 256u * q), 4, 0, 0); }
+#endif
 				}
 			}
 			issued += pk_pieces + exc_loads;
@@ -300,10 +368,10 @@ __global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu
 			}
 			head += pieces;
 			++next_issue;
-			if (next_issue < my_cnt) { d_issue = load_desc_scalar(descs, gw + static_cast<uint64_t>(next_issue) * stride); } // the next descriptor: in flight from here on
+			if (next_issue < my_cnt) { d_issue = read_desc(next_issue); }
 		}
 		const uint64_t           v = gw + static_cast<uint64_t>(k) * stride;
-		const alpgpu_vector_desc d = load_desc_scalar(descs, v); // read before (as d_issue): a scalar-cache hit
+		const alpgpu_vector_desc d = read_desc(k);
 		const bool               is_alp = d.scheme == ALPGPU_SCHEME_ALP;
 		const RdDict             dict   = load_rd_dict_scalar(rgs, v, !is_alp);
 		const uint32_t start_piece = q_start[0];
@@ -315,15 +383,44 @@ __global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu
 		}
 		uint32_t pk_pieces, exc_loads;
 		(void)pieces_of(d, pk_pieces, exc_loads);
+		const bool direct = pk_pieces + (exc_loads ? 1u : 0u) > static_cast<uint32_t>(kRingPieces); // not in the ring: everything from HBM
+		if (direct) { pk_pieces = exc_loads = 0u; }
 		const int      cnt      = d.exc_cnt;
 		const uint32_t val_b    = is_alp ? 8u : 2u;
 		const uint32_t rec      = ((val_b + 2u) * static_cast<uint32_t>(cnt) + 7u) & ~7u;
-		const bool     whole    = rec <= kExcStageBytes;                                  // positions staged too
-		const int      n_staged = whole ? cnt : static_cast<int>(kExcStageBytes / val_b); // values readable from the ring
+		const bool     whole    = !direct && rec <= kExcStageBytes;                                       // positions staged too
+		const int      n_staged = direct ? 0 : (whole ? cnt : static_cast<int>(kExcStageBytes / val_b)); // values readable from the ring
 		const uint8_t* rec_g    = excs + d.exc_off;
 		const uint32_t rec_l    = ring_lds + (((start_piece + pk_pieces) & (kRingPieces - 1u)) << 10);
 		if (cnt > 0 && lane < 32) { lds_write_b32(mask_lds + 4u * static_cast<uint32_t>(lane), 0u); }
 		wait_vmcnt_le(issued - end_count); // everything of vector k has landed in the ring
+#ifdef ALPGPU_CONS_DELAY // experiment
+		for (int zz = 0; zz < ALPGPU_CONS_DELAY; ++zz) { __builtin_amdgcn_s_sleep(127); }
+#endif
+#ifdef ALPGPU_CONS_VERIFY // experiment: is the ring what was asked for?  out[v] = mismatching 16-byte units + 1000 * (first bad unit + 1)
+		{
+			const uint32_t n_units_k = 8u * (static_cast<uint32_t>(d.bw) + (is_alp ? 0u : static_cast<uint32_t>(d.lbw)));
+			const ull2v_t* gk        = reinterpret_cast<const ull2v_t*>(packed + d.packed_off);
+			int            bad = 0, first = 1 << 20;
+			for (uint32_t c = lane; c < n_units_k; c += 64) {
+				const ull2v_t want = gk[c];
+				ull2v_t       have;
+				asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(have) : "v"(ring_lds + ((((start_piece & (kRingPieces - 1u)) << 10) + 16u * c) & (kRingBytes - 1u))) : "memory");
+				if (want.x != have.x || want.y != have.y) {
+					++bad;
+					first = first < static_cast<int>(c) ? first : static_cast<int>(c);
+				}
+			}
+			for (int dd = 32; dd >= 1; dd >>= 1) {
+				bad += __shfl_xor(bad, dd);
+				const int o = __shfl_xor(first, dd);
+				first       = o < first ? o : first;
+			}
+			if (lane == 0) { static_cast<double*>(out)[v] = bad == 0 ? 0.0 : static_cast<double>(bad + 1000 * (first + 1)); }
+			tail = start_piece + pk_pieces + (exc_loads ? 1u : 0u);
+			continue;
+		}
+#endif
 		ConsExcMask em {0u, 0};
 		if (cnt > 0) { // wave-uniform
 			if (whole) {
@@ -359,107 +456,125 @@ __global__ __launch_bounds__(64 * kConsWaves) void k_consume_column(const alpgpu
 			return r;
 		};
 
-		// all of this lane's packed words, requested back to back: pair (m, lane) sits in row 8m + (lane >> 3), unit column a = lane & 7
+		// This lane's packed words, four value steps (= eight 16-byte units) at a time: pair (m, lane) sits in row 8m + (lane >> 3), unit
+		// column a = lane & 7.  (All sixteen units at once would hold 64 registers: over the 128 that four wavefronts per SIMD leave.)
 		const uint32_t vstart = (start_piece & (kRingPieces - 1u)) << 10;
 		const int      bw     = d.bw;
 		const int      a      = lane & 7;
 		const int      r0     = lane >> 3;
-		ull2v_t        w0[8], w1[8];
-		int            sh[8];
+		const uint64_t mask   = bw_mask(bw);
+		// ALP: the vector's constants, and the conversion shortcut of decode_kernels.hip (decode_staged_vector) decided once from its descriptor
+		const uint64_t base   = static_cast<uint64_t>(d.base);
+		const int64_t  fact   = static_cast<int64_t>(lane_u64(static_cast<uint64_t>(t_fact), is_alp ? d.f : 0));
+		const double   frac   = __longlong_as_double(static_cast<long long>(lane_u64(static_cast<uint64_t>(__double_as_longlong(t_frac)), is_alp ? d.e : 0)));
+		const double   fact_d = __longlong_as_double(static_cast<long long>(lane_u64(static_cast<uint64_t>(__double_as_longlong(t_expd)), is_alp ? d.f : 0)));
+		const int64_t  blo      = d.base;
+		const bool     narrow   = is_alp && bw <= 50 && blo > -(1ll << 51) && blo < (1ll << 51) && blo + static_cast<int64_t>(mask) < (1ll << 51);
+		const double   maxabs   = narrow ? __builtin_fmax(__builtin_fabs(static_cast<double>(blo)), __builtin_fabs(static_cast<double>(blo + static_cast<int64_t>(mask)))) : 0.0;
+		const bool     shortcut = narrow && maxabs * fact_d < 9.2233720368547e18;
+		const uint64_t kbits    = 0x4338000000000000ull + base;
+		// ALP_RD (decode_kernels.hip): right parts = u64 lanes (bw = rbw, base 0); left parts = u16 lanes right behind them, 64 streams x 16
+		// rows: a lane's pair shares the row 2m + (lane >> 5) and is one aligned u32 of the left stream
+		const int      lbw   = d.lbw;
+		const uint32_t lmsk  = (1u << lbw) - 1u;
+		const uint64_t dlo = dict.lo, dhi = dict.hi;
+		const uint32_t lbase = vstart + 128u * static_cast<uint32_t>(bw);
+		double         acc   = 0.0;
+#pragma unroll 1 // (code size: the two halves share their instructions; unrolled, the kernel is twice as long for nothing)
+		for (int h = 0; h < 2; ++h) {
+			ull2v_t w[8]; // w[2i], w[2i + 1]: the unit of step m = 4h + i and the unit one stream word further
+			int     sh[4];
+			{
+				uint32_t ad[8];
 #pragma unroll
-		for (int m = 0; m < 8; ++m) {
-			const int      p   = (8 * m + r0) * bw;
-			const uint32_t off = 16u * static_cast<uint32_t>(8 * (p >> 6) + a);
-			sh[m]              = p & 63;
-			w0[m]              = lds_read_b128_async(ring_lds + ((vstart + off) & (kRingBytes - 1u)));
-			w1[m]              = lds_read_b128_async(ring_lds + ((vstart + off + 128u) & (kRingBytes - 1u)));
-		}
-		double acc = 0.0;
-		if (is_alp) {
-			asm volatile("s_waitcnt lgkmcnt(0)"
-			             : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w0[4]), "+v"(w0[5]), "+v"(w0[6]), "+v"(w0[7]), "+v"(w1[0]), "+v"(w1[1]),
-			               "+v"(w1[2]), "+v"(w1[3]), "+v"(w1[4]), "+v"(w1[5]), "+v"(w1[6]), "+v"(w1[7])
-			             :
-			             : "memory");
-			const uint64_t base   = static_cast<uint64_t>(d.base);
-			const int64_t  fact   = static_cast<int64_t>(lane_u64(static_cast<uint64_t>(t_fact), d.f));
-			const double   frac   = __longlong_as_double(static_cast<long long>(lane_u64(static_cast<uint64_t>(__double_as_longlong(t_frac)), d.e)));
-			const double   fact_d = __longlong_as_double(static_cast<long long>(lane_u64(static_cast<uint64_t>(__double_as_longlong(t_expd)), d.f)));
-			const uint64_t mask   = bw_mask(bw);
-			// the conversion shortcut of decode_kernels.hip (decode_staged_vector), decided once per vector from its descriptor
-			const int64_t  blo      = d.base;
-			const bool     narrow   = bw <= 50 && blo > -(1ll << 51) && blo < (1ll << 51) && blo + static_cast<int64_t>(mask) < (1ll << 51);
-			const double   maxabs   = narrow ? __builtin_fmax(__builtin_fabs(static_cast<double>(blo)), __builtin_fabs(static_cast<double>(blo + static_cast<int64_t>(mask)))) : 0.0;
-			const bool     shortcut = narrow && maxabs * fact_d < 9.2233720368547e18;
-			const uint64_t kbits    = 0x4338000000000000ull + base;
-#pragma unroll
-			for (int m = 0; m < 8; ++m) {
-				const U64Pair u = unpack_pair_words(w0[m], w1[m], sh[m], mask);
-				double        ox, oy;
-				if (shortcut) { // wave-uniform
-					ox = ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac;
-					oy = ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac;
+				for (int i = 0; i < 4; ++i) {
+					const int      p   = (8 * (4 * h + i) + r0) * bw;
+					const uint32_t off = 16u * static_cast<uint32_t>(8 * (p >> 6) + a);
+					sh[i]              = p & 63;
+					ad[2 * i]          = ring_lds + ((vstart + off) & (kRingBytes - 1u));
+					ad[2 * i + 1]      = ring_lds + ((vstart + off + 128u) & (kRingBytes - 1u));
+				}
+				if (!direct) { // wave-uniform
+					lds_read8_b128(w, ad);
 				} else {
-					ox = decode_value(static_cast<int64_t>(u.x + base), fact, frac);
-					oy = decode_value(static_cast<int64_t>(u.y + base), fact, frac);
-				}
-				if (cnt > 0) {
-					int            rank;
-					const uint32_t hits = cons_exception_hits(em, m, lane, rank);
-					if (hits & 1u) {
-						ox = __longlong_as_double(static_cast<long long>(exception_bits(rank)));
-						++rank;
-					}
-					if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(exception_bits(rank))); }
-				}
-				consume_one<SINK>(acc, ox, lo, hi);
-				consume_one<SINK>(acc, oy, lo, hi);
-			}
-		} else {
-			// ALP_RD (decode_kernels.hip): right parts = u64 lanes (bw = rbw, base 0); left parts = u16 lanes right behind them, 64 streams x
-			// 16 rows: a lane's pair shares the row 2m + (lane >> 5) and is one aligned u32 of the left stream
-			const int      rbw   = bw;
-			const int      lbw   = d.lbw;
-			const uint64_t mask  = bw_mask(rbw);
-			const uint32_t lmsk  = (1u << lbw) - 1u;
-			const uint64_t dlo = dict.lo, dhi = dict.hi;
-			const uint32_t lbase = vstart + 128u * static_cast<uint32_t>(rbw);
-			uint32_t       l0w[8], l1w[8];
+					const ull2v_t* gu = reinterpret_cast<const ull2v_t*>(packed + d.packed_off);
 #pragma unroll
-			for (int m = 0; m < 8; ++m) {
-				const int      p   = (2 * m + (lane >> 5)) * lbw;
-				const uint32_t off = 4u * static_cast<uint32_t>(32 * (p >> 4) + (lane & 31));
-				l0w[m]             = lds_read_b32_async(ring_lds + ((lbase + off) & (kRingBytes - 1u)));
-				l1w[m]             = lds_read_b32_async(ring_lds + ((lbase + off + 128u) & (kRingBytes - 1u)));
-			}
-			asm volatile("s_waitcnt lgkmcnt(0)"
-			             : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w0[4]), "+v"(w0[5]), "+v"(w0[6]), "+v"(w0[7]), "+v"(w1[0]), "+v"(w1[1]),
-			               "+v"(w1[2]), "+v"(w1[3]), "+v"(w1[4]), "+v"(w1[5]), "+v"(w1[6]), "+v"(w1[7])
-			             :
-			             : "memory");
-			asm volatile("" : "+v"(l0w[0]), "+v"(l0w[1]), "+v"(l0w[2]), "+v"(l0w[3]), "+v"(l0w[4]), "+v"(l0w[5]), "+v"(l0w[6]), "+v"(l0w[7]), "+v"(l1w[0]), "+v"(l1w[1]),
-			             "+v"(l1w[2]), "+v"(l1w[3]), "+v"(l1w[4]), "+v"(l1w[5]), "+v"(l1w[6]), "+v"(l1w[7])
-			             :
-			             : "memory");
-#pragma unroll
-			for (int m = 0; m < 8; ++m) {
-				const U64Pair  u  = unpack_pair_words(w0[m], w1[m], sh[m], mask);
-				const int      s  = ((2 * m + (lane >> 5)) * lbw) & 15;
-				const uint32_t i0 = (((l0w[m] & 0xFFFFu) >> s) | ((l1w[m] & 0xFFFFu) << (16 - s))) & lmsk;
-				const uint32_t i1 = (((l0w[m] >> 16) >> s) | ((l1w[m] >> 16) << (16 - s))) & lmsk;
-				uint64_t       l0 = ((i0 < 4 ? dlo >> (16 * i0) : dhi >> (16 * (i0 & 3))) & 0xFFFFull);
-				uint64_t       l1 = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
-				if (cnt > 0) {
-					int            rank;
-					const uint32_t hits = cons_exception_hits(em, m, lane, rank);
-					if (hits & 1u) {
-						l0 = exception_bits(rank);
-						++rank;
+					for (int i = 0; i < 4; ++i) {
+						const int u  = 8 * (((8 * (4 * h + i) + r0) * bw) >> 6) + a;
+						w[2 * i]     = gu[u];
+						w[2 * i + 1] = gu[u + 8]; // one unit row past the vector's end may be read (content irrelevant; the streams carry that slack)
 					}
-					if (hits & 2u) { l1 = exception_bits(rank); }
 				}
-				consume_one<SINK>(acc, __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x)), lo, hi);
-				consume_one<SINK>(acc, __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y)), lo, hi);
+			}
+			if (is_alp) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int     m = 4 * h + i;
+					const U64Pair u = unpack_pair_words(w[2 * i], w[2 * i + 1], sh[i], mask);
+					double        ox, oy;
+					if (shortcut) { // wave-uniform
+						ox = ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac;
+						oy = ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac;
+					} else {
+						ox = decode_value(static_cast<int64_t>(u.x + base), fact, frac);
+						oy = decode_value(static_cast<int64_t>(u.y + base), fact, frac);
+					}
+					if (cnt > 0) {
+						int            rank;
+						const uint32_t hits = cons_exception_hits(em, m, lane, rank);
+						if (hits & 1u) {
+							ox = __longlong_as_double(static_cast<long long>(exception_bits(rank)));
+							++rank;
+						}
+						if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(exception_bits(rank))); }
+					}
+					consume_one<SINK>(acc, ox, lo, hi);
+					consume_one<SINK>(acc, oy, lo, hi);
+				}
+			} else {
+				uint32_t lw[8]; // lw[2i], lw[2i + 1]: the left-stream words of step 4h + i
+				{
+					uint32_t ad[8];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int      p   = (2 * (4 * h + i) + (lane >> 5)) * lbw;
+						const uint32_t off = 4u * static_cast<uint32_t>(32 * (p >> 4) + (lane & 31));
+						ad[2 * i]          = ring_lds + ((lbase + off) & (kRingBytes - 1u));
+						ad[2 * i + 1]      = ring_lds + ((lbase + off + 128u) & (kRingBytes - 1u));
+					}
+					if (!direct) {
+						lds_read8_b32(lw, ad);
+					} else {
+						const uint32_t* gl = reinterpret_cast<const uint32_t*>(packed + d.packed_off + 128ull * static_cast<uint32_t>(bw));
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int j   = 32 * (((2 * (4 * h + i) + (lane >> 5)) * lbw) >> 4) + (lane & 31);
+							lw[2 * i]     = gl[j];
+							lw[2 * i + 1] = gl[j + 32];
+						}
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int      m  = 4 * h + i;
+					const U64Pair  u  = unpack_pair_words(w[2 * i], w[2 * i + 1], sh[i], mask);
+					const int      s  = ((2 * m + (lane >> 5)) * lbw) & 15;
+					const uint32_t i0 = (((lw[2 * i] & 0xFFFFu) >> s) | ((lw[2 * i + 1] & 0xFFFFu) << (16 - s))) & lmsk;
+					const uint32_t i1 = (((lw[2 * i] >> 16) >> s) | ((lw[2 * i + 1] >> 16) << (16 - s))) & lmsk;
+					uint64_t       l0 = ((i0 < 4 ? dlo >> (16 * i0) : dhi >> (16 * (i0 & 3))) & 0xFFFFull);
+					uint64_t       l1 = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
+					if (cnt > 0) {
+						int            rank;
+						const uint32_t hits = cons_exception_hits(em, m, lane, rank);
+						if (hits & 1u) {
+							l0 = exception_bits(rank);
+							++rank;
+						}
+						if (hits & 2u) { l1 = exception_bits(rank); }
+					}
+					consume_one<SINK>(acc, __longlong_as_double(static_cast<long long>((l0 << bw) | u.x)), lo, hi);
+					consume_one<SINK>(acc, __longlong_as_double(static_cast<long long>((l1 << bw) | u.y)), lo, hi);
+				}
 			}
 		}
 		// this vector's ring reads have all returned (every one of them was waited for): its pieces are free for the next loads

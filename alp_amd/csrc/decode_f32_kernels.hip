@@ -238,8 +238,7 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 				decode_staged_vector_f32<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, tid, wave, lane, &acc, range_lo,
 				                                         range_hi);
 			}
-#pragma unroll
-			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
+			acc = wave_tree_sum_f64(acc); // balanced tree over adjacent lanes (alp_device.hpp), as in the double kernel
 			if (lane == 0) { s_part[i][wave] = acc; }
 		}
 		__syncthreads();

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	__syncthreads();
 
 	if constexpr (SINK != kSinkStore) {
-		// per-vector sums: lane partial (step order) -> wavefront butterfly (xor 32,16,..,1) -> (w0 + w1) + (w2 + w3)
+		// per-vector sums: lane partial (step order) -> adjacent-lane tree per wavefront -> (w0 + w1) + (w2 + w3)
 		// (counts take the same route; they are small integers, so the order does not matter)
 		__shared__ double s_part[V][kDecWaves];
 #pragma unroll
@@ -338,8 +338,9 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 					decode_staged_vector<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
 				}
 			}
-#pragma unroll
-			for (int dd = 32; dd >= 1; dd >>= 1) { acc = acc + __shfl_xor(acc, dd); }
+			// the wavefront's 64 lane partials: balanced tree over adjacent lanes (DPP, alp_device.hpp) — round 2 used a ds_bpermute butterfly
+			// here, 12 LDS round trips and ~30 vector instructions per vector in a kernel that is VALU-bound (profiles/r03_consumers.txt)
+			acc = wave_tree_sum_f64(acc);
 			if (lane == 0) { s_part[i][wave] = acc; }
 		}
 		__syncthreads();

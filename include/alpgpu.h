@@ -156,9 +156,14 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* ALPGPU_OPT_DEBUG_FORCE_STALL: 1 = every look-back of the single pass that has to wait gives up at once (tests of the
  * recovery route; the result is still a complete, byte-identical column). */
 #define ALPGPU_OPT_DEBUG_FORCE_STALL 4
-/* ALPGPU_OPT_DEBUG_LEGACY_CONSUMER: 1 = alpgpu_decode_sum_f64 through the round-2 launch shape (one short-lived workgroup per two
- * vectors, the storing decode's kernel with a SUM sink) — for A/B timing only: its summation order is another one. */
-#define ALPGPU_OPT_DEBUG_LEGACY_CONSUMER 5
+/* ALPGPU_OPT_CONSUMER_PIPELINED: 1 = alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 / alpgpu_column_sum_f64 through the
+ * persistent, software-pipelined kernel of alp_amd/csrc/consume_kernels.hip (one wavefront per vector, packed words, exception
+ * records and descriptors prefetched into per-wavefront LDS rings by LDS-DMA) instead of the default (one short-lived workgroup per
+ * two vectors).  Measured in round 3: the consumers are VALU-bound, not latency-bound — the default executes 506 vector instructions
+ * per vector at 83 % VALU utilisation; the pipelined form needs 362-408 but keeps 16 wavefronts per CU and ends within +-5 % of the
+ * default (profiles/r03_consumers.txt) — so it stays an option.  Its summation order is its own: lane L adds its 16 values
+ * 128m + 2L, 128m + 2L + 1 (m = 0..7) in ascending order from +0.0, then the adjacent-lane tree over the 64 lane sums. */
+#define ALPGPU_OPT_CONSUMER_PIPELINED 5
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
@@ -243,11 +248,11 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
 
 /* Decode fused into a consumer (the SCAN/SUM shape of the reference's end-to-end bench,
  * publication/source_code/bench_end_to_end/src/benchmarks/alp/queries/q1.cpp:63-104): d_sums[v] = sum of the 1024 decoded
- * values of vector v, exceptions patched in; the doubles themselves never reach HBM.  A persistent, software-pipelined kernel
- * (alp_amd/csrc/consume_kernels.hip): one wavefront per vector, packed words and exception records prefetched into an LDS ring.
- * Summation order (so that the result can be reproduced bit for bit; changed in round 3 with the kernel's shape): lane L of 64
- * adds its 16 values 128m + 2L, 128m + 2L + 1 (m = 0..7) in ascending index order starting from +0.0; the 64 lane sums combine
- * by a balanced binary tree over ADJACENT lanes — (0,1), (2,3), ...; then (0..1, 2..3), ...; six levels. */
+ * values of vector v, exceptions patched in; the doubles themselves never reach HBM.  Summation order (so that the result can
+ * be reproduced bit for bit): wavefront q of 4 owns values 256q..256q+255; lane L adds its values 256q+2L, +1, 256q+128+2L, +1
+ * in that order starting from +0.0; the 64 lane sums of a wavefront combine by a balanced binary tree over ADJACENT lanes —
+ * (0,1), (2,3), ...; then (0..1, 2..3), ...; six levels (round 3; round 2 used a butterfly, partner L^32 first) — and the four
+ * wavefront sums as (w0 + w1) + (w2 + w3). */
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 /* The other consumer named there, a predicate pushed into the scan: d_counts[v] = number of decoded values x of vector v with
  * lo <= x <= hi (exceptions patched in; NaN never qualifies; -0.0 == 0.0 as in C).  Nothing but 4 bytes per vector is written. */
@@ -382,7 +387,7 @@ int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, al
 int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
 /* The fused consumers of alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 for float columns.  Sums accumulate in double
  * (every float widens exactly): thread t of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0; the 64
- * threads of a wavefront combine by a butterfly (partner ^32, ^16, .., ^1); the four wavefront sums as (w0 + w1) + (w2 + w3). */
+ * threads of a wavefront combine by the balanced tree over adjacent lanes (as above); the four wavefront sums as (w0 + w1) + (w2 + w3). */
 int alpgpu_decode_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 int alpgpu_decode_count_range_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
 int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values);

@@ -18,8 +18,22 @@ def pairwise_tree(p):
 
 
 def host_sums(values):
-    """values [n, 1024] -> the order documented in include/alpgpu.h (round 3): lane L of 64 adds its 16 values 128m + 2L, 128m + 2L + 1
-    (m = 0..7) in ascending index order starting from +0.0; the lane sums combine by a balanced tree over adjacent lanes"""
+    """values [n, 1024] -> the order documented in include/alpgpu.h: wavefront q of 4 owns values 256q..256q+255; lane L adds
+    256q+2L, +1, 256q+128+2L, +1 in that order from +0.0; adjacent-lane tree over the 64 lane sums; (w0 + w1) + (w2 + w3)"""
+    n = values.shape[0]
+    v = values.reshape(n, 4, 2, 64, 2)  # vector, wavefront q, step mm, lane L, pair element
+    p = np.zeros((n, 4, 64))
+    with np.errstate(invalid="ignore", over="ignore"):
+        for mm in range(2):
+            p = p + v[:, :, mm, :, 0]
+            p = p + v[:, :, mm, :, 1]
+        w = pairwise_tree(p)
+        return (w[:, 0] + w[:, 1]) + (w[:, 2] + w[:, 3])
+
+
+def host_sums_pipelined(values):
+    """the pipelined kernel's own order (ALPGPU_OPT_CONSUMER_PIPELINED): lane L of 64 adds its 16 values 128m + 2L, 128m + 2L + 1 (m = 0..7)
+    in ascending index order from +0.0; adjacent-lane tree over the 64 lane sums"""
     n = values.shape[0]
     v = values.reshape(n, 8, 64, 2)  # vector, step m, lane L, pair element
     p = np.zeros((n, 64))
@@ -28,6 +42,15 @@ def host_sums(values):
             p = p + v[:, m, :, 0]
             p = p + v[:, m, :, 1]
         return pairwise_tree(p)
+
+
+@pytest.fixture(params=["default", "pipelined"])
+def shape(request, ctx):
+    """both kernels behind alpgpu_decode_sum_f64 / _count_range_f64 / alpgpu_column_sum_f64, each with its documented order"""
+    from alp_amd import capi
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 1 if request.param == "pipelined" else 0)
+    yield host_sums_pipelined if request.param == "pipelined" else host_sums
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
 
 
 def host_column_total(sums):
@@ -59,7 +82,7 @@ def _same_bits(got, want):
 
 
 @pytest.mark.parametrize("name", list(COLUMNS.keys()))
-def test_decode_sum_matches_documented_order(ctx, oracle, name):
+def test_decode_sum_matches_documented_order(ctx, oracle, name, shape):
     from alp_amd import capi
     col = COLUMNS[name]()
     enc = oracle.encode_column(col)
@@ -70,7 +93,7 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name):
     ctx.synchronize()
     dec = dec.cpu().numpy()
     assert np.array_equal(dec.view(np.uint64), col.view(np.uint64))
-    want = host_sums(dec.reshape(-1, 1024))
+    want = shape(dec.reshape(-1, 1024))
     got = got.cpu().numpy()
     same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), f"{name}: {np.nonzero(~same)[0][:5]} {got[~same][:3]} {want[~same][:3]}"
@@ -80,7 +103,7 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name):
     assert _same_bits(total.cpu().numpy(), host_column_total(want)).all(), name
 
 
-def test_many_vectors_per_wavefront_ring_wraps_and_every_width(ctx, oracle):
+def test_many_vectors_per_wavefront_ring_wraps_and_every_width(ctx, oracle, shape):
     """A column long enough that every wavefront of the persistent kernel consumes many vectors (its LDS ring wraps, its prefetch queue
     fills and drains), with bit widths 0..52, exception-free and exception-carrying vectors, ALP and ALP_RD rowgroups interleaved."""
     from alp_amd import capi
@@ -89,11 +112,18 @@ def test_many_vectors_per_wavefront_ring_wraps_and_every_width(ctx, oracle):
     rng = np.random.default_rng(7)
     for bits in (1, 7, 20, 33, 47, 52):  # integers of that many bits: (e, f) = (0, 0), width = bits
         parts.append(rng.integers(0, 1 << bits, 100 * 1024).astype(np.float64))
-    col = np.concatenate(parts * 4)  # 5600 vectors: > 2 per wavefront of a 256-CU x 8-wavefront grid, many more on the tail wavefronts
+    # vectors too large for a wavefront's LDS ring (the kernel's direct path): random bit patterns whose top four bits take nine values,
+    # one of them rare -> ALP_RD with a 60-bit right part, 3-bit dictionary index and a few exceptions = 504 units + a record
+    nib = np.array([0x3, 0x4, 0xB, 0xC, 0x1, 0x2, 0x5, 0x6], dtype=np.uint64)[rng.integers(0, 8, 100 * 1024)]
+    nib[rng.random(nib.size) < 0.01] = 0
+    parts.append(((nib << np.uint64(60)) | rng.integers(0, 1 << 60, nib.size, dtype=np.uint64)).view(np.float64))
+    col = np.concatenate(parts * 4)  # 6000 vectors: more than one per wavefront of a 256-CU x 16-wavefront grid, many more on the tail wavefronts
     enc = oracle.encode_column(col)
+    assert enc["bw"].max() >= 60 and (enc["exc_cnt"][enc["bw"] >= 60] > 0).any()  # those vectors need 9 ring pieces
     dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
+    assert torch.equal(ctx.decode(dcol).view(torch.int64).cpu(), torch.from_numpy(col).view(torch.int64))
     got = ctx.decode_sum(dcol).cpu().numpy()
-    want = host_sums(col.reshape(-1, 1024))
+    want = shape(col.reshape(-1, 1024))
     assert _same_bits(got, want).all(), np.nonzero(~_same_bits(got, want))[0][:8]
     assert _same_bits(ctx.column_sum(dcol).cpu().numpy(), host_column_total(want)).all()
     v = col.reshape(-1, 1024)
@@ -102,7 +132,7 @@ def test_many_vectors_per_wavefront_ring_wraps_and_every_width(ctx, oracle):
         assert np.array_equal(cnt, ((v >= -1000.0) & (v <= 1000.0)).sum(axis=1))
 
 
-def test_vectors_with_more_exceptions_than_the_ring_stages(ctx, oracle):
+def test_vectors_with_more_exceptions_than_the_ring_stages(ctx, oracle, shape):
     """exception records larger than the 1 KiB that travels with the packed words (ALP: > 102 exceptions; > 128: values past the stage),
     up to all 1024 values being exceptions"""
     from alp_amd import capi
@@ -116,7 +146,7 @@ def test_vectors_with_more_exceptions_than_the_ring_stages(ctx, oracle):
     assert enc["exc_cnt"].max() >= 1000
     dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
     got = ctx.decode_sum(dcol).cpu().numpy()
-    want = host_sums(col.reshape(-1, 1024))
+    want = shape(col.reshape(-1, 1024))
     assert _same_bits(got, want).all(), np.nonzero(~_same_bits(got, want))[0][:8]
 
 
@@ -152,7 +182,7 @@ def test_column_validate_flags_malformed_descriptors(ctx, oracle):
 
 
 @pytest.mark.parametrize("name", list(COLUMNS.keys()))
-def test_decode_count_range_matches_numpy(ctx, oracle, name):
+def test_decode_count_range_matches_numpy(ctx, oracle, name, shape):
     """the predicate consumer: per-vector counts of lo <= x <= hi on the decoded values (exceptions, NaN, Inf, -0.0 included)"""
     from alp_amd import capi
     col = COLUMNS[name]()
@@ -173,17 +203,14 @@ def test_decode_count_range_matches_numpy(ctx, oracle, name):
 
 def host_sums_f32(values):
     """values [n, 1024] float32 -> the order documented in include/alpgpu.h: thread t adds values 4t..4t+3 (in double),
-    butterfly over the 64 threads of a wavefront, (w0 + w1) + (w2 + w3)"""
+    adjacent-lane tree over the 64 threads of a wavefront, (w0 + w1) + (w2 + w3)"""
     n = values.shape[0]
     v = values.astype(np.float64).reshape(n, 4, 64, 4)  # vector, wavefront, lane, quad element
     p = np.zeros((n, 4, 64))
     with np.errstate(invalid="ignore", over="ignore"):
         for c in range(4):
             p = p + v[:, :, :, c]
-        idx = np.arange(64)
-        for d in (32, 16, 8, 4, 2, 1):
-            p = p + p[:, :, idx ^ d]
-        w = p[:, :, 0]
+        w = pairwise_tree(p)
         return (w[:, 0] + w[:, 1]) + (w[:, 2] + w[:, 3])
 
 
