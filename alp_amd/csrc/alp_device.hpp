@@ -196,6 +196,42 @@ __device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state(const alpgp
 	return s;
 }
 
+// The same from a state that another kernel — the persistent rowgroup search on a second stream (init_kernels.hip, ASYNC) — is
+// publishing while this one runs.  The eight words are read with agent-scope loads (they bypass this CU's L1 and this XCD's L2, where
+// stale lines of an earlier call could sit) in ONE 32-byte request; the tag (pad byte = kStateReady, stored last by the publisher after
+// the other words had reached memory) says whether they are there.  Polls with s_sleep in between; gives up after spin_limit polls
+// (ok = false: the caller raises the encode's stall flag and the recovery route re-encodes).  The returned state has pad = 0.
+constexpr uint32_t kStateReady = 0xA5u;
+__device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state_async(const alpgpu_rowgroup_state* __restrict__ p, int lane, uint32_t spin_limit, bool& ok) {
+	const uint32_t* src  = reinterpret_cast<const uint32_t*>(p) + (lane & 7);
+	uint32_t        mine = 0, spins = 0;
+	ok                   = true;
+	for (;;) {
+		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((static_cast<uint32_t>(__builtin_amdgcn_readlane(mine, 3)) >> 24) == kStateReady) { break; }
+		if (++spins > spin_limit) {
+			ok = false;
+			break;
+		}
+		__builtin_amdgcn_s_sleep(32);
+	}
+	uint32_t w[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { w[i] = __builtin_amdgcn_readlane(mine, i); }
+	alpgpu_rowgroup_state s;
+	s.scheme = static_cast<uint8_t>(w[0]);
+	s.k      = static_cast<uint8_t>(w[0] >> 8);
+#pragma unroll
+	for (int i = 0; i < 10; ++i) { s.combos[i] = static_cast<uint8_t>(w[(2 + i) >> 2] >> (8 * ((2 + i) & 3))); }
+	s.rd_rbw       = static_cast<uint8_t>(w[3]);
+	s.rd_lbw       = static_cast<uint8_t>(w[3] >> 8);
+	s.rd_dict_size = static_cast<uint8_t>(w[3] >> 16);
+	s.pad          = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { s.rd_dict[i] = static_cast<uint16_t>(w[4 + (i >> 1)] >> (16 * (i & 1))); }
+	return s;
+}
+
 // The ALP_RD dictionary of a vector's rowgroup (eight u16 entries = bytes 16..31 of the state) as two words.  The column decode
 // kernels read it right after the descriptor, together with the packed words — read inside the decode it was a third dependent
 // round trip, behind the barrier, for every ALP_RD vector.

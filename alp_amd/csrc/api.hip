@@ -26,6 +26,10 @@ struct alpgpu_ctx {
 	uint64_t    hbm_bytes;
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
 	int         force_stall;     // debug: the single pass gives up in its look-back, the recovery route re-encodes
+	int         async_init_wg_per_cu; // persistent search workgroups per CU (1; ALPGPU_ASYNC_INIT_WG_PER_CU for experiments)
+	int         async_init;      // 1 (default): alpgpu_encode_* of a long column runs the rowgroup search BESIDE the vector encode (second stream)
+	hipStream_t init_stream;     // ... on this stream (highest priority: its few workgroups are placed first)
+	hipEvent_t  ev_fork, ev_head, ev_join;
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -90,6 +94,22 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 		return fail(ALPGPU_ERR_HIP, "hipStreamCreate failed");
 	}
 	ctx->stream         = ctx->own_stream;
+	{
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		const char* pr = std::getenv("ALPGPU_INIT_STREAM_PRIO"); // experiments: "low" / "normal"; default: highest
+		const int   prio = pr && pr[0] == 'l' ? least : (pr && pr[0] == 'n' ? 0 : greatest);
+		if (hipStreamCreateWithPriority(&ctx->init_stream, hipStreamNonBlocking, prio) != hipSuccess ||
+		    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess) {
+			(void)hipStreamDestroy(ctx->own_stream);
+			delete ctx;
+			return fail(ALPGPU_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
+		}
+	}
+	ctx->async_init     = std::getenv("ALPGPU_ENCODE_SYNC_INIT") ? 0 : 1;
+	ctx->async_init_wg_per_cu = std::getenv("ALPGPU_ASYNC_INIT_WG_PER_CU") ? std::atoi(std::getenv("ALPGPU_ASYNC_INIT_WG_PER_CU")) : 1;
+	if (ctx->async_init_wg_per_cu < 1) { ctx->async_init_wg_per_cu = 1; }
 	ctx->n_cus          = prop.multiProcessorCount;
 	ctx->hbm_bytes      = prop.totalGlobalMem;
 	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup, bit 1: plain stores
@@ -123,6 +143,11 @@ void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 	(void)hipSetDevice(ctx->device);
 	if (ctx->ws_busy) { (void)hipEventSynchronize(ctx->ws_event); }
 	(void)hipEventDestroy(ctx->ws_event);
+	(void)hipStreamSynchronize(ctx->init_stream);
+	(void)hipEventDestroy(ctx->ev_fork);
+	(void)hipEventDestroy(ctx->ev_head);
+	(void)hipEventDestroy(ctx->ev_join);
+	(void)hipStreamDestroy(ctx->init_stream);
 	(void)hipStreamDestroy(ctx->own_stream);
 	if (ctx->workspace) { (void)hipFree(ctx->workspace); }
 	delete ctx;
@@ -159,6 +184,10 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DEBUG_FORCE_STALL:
 		ctx->force_stall = value ? 1 : 0;
+		return ALPGPU_OK;
+	case ALPGPU_OPT_ENCODE_ASYNC_INIT:
+		if (value < 0 || value > 2) { return fail(ALPGPU_ERR_INVALID, "async init: 0 (off), 1 (double columns: default) or 2 (float columns too)"); }
+		ctx->async_init = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_CONSUMER_PIPELINED:
 		ctx->pipelined_consumer = value ? 1 : 0;
@@ -307,7 +336,9 @@ int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, u
 // raises when its look-back gives up (d_totals[6]).  No host synchronisation; when nothing stalled — always, in practice —
 // the four gated launches cost a few microseconds.  A column is therefore complete whenever this returns ALPGPU_OK and the
 // stream has drained, whatever the dispatch order of the single pass was.
-int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
+// async_states: the rowgroup states are being published by the persistent search on ctx->init_stream (recorded in ctx->ev_join); the
+// single pass polls for them, and everything that reads the states plainly — the tag clean-up, the recovery route — waits for that stream
+static int encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col, bool async_states) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
@@ -321,19 +352,69 @@ int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	if (ctx->encode_two_pass) {
 		rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus);
 	} else {
-		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0);
+		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head); // (waits for / joins the search's stream)
 		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus, col->d_totals + 6); }
 	}
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
 	return workspace_used(ctx);
 }
+int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) { return encode_vectors_f64(ctx, d_in, n_vectors, col, false); }
 
-// Rowgroup init, then the vector encode, on the context's stream.  (Running the rowgroup search of the next chunk of the column
-// on a second stream while the vector encode of the current chunk runs was tried: 26 % SLOWER on MI355X — the single-pass
-// encode wants the whole device for its in-order tiles)
+// Rowgroup search + vector encode.
+// Short columns (and ALPGPU_OPT_ENCODE_ASYNC_INIT = 0, and the two-pass form): one after the other on the context's stream.
+// Long columns: the search of the first kAsyncHeadRowgroups rowgroups runs in front (a few tens of microseconds); the rest of the search
+// is the PERSISTENT kernel (about one 4-wavefront workgroup per CU, init_kernels.hip) on the context's second stream, started together
+// with the single-pass vector encode, which polls for each rowgroup's state as its tiles reach it.  The search is VALU-bound and touches
+// 3 % of the bytes, the vector encode is memory-bound with idle issue slots: side by side on the same CUs — one search wavefront per
+// SIMD fits beside two encode tiles, registers and LDS — the 0.55 ms the search took in front of a 1 Mi-vector encode disappear into it.
+// (Round 1 tried the search of the NEXT chunk as a full-width grid on a second stream: 26 % slower — its 9-wavefront, 62 KiB workgroups
+// displaced encode tiles.)  Everything rejoins the context's stream: callers see one stream, as before.
+constexpr uint64_t kAsyncHeadRowgroups = 256;  // searched in front: what the persistent search needs to get ahead of the encode's front
+constexpr uint64_t kAsyncMinRowgroups  = 1024; // shorter columns are not worth two streams
+static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col, bool async_states);
+extern "C++" {
+template <class T>
+static int encode_with_side_search(alpgpu_ctx* ctx, const T* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	constexpr bool f32  = sizeof(T) == 4;
+	const uint64_t n_rg = (n_vectors + 99) / 100;
+	ALPGPU_CHECK_CTX(ctx);
+	if (!d_in) { return fail(ALPGPU_ERR_INVALID, "null input"); }
+	if (int rc = check_column(col, n_vectors)) { return rc; }
+	static const bool serial = std::getenv("ALPGPU_ASYNC_SERIAL") != nullptr; // experiment: the publishing search IN FRONT of the polling encode, one stream
+	hipStream_t       side   = serial ? ctx->stream : ctx->init_stream;
+	ALPGPU_HIP(hipMemsetAsync(col->d_rowgroups, 0, 32ull * n_rg, ctx->stream)); // no tag is set
+	ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+	if (!serial) { ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0)); }
+	// the head of the search and, behind it, the persistent rest: both on the side stream; the context's stream meanwhile clears its
+	// totals and status words and then waits for the head only
+	auto search = [&](uint64_t first, uint64_t count, int grid) {
+		if constexpr (f32) {
+			return alpgpu::launch_rowgroup_init_async_f32(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid);
+		} else {
+			return alpgpu::launch_rowgroup_init_async(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid);
+		}
+	};
+	if (search(0, kAsyncHeadRowgroups, static_cast<int>(kAsyncHeadRowgroups)) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError()); }
+	ALPGPU_HIP(hipEventRecord(ctx->ev_head, side));
+	if (search(kAsyncHeadRowgroups, n_rg - kAsyncHeadRowgroups, ctx->n_cus * ctx->async_init_wg_per_cu) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
+	}
+	ALPGPU_HIP(hipEventRecord(ctx->ev_join, side));
+	if constexpr (f32) {
+		return encode_vectors_f32(ctx, d_in, n_vectors, col, true);
+	} else {
+		return encode_vectors_f64(ctx, d_in, n_vectors, col, true);
+	}
+}
+} // extern "C++"
+
 int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
-	if (int rc = alpgpu_rowgroup_init_f64(ctx, d_in, n_vectors, col)) { return rc; }
-	return alpgpu_encode_vectors_f64(ctx, d_in, n_vectors, col);
+	const uint64_t n_rg = (n_vectors + 99) / 100;
+	if (!ctx || !ctx->async_init || ctx->encode_two_pass || n_rg < kAsyncMinRowgroups) {
+		if (int rc = alpgpu_rowgroup_init_f64(ctx, d_in, n_vectors, col)) { return rc; }
+		return alpgpu_encode_vectors_f64(ctx, d_in, n_vectors, col);
+	}
+	return encode_with_side_search(ctx, d_in, n_vectors, col);
 }
 
 static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
@@ -766,7 +847,7 @@ int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, ui
 	return state_from_samples_f32(ctx, d_samples, n_samples, d_state, 1);
 }
 
-int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) { // see alpgpu_encode_vectors_f64
+static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col, bool async_states) { // see encode_vectors_f64
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
@@ -780,16 +861,24 @@ int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vec
 	if (ctx->encode_two_pass) {
 		rc = alpgpu::launch_encode_vectors_f32(ctx->stream, d_in, n_vectors, col, ws);
 	} else {
-		rc = alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0);
+		rc = alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head);
 		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors_f32(ctx->stream, d_in, n_vectors, col, ws, col->d_totals + 6); }
 	}
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
 	return workspace_used(ctx);
 }
+int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) { return encode_vectors_f32(ctx, d_in, n_vectors, col, false); }
 
+// Float columns keep the search in front unless ALPGPU_OPT_ENCODE_ASYNC_INIT = 2: the float single pass needs 77 VGPRs, THREE of its
+// tiles fit a CU, and the persistent search's wavefront takes one of them away for as long as it lives — 3.53 against 3.38 ms per 1 Mi
+// vectors (profiles/r03_async_init.txt); beside the double kernel's two tiles it fits in what they leave.
 int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
-	if (int rc = alpgpu_rowgroup_init_f32(ctx, d_in, n_vectors, col)) { return rc; }
-	return alpgpu_encode_vectors_f32(ctx, d_in, n_vectors, col);
+	const uint64_t n_rg = (n_vectors + 99) / 100;
+	if (!ctx || ctx->async_init < 2 || ctx->encode_two_pass || n_rg < kAsyncMinRowgroups) {
+		if (int rc = alpgpu_rowgroup_init_f32(ctx, d_in, n_vectors, col)) { return rc; }
+		return alpgpu_encode_vectors_f32(ctx, d_in, n_vectors, col);
+	}
+	return encode_with_side_search(ctx, d_in, n_vectors, col);
 }
 
 int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out) {

@@ -483,8 +483,8 @@ struct RdEncoded {
 };
 
 __device__ __forceinline__ void encode_rd_registers(const VecIn& in, const alpgpu_rowgroup_state& rg, int lane, RdEncoded& R,
-                                                    const uint16_t* __restrict__ order_rg = nullptr) {
-	const RdOrderView order = load_rd_order(order_rg, rg, lane);
+                                                    const uint16_t* __restrict__ order_rg = nullptr, bool coherent = false) {
+	const RdOrderView order = load_rd_order(order_rg, rg, lane, coherent);
 	const int      rbw  = rg.rd_rbw;
 	const uint64_t mask = bw_mask(rbw);
 	const int      ds   = rg.rd_dict_size;

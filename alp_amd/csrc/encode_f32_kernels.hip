@@ -26,14 +26,17 @@ constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors
 
 // kSinglePass: `status` = look-back words.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only), `gate` as in
 // encode_kernels.hip, v_first = 0.
+// (the single pass is held to 96 VGPRs — __launch_bounds__' second argument, wavefronts per SIMD: four of them per SIMD then leave the 96
+// registers the persistent rowgroup search needs to share the CU)
 template <int MODE>
-__global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+__global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? 5 : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                        uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                        uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
                                                                        uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order,
-                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate) {
+                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate, uint32_t async_states) {
 	if (MODE != kSinglePass && gate != nullptr && *gate == 0) { return; }
+	__builtin_amdgcn_s_setprio(2); // over the persistent rowgroup search that may share the CU (see k_encode_fused)
 	if (MODE == kPack && totals[2] != 0) { // capacity overflow (reported through alpgpu_column_totals): no stream bytes, descriptors a decoder can follow
 		const uint64_t vo = v_first + static_cast<uint64_t>(blockIdx.x) * kFusedWaves + (threadIdx.x >> 6);
 		if ((threadIdx.x & 63) == 0 && vo < v_first + n_vectors_launch) { descs[vo] = empty_descriptor(); }
@@ -66,8 +69,15 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 	d.base                   = 0;
 	d.bw = d.e = d.f = d.lbw = 0;
 	d.exc_cnt = d.scheme = 0;
-	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane); // once, into registers
+	// once, into registers; async_states: published by the persistent search beside this kernel (see k_encode_fused)
+	bool                         state_ok = true;
+	const alpgpu_rowgroup_state  st  = (MODE == kSinglePass && async_states) ? load_rowgroup_state_async(rgs + (live ? v : v_first) / kRowgroup, lane, spin_limit >> 4, state_ok)
+	                                                                         : load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane);
 	const alpgpu_rowgroup_state* rgp = &st;
+	if (!state_ok) { // wave-uniform: a stall, like a look-back that gives up
+		if (lane == 0) { status_store(totals + 3, 1ull); }
+		return;
+	}
 	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
 	// that nothing but the ordered offset stands between the wait and the stores
 	const uint64_t base_p = totals[0], base_e = totals[1];
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 			const uint32_t rmask = bw_mask32(rbw);
 			const uint64_t lmask = (1ull << lbw) - 1ull;
 			d.bw = static_cast<uint8_t>(rbw), d.lbw = static_cast<uint8_t>(lbw);
-			const RdOrderView order = load_rd_order(rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, *rgp, lane);
+			const RdOrderView order = load_rd_order(rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, *rgp, lane, MODE == kSinglePass && async_states != 0);
 			uint32_t dict[8]; // read once: left inside the loop, the compiler re-reads the dictionary from memory for every value
 #pragma unroll
 			for (int dd = 0; dd < 8; ++dd) { dict[dd] = rgp->rd_dict[dd]; }
@@ -244,30 +254,45 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused_f32(const flo
 	if (lane == 0) { descs[v] = d; }
 }
 
-__global__ void k_fused_finish_f32(uint64_t* __restrict__ totals) {
-	totals[0] = totals[4];
-	totals[1] = totals[5];
-	if (totals[3] != 0) { totals[6] = 1; } // the gate of the recovery kernels (see k_fused_finish)
+// (see k_fused_finish in encode_kernels.hip)
+__global__ __launch_bounds__(256) void k_fused_finish_f32(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear) {
+	if (threadIdx.x == 0) {
+		totals[0] = totals[4];
+		totals[1] = totals[5];
+		if (totals[3] != 0) { totals[6] = 1; } // the gate of the recovery kernels
+	}
+	if (clear_rgs != nullptr) {
+		for (uint64_t i = threadIdx.x; i < n_clear; i += 256) { clear_rgs[i].pad = 0; }
+	}
 }
 
 int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                                  bool force_stall) {
+                                  bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		if (async_states && first == v_first && async_head != nullptr) {
+			if (hipStreamWaitEvent(stream, async_head, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		}
 		hipLaunchKernelGGL(k_encode_fused_f32<kSinglePass>, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, static_cast<const uint64_t*>(nullptr));
-		hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(1), 0, stream, col->d_totals);
+		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, static_cast<const uint64_t*>(nullptr), async_states ? 1u : 0u);
+		if (async_states && first + n_launch >= v_first + n_range) {
+			if (hipStreamWaitEvent(stream, async_join, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
+			hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(256), 0, stream, col->d_totals, col->d_rowgroups, col->n_rowgroups);
+		} else {
+			hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(256), 0, stream, col->d_totals, static_cast<alpgpu_rowgroup_state*>(nullptr), 0ull);
+		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall) {
+int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall,
+                            bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
 	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors, force_stall);
+	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors, force_stall, async_states, async_join, async_head);
 }
 
 // the two-pass form for float columns (gate: see launch_encode_vectors in encode_kernels.hip)
@@ -278,10 +303,10 @@ int launch_encode_vectors_f32(hipStream_t stream, const float* d_in, uint64_t n_
 	}
 	const dim3 grid(static_cast<unsigned>((n_vectors + kFusedWaves - 1) / kFusedWaves)), block(64 * kFusedWaves);
 	hipLaunchKernelGGL(k_encode_fused_f32<kAnalyze>, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
-	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate);
+	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate, 0u);
 	if (launch_scan_offsets(stream, col, n_vectors, d_workspace, true, gate) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
 	hipLaunchKernelGGL(k_encode_fused_f32<kPack>, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
-	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate);
+	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate, 0u);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

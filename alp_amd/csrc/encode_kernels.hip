@@ -25,6 +25,9 @@
 namespace alpgpu {
 
 constexpr int kScanTile = 1024;
+#ifndef ALPGPU_ENC_PRIO
+#define ALPGPU_ENC_PRIO 2
+#endif
 
 // ---- pass 1: analysis -----------------------------------------------------------------------------------
 // `gate` (all kernels of this form): nullptr, or a word that must be non-zero for the kernel to do anything — the recovery route
@@ -286,7 +289,10 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
                                                                    uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                    uint64_t* __restrict__ totals, uint64_t packed_capacity,
                                                                    uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch,
-                                                                   const uint16_t* __restrict__ rd_order, uint32_t spin_limit) {
+                                                                   const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states) {
+	// instruction-issue priority over the persistent rowgroup search that may share the CU (alpgpu_encode_f64 on a long column): the
+	// search then takes the issue slots this kernel leaves idle instead of competing for them (3.28 -> 3.14 ms per 1 Mi vectors)
+	__builtin_amdgcn_s_setprio(ALPGPU_ENC_PRIO);
 	__shared__ EncodeLds lds[kFusedWaves];
 	__shared__ uint64_t  s_size[kFusedWaves]; // per vector: (packed units << 31) | exception units
 	__shared__ uint64_t  s_excl;              // tile's exclusive prefix in the same packing, or ~0 on a stall
@@ -326,8 +332,18 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	const uint64_t v_read = live ? v : v_first;
 	x                     = load_vector(in, v_read, lane);
 	// the rowgroup's state, once, into registers (alp_device.hpp); its read is in flight together with the input's
-	const alpgpu_rowgroup_state  st  = load_rowgroup_state(rgs + v_read / kRowgroup, lane);
+	// async_states (alpgpu_encode_f64 on a long column): the states are being published by the persistent rowgroup search that runs
+	// beside this kernel on a second stream; a wavefront polls its rowgroup's tag (nearly always set long before: the search runs
+	// rowgroups ahead).  A state that does not arrive within the spin limit is a stall like a look-back that gives up: flag, no output
+	// of this tile, the recovery route (behind both streams) re-encodes.
+	bool                         state_ok = true;
+	const alpgpu_rowgroup_state  st  = async_states ? load_rowgroup_state_async(rgs + v_read / kRowgroup, lane, spin_limit >> 4, state_ok)
+	                                                : load_rowgroup_state(rgs + v_read / kRowgroup, lane);
 	const alpgpu_rowgroup_state* rgp = &st;
+	if (!state_ok) { // wave-uniform
+		if (lane == 0) { status_store(totals + 3, 1ull); }
+		return; // (the tile's other wavefronts and its successors run into their own spin limits: status words never appear)
+	}
 	if (live) {
 		PHASE_WAIT_MEM();
 		PHASE_MARK(0);
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 			}
 		} else {
 			RdEncoded R;
-			encode_rd_registers(x, *rgp, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr);
+			encode_rd_registers(x, *rgp, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, async_states != 0);
 			d.bw = rgp->rd_rbw, d.lbw = rgp->rd_lbw;
 			cnt = R.cnt;
 			ulonglong2*    lv    = reinterpret_cast<ulonglong2*>(L.vals);
@@ -519,10 +535,17 @@ extern "C" __attribute__((visibility("default"))) int alpgpu_debug_fused_phases(
 
 // publishes the running totals after a fused launch (single thread; keeps totals[0..1] stable while the launch runs) and
 // latches the stall flag into totals[6], the gate of the recovery kernels (k_scan_totals clears totals[3] on its way)
-__global__ void k_fused_finish(uint64_t* __restrict__ totals) {
-	totals[0] = totals[4];
-	totals[1] = totals[5];
-	if (totals[3] != 0) { totals[6] = 1; }
+// clear_rgs != nullptr (the last launch of an encode whose states were published beside it): the publishing tags (pad bytes) of the
+// n_clear states are reset, so that the column's states are the reference's bytes (256 threads stride over them)
+__global__ __launch_bounds__(256) void k_fused_finish(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear) {
+	if (threadIdx.x == 0) {
+		totals[0] = totals[4];
+		totals[1] = totals[5];
+		if (totals[3] != 0) { totals[6] = 1; }
+	}
+	if (clear_rgs != nullptr) {
+		for (uint64_t i = threadIdx.x; i < n_clear; i += 256) { clear_rgs[i].pad = 0; }
+	}
 }
 
 // ---- the single-pass encode's memory traffic and nothing else (alpgpu_debug_traffic_probe) ---------------------------------------
@@ -564,24 +587,36 @@ int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col) {
 }
 
 // vectors [v_first, v_first + n_range): continues the streams where d_totals[0..1] say the previous range ended
+// async_head / async_join (with async_states): the events behind the head of the search and behind the persistent rest; the stream
+// waits for the first in front of the first encode launch, for the second in front of the LAST finish kernel, which then clears the tags
 int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                              bool force_stall) {
+                              bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
 		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		if (async_states && first == v_first && async_head != nullptr) { // the head of the search (side stream) is what the first tiles need
+			if (hipStreamWaitEvent(stream, async_head, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		}
 		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit);
-		hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, stream, col->d_totals);
+		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u);
+		const bool last = first + n_launch >= v_first + n_range;
+		if (async_states && last) {
+			if (hipStreamWaitEvent(stream, async_join, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
+			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(256), 0, stream, col->d_totals, col->d_rowgroups, col->n_rowgroups);
+		} else {
+			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(256), 0, stream, col->d_totals, static_cast<alpgpu_rowgroup_state*>(nullptr), 0ull);
+		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall) {
+int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall,
+                        bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
 	if (launch_encode_reset_totals(stream, col) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
-	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors, force_stall);
+	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors, force_stall, async_states, async_join, async_head);
 }
 
 // the scan of the two-pass form (shared with the float column kernels): descriptor sizes -> offsets, totals, overflow flag

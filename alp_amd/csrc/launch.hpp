@@ -27,15 +27,21 @@ int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vect
                          uint64_t rg_count = 0);
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
+// the persistent, publishing form (runs beside the single-pass encode on a second stream) and the tag clean-up behind it
+int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
+                               uint64_t rg_count, int grid);
+int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
+                                   uint64_t rg_count, int grid);
 
 // encode_kernels.hip
 uint64_t encode_workspace_bytes(uint64_t n_vectors);
 // single pass (force_stall: debug, every look-back that has to wait gives up — exercises the recovery route)
-int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false);
+int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,
+                        bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
 // pieces of the above for a caller that interleaves other work: zero d_totals, then vector ranges in ascending order
 int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col);
 int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                              bool force_stall = false);
+                              bool force_stall = false, bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
 // two pass; gate = nullptr: unconditionally, else a device word that must be non-zero for the kernels to do anything (d_totals + 6)
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus, const uint64_t* gate = nullptr);
@@ -80,9 +86,10 @@ int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float
 int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
                              uint64_t rg_first = 0, uint64_t rg_count = 0);
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
-int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false);
+int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,
+                            bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
 int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                                  bool force_stall = false);
+                                  bool force_stall = false, bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
 int launch_encode_vectors_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, const uint64_t* gate = nullptr);
 int launch_pad_tail_f32(hipStream_t stream, float* d_in, uint64_t n_values);
 int launch_ffor_i32(hipStream_t stream, int n_cus, const int32_t* in, int32_t* packed, size_t stride, const uint8_t* bw, const int32_t* base, uint64_t n);

@@ -18,7 +18,9 @@ struct RdOrderView {
 };
 
 // one wavefront; order_rg = this rowgroup's table or nullptr
-__device__ __forceinline__ RdOrderView load_rd_order(const uint16_t* __restrict__ order_rg, const alpgpu_rowgroup_state& rg, int lane) {
+// coherent: the table was written by ANOTHER kernel that is still running (the persistent rowgroup search, released before the state
+// that announced it): agent-scope loads, which bypass this CU's L1 and this XCD's L2
+__device__ __forceinline__ RdOrderView load_rd_order(const uint16_t* __restrict__ order_rg, const alpgpu_rowgroup_state& rg, int lane, bool coherent = false) {
 	RdOrderView V;
 	V.ds    = rg.rd_dict_size;
 	V.count = 0;
@@ -28,11 +30,21 @@ __device__ __forceinline__ RdOrderView load_rd_order(const uint16_t* __restrict_
 	if (order_rg == nullptr) { return V; }
 	// count and entries are read together (the table's stride covers 1 + 288 entries whatever the count): one round trip
 	uint32_t  raw[5];
-	const int D = order_rg[0];
+	int D;
+	if (!coherent) { // wave-uniform
+		D = order_rg[0];
 #pragma unroll
-	for (int k = 0; k < 5; ++k) {
-		const int i = 64 * k + lane;
-		raw[k]      = i < 288 ? order_rg[1 + i] : 0xFFFFu;
+		for (int k = 0; k < 5; ++k) {
+			const int i = 64 * k + lane;
+			raw[k]      = i < 288 ? order_rg[1 + i] : 0xFFFFu;
+		}
+	} else {
+		D = __hip_atomic_load(order_rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+		for (int k = 0; k < 5; ++k) {
+			const int i = 64 * k + lane;
+			raw[k]      = i < 288 ? static_cast<uint32_t>(__hip_atomic_load(order_rg + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0xFFFFu;
+		}
 	}
 	if (D < V.ds || D > 288) { return V; }
 #pragma unroll

@@ -156,6 +156,12 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* ALPGPU_OPT_DEBUG_FORCE_STALL: 1 = every look-back of the single pass that has to wait gives up at once (tests of the
  * recovery route; the result is still a complete, byte-identical column). */
 #define ALPGPU_OPT_DEBUG_FORCE_STALL 4
+/* ALPGPU_OPT_ENCODE_ASYNC_INIT: 1 (default) = alpgpu_encode_f64 of a column of >= 1024 rowgroups runs the rowgroup search as a
+ * persistent kernel on a second, internal stream BESIDE the single-pass vector encode, which polls for each rowgroup's state (the two
+ * rejoin the context's stream before the call's last launches: callers still see one stream); 0 = search, then vectors, on one stream;
+ * 2 = beside the encode for float columns as well (measured slower there: the float tiles leave the search no room).  Results are
+ * identical in every mode. */
+#define ALPGPU_OPT_ENCODE_ASYNC_INIT 6
 /* ALPGPU_OPT_CONSUMER_PIPELINED: 1 = alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 / alpgpu_column_sum_f64 through the
  * persistent, software-pipelined kernel of alp_amd/csrc/consume_kernels.hip (one wavefront per vector, packed words, exception
  * records and descriptors prefetched into per-wavefront LDS rings by LDS-DMA) instead of the default (one short-lived workgroup per
