@@ -77,6 +77,9 @@ _sig("alpgpu_malloc_host", _int, _vp, C.POINTER(_vp), _sz)
 for _t in ("f64", "f32"):
     _sig("alpgpu_compress_host_" + _t, _int, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64))
     _sig("alpgpu_decompress_host_" + _t, _int, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64))
+for _t in ("f64", "f32"):
+    _sig("alpgpu_compress_host_multi_" + _t, _int, C.POINTER(_vp), _int, _vp, _u64, _vp, _u64, C.POINTER(_u64))
+    _sig("alpgpu_decompress_host_multi_" + _t, _int, C.POINTER(_vp), _int, _vp, _u64, _vp, _u64, C.POINTER(_u64))
 _sig("alpgpu_free_host", _int, _vp, _vp)
 _sig("alpgpu_memcpy_h2d_async", _int, _vp, _vp, _vp, _sz)
 _sig("alpgpu_debug_decode_probe_f64", _int, _vp, C.POINTER(CColumn), _vp)
@@ -215,6 +218,31 @@ class Context:
         _check(getattr(lib, "alpgpu_decompress_host_" + t)(self.h, _vp(blob_host.data_ptr()), blob_host.numel(), _vp(out_host.data_ptr()), out_host.numel(), C.byref(nv)),
                "alpgpu_decompress_host_" + t)
         return int(nv.value)
+
+    @staticmethod
+    def compress_host_multi(ctxs, x_host, blob_host=None):
+        """alpgpu_compress_host_multi_*: the host column cut into whole-rowgroup shards over the contexts (one per GPU, normally), one blob"""
+        import torch
+        t = "f64" if x_host.dtype == torch.float64 else "f32"
+        n = (x_host.numel() + 1023) // 1024
+        if blob_host is None:
+            cap = int(lib.alpgpu_blob_size(n, getattr(lib, "alpgpu_packed_capacity" + ("" if t == "f64" else "_f32"))(n), getattr(lib, "alpgpu_exc_capacity" + ("" if t == "f64" else "_f32"))(n)))
+            blob_host = torch.empty(cap, dtype=torch.uint8)
+        arr = (_vp * len(ctxs))(*[c.h for c in ctxs])
+        w = _u64()
+        _check(getattr(lib, "alpgpu_compress_host_multi_" + t)(arr, len(ctxs), _vp(x_host.data_ptr()), x_host.numel(), _vp(blob_host.data_ptr()), blob_host.numel(), C.byref(w)),
+               "alpgpu_compress_host_multi_" + t)
+        return blob_host[: w.value]
+
+    @staticmethod
+    def decompress_host_multi(ctxs, blob_host, out_host):
+        import torch
+        t = "f64" if out_host.dtype == torch.float64 else "f32"
+        arr = (_vp * len(ctxs))(*[c.h for c in ctxs])
+        nv = _u64()
+        _check(getattr(lib, "alpgpu_decompress_host_multi_" + t)(arr, len(ctxs), _vp(blob_host.data_ptr()), blob_host.numel(), _vp(out_host.data_ptr()), out_host.numel(), C.byref(nv)),
+               "alpgpu_decompress_host_multi_" + t)
+        return nv.value
 
     def decode_probe(self, col: "DeviceColumn", out):
         """decode_sum without the unpack arithmetic (include/alpgpu.h: alpgpu_debug_decode_probe_f64)"""

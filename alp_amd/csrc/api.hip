@@ -8,6 +8,7 @@
 #include <cstring>
 #include <atomic>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -1009,24 +1010,18 @@ struct HostPipe { // everything a call allocates, released on every return path
 	}
 };
 
+// One contiguous piece of a column (whole rowgroups; the column's last piece may end in an incomplete vector) through the pipeline of
+// ctx: rowgroup states -> out_rg, descriptors -> out_vec (offsets counted from the piece's own streams), packed stream -> out_str, exception
+// stream -> out_str + align8(packed bytes).  out_cap = bytes available at out_str.  *pb / *eb = the streams' sizes (also when they do not
+// fit: ALPGPU_ERR_CAPACITY, nothing usable written).  A whole column is one piece (compress_host); N pieces on N contexts are N of these
+// side by side (compress_host_multi).
 template <int VALUE_BYTES>
-int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+int compress_host_piece(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, uint8_t* blob_rg, uint8_t* blob_vec, uint8_t* blob_str, uint64_t out_cap,
+                        uint64_t* out_pb, uint64_t* out_eb) {
 	ALPGPU_CHECK_CTX(ctx);
-	if ((!h_in && n_values) || !h_blob) { return fail(ALPGPU_ERR_INVALID, "null input or blob"); }
-	const uint64_t n   = (n_values + 1023) / 1024;
-	const uint64_t nrg = (n + 99) / 100;
-	const uint64_t VB  = 1024ull * VALUE_BYTES;
-	// the blob must at least hold its fixed part before anything is produced
-	if (capacity < alpgpu_blob_size(n, 0, 0)) {
-		if (written) { // nothing has been encoded yet: the size that always suffices
-			*written = VALUE_BYTES == 8 ? alpgpu_blob_size(n, alpgpu_packed_capacity(n), alpgpu_exc_capacity(n)) : alpgpu_blob_size(n, alpgpu_packed_capacity_f32(n), alpgpu_exc_capacity_f32(n));
-		}
-		return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small for the column's descriptors");
-	}
-	uint8_t* blob     = static_cast<uint8_t*>(h_blob);
-	uint8_t* blob_rg  = blob + sizeof(alpgpu_blob_header);
-	uint8_t* blob_vec = blob_rg + 32ull * nrg;
-	uint8_t* blob_str = blob_vec + 32ull * n;
+	const uint64_t n        = (n_values + 1023) / 1024;
+	const uint64_t VB       = 1024ull * VALUE_BYTES;
+	const uint64_t capacity = out_cap; // of the streams
 	HostPipe P;
 	P.ctx   = ctx;
 	P.saved = ctx->stream;
@@ -1104,7 +1099,7 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 				ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
 				if (hipMalloc(&grown, want) != hipSuccess) {
 					(void)hipGetLastError();
-					if (written) { *written = alpgpu_blob_size(n, total_p + pb, want); }
+					*out_pb = total_p + pb, *out_eb = want;
 					return fail(ALPGPU_ERR_HIP, "the column's exception stream outgrew the pipeline's reserve and HBM has no room for a larger one (encode the column in pieces)");
 				}
 				if (total_e) { ALPGPU_HIP(hipMemcpy(grown, d_exc_all, total_e, hipMemcpyDeviceToDevice)); }
@@ -1119,8 +1114,7 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 			chunk_e.push_back(total_e);
 			// the packed stream's place in the blob is known chunk by chunk: it comes down at once, under the next chunk's copy up and
 			// encode; the exception stream's place depends on the packed stream's final size, so it collects in HBM
-			const uint64_t fixed = static_cast<uint64_t>(blob_str - blob);
-			if (fixed + total_p + pb <= capacity) {
+			if (total_p + pb <= capacity) {
 				if (pb) { ALPGPU_HIP(hipMemcpyAsync(blob_str + total_p, col[k].d_packed, pb, hipMemcpyDeviceToHost, P.stream[k])); }
 			} else {
 				blob_full = true; // keep counting: the caller learns the size it needs
@@ -1134,9 +1128,8 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 		ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
 		ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
 	}
-	const uint64_t need = alpgpu_blob_size(n, total_p, total_e);
-	if (written) { *written = need; }
-	if (capacity < need || blob_full) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
+	*out_pb = total_p, *out_eb = total_e;
+	if (blob_full || align8(total_p) + total_e > capacity) { return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small (size returned in *written)"); }
 	if (n) {
 		if (total_e) { ALPGPU_HIP(hipMemcpyAsync(blob_str + align8(total_p), d_exc_all, total_e, hipMemcpyDeviceToHost, P.stream[1])); }
 		// meanwhile: the chunks' descriptors become the column's (offsets continue where the chunks before ended)
@@ -1152,57 +1145,209 @@ int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_
 		ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
 		ALPGPU_HIP(hipStreamSynchronize(P.stream[1]));
 	}
-	alpgpu_blob_header h;
-	std::memset(&h, 0, sizeof(h));
-	std::memcpy(h.magic, "ALPGPU1", 8);
-	h.version = 1, h.header_bytes = sizeof(h), h.n_values = n_values, h.n_vectors = n, h.n_rowgroups = nrg;
-	h.packed_bytes = total_p, h.exc_bytes = total_e;
-	h.reserved     = VALUE_BYTES == 8 ? 0 : VALUE_BYTES;
-	std::memcpy(blob, &h, sizeof(h));
 	return ALPGPU_OK;
 }
 
 template <int VALUE_BYTES>
-int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
-	ALPGPU_CHECK_CTX(ctx);
-	if (!h_blob) { return fail(ALPGPU_ERR_INVALID, "null blob"); }
+uint64_t worst_case_blob(uint64_t n) {
+	return VALUE_BYTES == 8 ? alpgpu_blob_size(n, alpgpu_packed_capacity(n), alpgpu_exc_capacity(n)) : alpgpu_blob_size(n, alpgpu_packed_capacity_f32(n), alpgpu_exc_capacity_f32(n));
+}
+
+void write_blob_header(void* h_blob, uint64_t n_values, uint64_t n, uint64_t total_p, uint64_t total_e, int value_bytes) {
 	alpgpu_blob_header h;
-	if (int rc = validate_blob_header(h_blob, size, VALUE_BYTES, h)) { return rc; } // the vectors are validated chunk by chunk, while the chunk before is in flight
-	if (n_values) { *n_values = h.n_values; }
-	if (h.n_values > out_capacity_values) { return fail(ALPGPU_ERR_CAPACITY, "output buffer too small (value count returned in *n_values)"); }
-	if (!h_out && h.n_values) { return fail(ALPGPU_ERR_INVALID, "null output"); }
+	std::memset(&h, 0, sizeof(h));
+	std::memcpy(h.magic, "ALPGPU1", 8);
+	h.version = 1, h.header_bytes = sizeof(h), h.n_values = n_values, h.n_vectors = n, h.n_rowgroups = (n + 99) / 100;
+	h.packed_bytes = total_p, h.exc_bytes = total_e;
+	h.reserved     = value_bytes == 8 ? 0 : static_cast<uint64_t>(value_bytes);
+	std::memcpy(h_blob, &h, sizeof(h));
+}
+
+template <int VALUE_BYTES>
+int compress_host(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	ALPGPU_CHECK_CTX(ctx);
+	if ((!h_in && n_values) || !h_blob) { return fail(ALPGPU_ERR_INVALID, "null input or blob"); }
+	const uint64_t n   = (n_values + 1023) / 1024;
+	const uint64_t nrg = (n + 99) / 100;
+	// the blob must at least hold its fixed part before anything is produced
+	if (capacity < alpgpu_blob_size(n, 0, 0)) {
+		if (written) { *written = worst_case_blob<VALUE_BYTES>(n); } // nothing has been encoded yet: the size that always suffices
+		return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small for the column's descriptors");
+	}
+	uint8_t* blob     = static_cast<uint8_t*>(h_blob);
+	uint8_t* blob_rg  = blob + sizeof(alpgpu_blob_header);
+	uint8_t* blob_vec = blob_rg + 32ull * nrg;
+	uint8_t* blob_str = blob_vec + 32ull * n;
+	uint64_t pb = 0, eb = 0;
+	const int rc = compress_host_piece<VALUE_BYTES>(ctx, h_in, n_values, blob_rg, blob_vec, blob_str, capacity - static_cast<uint64_t>(blob_str - blob), &pb, &eb);
+	if (written) { *written = alpgpu_blob_size(n, pb, eb); }
+	if (rc != ALPGPU_OK) { return rc; }
+	write_blob_header(h_blob, n_values, n, pb, eb, VALUE_BYTES);
+	return ALPGPU_OK;
+}
+
+// whole-rowgroup shards of a column of n vectors: (first vector, vectors) of piece i of k — the rule of alp_amd/sharding.py: rowgroup_shard
+void shard_of(uint64_t n, int i, int k, uint64_t* first, uint64_t* count) {
+	const uint64_t nrg = (n + 99) / 100, base = nrg / k, extra = nrg % k;
+	const uint64_t first_rg = i * base + (static_cast<uint64_t>(i) < extra ? i : extra);
+	const uint64_t my_rg    = base + (static_cast<uint64_t>(i) < extra ? 1 : 0);
+	const uint64_t last     = (first_rg + my_rg) * 100 < n ? (first_rg + my_rg) * 100 : n;
+	*first                  = first_rg * 100;
+	*count                  = last > *first ? last - *first : 0;
+}
+
+// N contexts (normally one per GPU of the node; several on one device work too): the column is cut into N whole-rowgroup shards, shard i
+// runs through ctxs[i]'s two-stream pipeline on its own host thread — every GPU has its own PCIe link, so the shards travel side by side —
+// and the pieces are joined into ONE blob by the concat_shards rule (descriptor offsets shifted by the bytes of the shards before): byte
+// for byte the blob a single context writes for the column.  Rowgroup states and descriptors go straight to their places (their sizes
+// are known up front); a shard's streams first land in its own region of the caller's buffer (regions in proportion to the shards'
+// vector counts: the worst-case capacity always suffices) and are then moved together.
+template <int VALUE_BYTES>
+int compress_host_multi(alpgpu_ctx* const* ctxs, int k, const void* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	if (!ctxs || k < 1) { return fail(ALPGPU_ERR_INVALID, "no contexts"); }
+	for (int i = 0; i < k; ++i) {
+		if (!ctxs[i]) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+		for (int j = 0; j < i; ++j) {
+			if (ctxs[j] == ctxs[i]) { return fail(ALPGPU_ERR_INVALID, "the same context twice: one pipeline per context"); }
+		}
+	}
+	if (k == 1) { return compress_host<VALUE_BYTES>(ctxs[0], h_in, n_values, h_blob, capacity, written); }
+	if ((!h_in && n_values) || !h_blob) { return fail(ALPGPU_ERR_INVALID, "null input or blob"); }
+	const uint64_t n = (n_values + 1023) / 1024, nrg = (n + 99) / 100, VB = 1024ull * VALUE_BYTES;
+	const uint64_t fixed = alpgpu_blob_size(n, 0, 0);
+	if (capacity < fixed + 64ull * k) {
+		if (written) { *written = worst_case_blob<VALUE_BYTES>(n); }
+		return fail(ALPGPU_ERR_CAPACITY, "blob buffer too small for the column's descriptors");
+	}
+	uint8_t* blob     = static_cast<uint8_t*>(h_blob);
+	uint8_t* blob_rg  = blob + sizeof(alpgpu_blob_header);
+	uint8_t* blob_vec = blob_rg + 32ull * nrg;
+	uint8_t* blob_str = blob_vec + 32ull * n;
+	const uint64_t room = capacity - fixed;
+	std::vector<uint64_t> first(k), count(k), reg_off(k + 1), pb(k, 0), eb(k, 0);
+	std::vector<int>         rcs(k, ALPGPU_OK);
+	std::vector<std::string> errs(k);
+	for (int i = 0; i < k; ++i) { shard_of(n, i, k, &first[i], &count[i]); }
+	for (int i = 0; i <= k; ++i) { // region i = [reg_off[i], reg_off[i+1]) of the stream area, 8-byte aligned, in proportion to the vectors
+		const uint64_t upto = i < k ? first[i] : n;
+		reg_off[i]          = n ? (static_cast<uint64_t>(static_cast<unsigned __int128>(room) * upto / n) & ~7ull) : 0;
+	}
+	std::vector<std::thread> th;
+	for (int i = 0; i < k; ++i) {
+		th.emplace_back([&, i]() {
+			if (count[i] == 0) { return; }
+			const uint64_t v_end  = first[i] + count[i];
+			const uint64_t values = v_end * 1024 <= n_values ? count[i] * 1024 : n_values - first[i] * 1024;
+			rcs[i] = compress_host_piece<VALUE_BYTES>(ctxs[i], static_cast<const uint8_t*>(h_in) + first[i] * VB, values, blob_rg + 32ull * (first[i] / 100),
+			                                          blob_vec + 32ull * first[i], blob_str + reg_off[i], reg_off[i + 1] - reg_off[i], &pb[i], &eb[i]);
+			if (rcs[i] != ALPGPU_OK) { errs[i] = alpgpu_last_error(); }
+		});
+	}
+	for (auto& t : th) { t.join(); }
+	uint64_t total_p = 0, total_e = 0;
+	for (int i = 0; i < k; ++i) { total_p += pb[i], total_e += eb[i]; }
+	int bad = -1;
+	for (int i = 0; i < k; ++i) {
+		if (rcs[i] != ALPGPU_OK && (bad < 0 || rcs[bad] == ALPGPU_ERR_CAPACITY)) { bad = i; } // a failure other than "too small" is reported first
+	}
+	if (bad >= 0) {
+		if (written) { *written = rcs[bad] == ALPGPU_ERR_CAPACITY ? worst_case_blob<VALUE_BYTES>(n) : alpgpu_blob_size(n, total_p, total_e); }
+		return fail(rcs[bad], errs[bad].c_str());
+	}
+	if (written) { *written = alpgpu_blob_size(n, total_p, total_e); }
+	// exception streams aside, packed streams together (each moves towards the front: ascending order never overwrites what is still to move),
+	// exception streams behind them; then the descriptors' offsets continue where the shards before ended
+	std::vector<uint8_t> exc_all(total_e);
+	{
+		uint64_t e_at = 0;
+		for (int i = 0; i < k; ++i) {
+			if (eb[i]) { std::memcpy(exc_all.data() + e_at, blob_str + reg_off[i] + align8(pb[i]), eb[i]); }
+			e_at += eb[i];
+		}
+		uint64_t p_at = 0;
+		for (int i = 0; i < k; ++i) {
+			if (pb[i] && reg_off[i] != p_at) {
+				uint8_t *dst = blob_str + p_at, *src = blob_str + reg_off[i];
+				if (dst + pb[i] <= src && pb[i] >= (64ull << 20)) { // disjoint (the usual case from the second shard on): k threads copy a slice each
+					std::vector<std::thread> movers;
+					for (int t = 0; t < k; ++t) {
+						const uint64_t a = pb[i] * t / k, b = pb[i] * (t + 1) / k;
+						movers.emplace_back([=]() { std::memcpy(dst + a, src + a, b - a); });
+					}
+					for (auto& m : movers) { m.join(); }
+				} else {
+					std::memmove(dst, src, pb[i]);
+				}
+			}
+			p_at += pb[i];
+		}
+		if (total_p != align8(total_p)) { std::memset(blob_str + total_p, 0, align8(total_p) - total_p); }
+		if (total_e) { std::memcpy(blob_str + align8(total_p), exc_all.data(), total_e); }
+	}
+	{
+		uint64_t p_at = pb[0], e_at = eb[0];
+		for (int i = 1; i < k; ++i) {
+			for (uint64_t v = first[i]; v < first[i] + count[i]; ++v) {
+				alpgpu_vector_desc d;
+				std::memcpy(&d, blob_vec + 32ull * v, sizeof(d));
+				d.packed_off += p_at;
+				d.exc_off += e_at;
+				std::memcpy(blob_vec + 32ull * v, &d, sizeof(d));
+			}
+			p_at += pb[i], e_at += eb[i];
+		}
+	}
+	write_blob_header(h_blob, n_values, n, total_p, total_e, VALUE_BYTES);
+	return ALPGPU_OK;
+}
+
+// vectors [v_begin, v_end) (whole rowgroups, or to the column's end) of a blob whose header has passed validate_blob_header, decoded by
+// ctx's two-stream pipeline into h_out (the column's first value at h_out[0]).  Device buffers hold this range's records and bytes only;
+// descriptors keep their absolute stream offsets, so the streams' device pointers are biased by the range's first offsets.
+template <int VALUE_BYTES>
+int decompress_host_range(alpgpu_ctx* ctx, const void* h_blob, const alpgpu_blob_header& h, void* h_out, uint64_t v_begin, uint64_t v_end) {
+	ALPGPU_CHECK_CTX(ctx);
 	const uint64_t n = h.n_vectors;
-	if (n == 0) { return ALPGPU_OK; }
+	if (v_begin >= v_end) { return ALPGPU_OK; }
 	const uint64_t VB       = 1024ull * VALUE_BYTES;
 	const uint8_t* blob_rg  = static_cast<const uint8_t*>(h_blob) + sizeof(h);
 	const uint8_t* blob_vec = blob_rg + 32ull * h.n_rowgroups;
 	const uint8_t* blob_p   = blob_vec + 32ull * n;
 	const uint8_t* blob_e   = blob_p + align8(h.packed_bytes);
-	HostPipe P;
-	P.ctx   = ctx;
-	P.saved = ctx->stream;
-	alpgpu_column col;
-	std::memset(&col, 0, sizeof(col));
-	col.n_vectors = n, col.n_rowgroups = h.n_rowgroups, col.packed_capacity = h.packed_bytes, col.exc_capacity = h.exc_bytes;
-	col.packed_bytes_hint = h.packed_bytes, col.exc_bytes_hint = h.exc_bytes;
-	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_rowgroups), 32ull * h.n_rowgroups)) { return rc; }
-	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_vectors), 32ull * n)) { return rc; }
-	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_packed), h.packed_bytes + 128)) { return rc; }
-	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_exc), h.exc_bytes + 64)) { return rc; }
-	const uint64_t chunk = n < kHostChunkVectors ? n : kHostChunkVectors;
-	for (int k = 0; k < 2; ++k) {
-		ALPGPU_HIP(hipStreamCreateWithFlags(&P.stream[k], hipStreamNonBlocking));
-		if (hipMalloc(&P.d_in[k], chunk * VB) != hipSuccess) { return fail(ALPGPU_ERR_HIP, "hipMalloc (chunk buffer)", hipGetLastError()); }
-	}
-	// the descriptors and rowgroup states first (small), then stream by stream, chunk by chunk
-	ALPGPU_HIP(hipMemcpyAsync(col.d_rowgroups, blob_rg, 32ull * h.n_rowgroups, hipMemcpyHostToDevice, P.stream[0]));
-	ALPGPU_HIP(hipMemcpyAsync(col.d_vectors, blob_vec, 32ull * n, hipMemcpyHostToDevice, P.stream[0]));
-	ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
 	auto desc_at = [&](uint64_t v) {
 		alpgpu_vector_desc d;
 		std::memcpy(&d, blob_vec + 32ull * v, sizeof(d));
 		return d;
 	};
+	const uint64_t nr       = v_end - v_begin;
+	const uint64_t rg_begin = v_begin / 100, rg_end = (v_end + 99) / 100;
+	// the range's stream extents (offsets ascend with the vector index: checked chunk by chunk below)
+	const uint64_t P0 = desc_at(v_begin).packed_off, E0 = desc_at(v_begin).exc_off;
+	const uint64_t P1 = v_end < n ? desc_at(v_end).packed_off : h.packed_bytes;
+	const uint64_t E1 = v_end < n ? desc_at(v_end).exc_off : h.exc_bytes;
+	if (P0 > P1 || E0 > E1 || P1 > h.packed_bytes || E1 > h.exc_bytes) { return fail(ALPGPU_ERR_INVALID, "blob: stream offsets do not ascend with the vector index"); }
+	HostPipe P;
+	P.ctx   = ctx;
+	P.saved = ctx->stream;
+	alpgpu_column col;
+	std::memset(&col, 0, sizeof(col));
+	col.n_vectors = nr, col.n_rowgroups = rg_end - rg_begin, col.packed_capacity = h.packed_bytes, col.exc_capacity = h.exc_bytes;
+	uint8_t *d_p = nullptr, *d_e = nullptr;
+	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_rowgroups), 32ull * (rg_end - rg_begin))) { return rc; }
+	if (int rc = P.alloc(reinterpret_cast<void**>(&col.d_vectors), 32ull * nr)) { return rc; }
+	if (int rc = P.alloc(reinterpret_cast<void**>(&d_p), P1 - P0 + 128)) { return rc; }
+	if (int rc = P.alloc(reinterpret_cast<void**>(&d_e), E1 - E0 + 64)) { return rc; }
+	col.d_packed = reinterpret_cast<uint8_t*>(reinterpret_cast<uintptr_t>(d_p) - P0); // absolute offset o of the stream lives at d_p + (o - P0)
+	col.d_exc    = reinterpret_cast<uint8_t*>(reinterpret_cast<uintptr_t>(d_e) - E0);
+	const uint64_t chunk = nr < kHostChunkVectors ? nr : kHostChunkVectors;
+	for (int k = 0; k < 2; ++k) {
+		ALPGPU_HIP(hipStreamCreateWithFlags(&P.stream[k], hipStreamNonBlocking));
+		if (hipMalloc(&P.d_in[k], chunk * VB) != hipSuccess) { return fail(ALPGPU_ERR_HIP, "hipMalloc (chunk buffer)", hipGetLastError()); }
+	}
+	// the descriptors and rowgroup states first (small), then stream by stream, chunk by chunk
+	ALPGPU_HIP(hipMemcpyAsync(col.d_rowgroups, blob_rg + 32ull * rg_begin, 32ull * (rg_end - rg_begin), hipMemcpyHostToDevice, P.stream[0]));
+	ALPGPU_HIP(hipMemcpyAsync(col.d_vectors, blob_vec + 32ull * v_begin, 32ull * nr, hipMemcpyHostToDevice, P.stream[0]));
+	ALPGPU_HIP(hipStreamSynchronize(P.stream[0]));
 	// is the output page-locked memory the device can address?
 	uint8_t* out_dev = nullptr;
 	{
@@ -1214,7 +1359,7 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 			(void)hipGetLastError(); // pageable memory: not an error
 		}
 	}
-	const uint64_t n_chunks = (n + chunk - 1) / chunk;
+	const uint64_t n_chunks = (nr + chunk - 1) / chunk;
 	// Validation (every descriptor, every exception position: a pass over ~15 % of the blob) runs ahead of the pipeline on a few host
 	// threads, chunk by chunk; nothing of a chunk is launched before that chunk has passed.  A worker that finds a fault stops at it;
 	// the main thread validates that chunk again itself, for the error code and text.
@@ -1237,18 +1382,18 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 		bool     ok;
 	};
 	auto window_of = [&](uint64_t c) {
-		const uint64_t v0 = c * chunk, v1 = n - v0 < chunk ? n : v0 + chunk;
+		const uint64_t v0 = v_begin + c * chunk, v1 = v_end - v0 < chunk ? v_end : v0 + chunk;
 		Window W;
 		W.w[0] = desc_at(v0).packed_off, W.w[2] = desc_at(v0).exc_off;
 		W.w[1] = v1 < n ? desc_at(v1).packed_off : h.packed_bytes;
 		W.w[3] = v1 < n ? desc_at(v1).exc_off : h.exc_bytes;
-		W.ok   = W.w[0] <= W.w[1] && W.w[2] <= W.w[3] && W.w[1] <= h.packed_bytes && W.w[3] <= h.exc_bytes;
+		W.ok   = P0 <= W.w[0] && W.w[0] <= W.w[1] && W.w[1] <= P1 && E0 <= W.w[2] && W.w[2] <= W.w[3] && W.w[3] <= E1;
 		return W;
 	};
 	for (unsigned w = 0; w < n_workers; ++w) {
 		workers.emplace_back([&, w]() {
 			for (uint64_t c = w; c < n_chunks; c += n_workers) {
-				const uint64_t b = c * chunk, e = n - b < chunk ? n : b + chunk;
+				const uint64_t b = v_begin + c * chunk, e = v_end - b < chunk ? v_end : b + chunk;
 				const Window   W = window_of(c);
 				const int      rc = W.ok ? validate_blob_vectors(h_blob, h, VALUE_BYTES, b, e, W.w) : ALPGPU_ERR_INVALID;
 				verdict[c].store(rc == ALPGPU_OK ? 1 : 2, std::memory_order_release);
@@ -1258,8 +1403,8 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 	}
 	for (uint64_t i = 0; i < n_chunks; ++i) {
 		const int      k   = static_cast<int>(i & 1);
-		const uint64_t v0  = i * chunk;
-		const uint64_t cnt = n - v0 < chunk ? n - v0 : chunk;
+		const uint64_t v0  = v_begin + i * chunk;
+		const uint64_t cnt = v_end - v0 < chunk ? v_end - v0 : chunk;
 		int            vd;
 		while ((vd = verdict[i].load(std::memory_order_acquire)) == 0) { std::this_thread::yield(); }
 		const Window W = window_of(i);
@@ -1267,13 +1412,13 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 		if (vd != 1) { return validate_blob_vectors(h_blob, h, VALUE_BYTES, v0, v0 + cnt, W.w); }
 		// the chunk's bytes: its ranges end where the next chunk's begin, and every record of the chunk lies inside them (validated above)
 		const uint64_t p0 = W.w[0], p1 = W.w[1], e0 = W.w[2], e1 = W.w[3];
-		if (p1 > p0) { ALPGPU_HIP(hipMemcpyAsync(col.d_packed + p0, blob_p + p0, p1 - p0, hipMemcpyHostToDevice, P.stream[k])); }
-		if (e1 > e0) { ALPGPU_HIP(hipMemcpyAsync(col.d_exc + e0, blob_e + e0, e1 - e0, hipMemcpyHostToDevice, P.stream[k])); }
+		if (p1 > p0) { ALPGPU_HIP(hipMemcpyAsync(d_p + (p0 - P0), blob_p + p0, p1 - p0, hipMemcpyHostToDevice, P.stream[k])); }
+		if (e1 > e0) { ALPGPU_HIP(hipMemcpyAsync(d_e + (e0 - E0), blob_e + e0, e1 - e0, hipMemcpyHostToDevice, P.stream[k])); }
 		alpgpu_column view = col; // descriptors hold absolute stream offsets: a view of whole rowgroups decodes on its own
 		view.n_vectors     = cnt;
 		view.n_rowgroups   = (cnt + 99) / 100;
-		view.d_vectors     = col.d_vectors + v0;
-		view.d_rowgroups   = col.d_rowgroups + v0 / 100;
+		view.d_vectors     = col.d_vectors + (v0 - v_begin);
+		view.d_rowgroups   = col.d_rowgroups + (v0 / 100 - rg_begin);
 		view.packed_bytes_hint = p1 - p0, view.exc_bytes_hint = e1 - e0;
 		ctx->stream        = P.stream[k];
 		const uint64_t val = (v0 + cnt) * 1024 <= h.n_values ? cnt * 1024 : h.n_values - v0 * 1024;
@@ -1292,6 +1437,50 @@ int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_
 	return ALPGPU_OK;
 }
 
+// k = 1: the whole column on ctxs[0].  k > 1: whole-rowgroup shards of the column (shard_of), shard i decoded by ctxs[i] on its own host thread
+// into its part of h_out — the mirror of compress_host_multi.
+template <int VALUE_BYTES>
+int decompress_host_multi(alpgpu_ctx* const* ctxs, int k, const void* h_blob, uint64_t size, void* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
+	if (!ctxs || k < 1) { return fail(ALPGPU_ERR_INVALID, "no contexts"); }
+	for (int i = 0; i < k; ++i) {
+		if (!ctxs[i]) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+		for (int j = 0; j < i; ++j) {
+			if (ctxs[j] == ctxs[i]) { return fail(ALPGPU_ERR_INVALID, "the same context twice: one pipeline per context"); }
+		}
+	}
+	if (!h_blob) { return fail(ALPGPU_ERR_INVALID, "null blob"); }
+	alpgpu_blob_header h;
+	if (int rc = validate_blob_header(h_blob, size, VALUE_BYTES, h)) { return rc; } // the vectors are validated chunk by chunk, while the chunk before is in flight
+	if (n_values) { *n_values = h.n_values; }
+	if (h.n_values > out_capacity_values) { return fail(ALPGPU_ERR_CAPACITY, "output buffer too small (value count returned in *n_values)"); }
+	if (!h_out && h.n_values) { return fail(ALPGPU_ERR_INVALID, "null output"); }
+	if (h.n_vectors == 0) { return ALPGPU_OK; }
+	if (k == 1) { return decompress_host_range<VALUE_BYTES>(ctxs[0], h_blob, h, h_out, 0, h.n_vectors); }
+	std::vector<int>         rcs(k, ALPGPU_OK);
+	std::vector<std::string> errs(k);
+	std::vector<std::thread> th;
+	for (int i = 0; i < k; ++i) {
+		th.emplace_back([&, i]() {
+			uint64_t first = 0, count = 0;
+			shard_of(h.n_vectors, i, k, &first, &count);
+			rcs[i] = decompress_host_range<VALUE_BYTES>(ctxs[i], h_blob, h, h_out, first, first + count);
+			if (rcs[i] != ALPGPU_OK) { errs[i] = alpgpu_last_error(); }
+		});
+	}
+	for (auto& t : th) { t.join(); }
+	for (int i = 0; i < k; ++i) {
+		if (rcs[i] != ALPGPU_OK) { return fail(rcs[i], errs[i].c_str()); }
+	}
+	return ALPGPU_OK;
+}
+
+template <int VALUE_BYTES>
+int decompress_host(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, void* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
+	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
+	alpgpu_ctx* one[1] = {ctx};
+	return decompress_host_multi<VALUE_BYTES>(one, 1, h_blob, size, h_out, out_capacity_values, n_values);
+}
+
 } // namespace
 } // extern "C++"
 
@@ -1306,6 +1495,20 @@ int alpgpu_decompress_host_f64(alpgpu_ctx* ctx, const void* h_blob, uint64_t siz
 }
 int alpgpu_decompress_host_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, float* h_out, uint64_t out_capacity_values, uint64_t* n_values) {
 	return decompress_host<4>(ctx, h_blob, size, h_out, out_capacity_values, n_values);
+}
+int alpgpu_compress_host_multi_f64(alpgpu_ctx* const* ctxs, int n_ctx, const double* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	return compress_host_multi<8>(ctxs, n_ctx, h_in, n_values, h_blob, capacity, written);
+}
+int alpgpu_compress_host_multi_f32(alpgpu_ctx* const* ctxs, int n_ctx, const float* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written) {
+	return compress_host_multi<4>(ctxs, n_ctx, h_in, n_values, h_blob, capacity, written);
+}
+int alpgpu_decompress_host_multi_f64(alpgpu_ctx* const* ctxs, int n_ctx, const void* h_blob, uint64_t size, double* h_out, uint64_t out_capacity_values,
+                                     uint64_t* n_values) {
+	return decompress_host_multi<8>(ctxs, n_ctx, h_blob, size, h_out, out_capacity_values, n_values);
+}
+int alpgpu_decompress_host_multi_f32(alpgpu_ctx* const* ctxs, int n_ctx, const void* h_blob, uint64_t size, float* h_out, uint64_t out_capacity_values,
+                                     uint64_t* n_values) {
+	return decompress_host_multi<4>(ctxs, n_ctx, h_blob, size, h_out, out_capacity_values, n_values);
 }
 
 } // extern "C"

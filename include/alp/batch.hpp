@@ -17,6 +17,8 @@
 #define ALP_BATCH_HPP
 #include <cstring>
 #include <stdexcept>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "alp/config.hpp"
@@ -251,8 +253,72 @@ struct rowgroup {
 // rowgroups go up on one stream while the previous chunk is encoded on another; ~35 GB/s of doubles from page-locked memory, ~10 GB/s
 // from pageable memory like the std::vectors used here; callers that care hand page-locked buffers to the C functions directly).
 // This is what replaces the reference's caller loop (publication/source_code/bench_compression_ratio/alp.cpp:198-229) as a whole.
+// A pool of contexts for a list of devices (one each; the same device may be listed more than once — e.g. in tests on a one-GPU box):
+// what alp::gpu::column<PT>::compress / decompress over a device list run on.  Contexts live until the process ends.
+inline std::vector<alpgpu_ctx*> contexts_for(const std::vector<int>& devices) {
+	static std::mutex                                   mu;
+	static std::vector<std::pair<int, alpgpu_ctx*>>     pool; // (device, context), in creation order
+	std::lock_guard<std::mutex>                         lock(mu);
+	std::vector<alpgpu_ctx*>                            out;
+	std::vector<bool>                                   taken(pool.size(), false);
+	for (int dev : devices) {
+		alpgpu_ctx* c = nullptr;
+		for (size_t i = 0; i < pool.size(); ++i) {
+			if (!taken[i] && pool[i].first == dev) {
+				taken[i] = true;
+				c        = pool[i].second;
+				break;
+			}
+		}
+		if (!c) {
+			check(alpgpu_ctx_create(dev, &c), "alpgpu_ctx_create");
+			pool.emplace_back(dev, c);
+			taken.push_back(true);
+		}
+		out.push_back(c);
+	}
+	return out;
+}
+
 template <class PT>
 struct column {
+	// The column cut into whole-rowgroup shards over `devices` (alpgpu_compress_host_multi_*): every GPU of the node works on its shard
+	// over its own PCIe link, the result is the one-device blob byte for byte.
+	static std::vector<uint8_t> compress(const PT* values, size_t n_values, const std::vector<int>& devices) {
+		const std::vector<alpgpu_ctx*> ctxs = contexts_for(devices);
+		const uint64_t                 n    = (n_values + config::VECTOR_SIZE - 1) / config::VECTOR_SIZE;
+		uint64_t                       cap  = alpgpu_blob_size(n, n * config::VECTOR_SIZE * sizeof(PT) + 1024 * ctxs.size(), 0);
+		std::vector<uint8_t>           blob;
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			blob.resize(cap);
+			uint64_t  written = 0;
+			const int rc = sizeof(PT) == 8 ? alpgpu_compress_host_multi_f64(ctxs.data(), static_cast<int>(ctxs.size()), reinterpret_cast<const double*>(values), n_values, blob.data(), cap, &written)
+			                               : alpgpu_compress_host_multi_f32(ctxs.data(), static_cast<int>(ctxs.size()), reinterpret_cast<const float*>(values), n_values, blob.data(), cap, &written);
+			if (rc == ALPGPU_ERR_CAPACITY && attempt == 0 && written > cap) {
+				cap = written;
+				continue;
+			}
+			check(rc, "alpgpu_compress_host_multi");
+			blob.resize(written);
+			break;
+		}
+		return blob;
+	}
+	static std::vector<PT> decompress(const uint8_t* blob, size_t size, const std::vector<int>& devices) {
+		const std::vector<alpgpu_ctx*> ctxs = contexts_for(devices);
+		uint64_t  n_values = 0;
+		const int probe    = sizeof(PT) == 8 ? alpgpu_decompress_host_multi_f64(ctxs.data(), 1, blob, size, nullptr, 0, &n_values)
+		                                     : alpgpu_decompress_host_multi_f32(ctxs.data(), 1, blob, size, nullptr, 0, &n_values);
+		if (probe != ALPGPU_OK && probe != ALPGPU_ERR_CAPACITY) { check(probe, "alpgpu_decompress_host_multi (header)"); }
+		std::vector<PT> out(n_values);
+		if (n_values == 0) { return out; }
+		if constexpr (sizeof(PT) == 8) {
+			check(alpgpu_decompress_host_multi_f64(ctxs.data(), static_cast<int>(ctxs.size()), blob, size, reinterpret_cast<double*>(out.data()), out.size(), &n_values), "alpgpu_decompress_host_multi_f64");
+		} else {
+			check(alpgpu_decompress_host_multi_f32(ctxs.data(), static_cast<int>(ctxs.size()), blob, size, reinterpret_cast<float*>(out.data()), out.size(), &n_values), "alpgpu_decompress_host_multi_f32");
+		}
+		return out;
+	}
 	static std::vector<uint8_t> compress(const PT* values, size_t n_values) {
 		const uint64_t n = (n_values + config::VECTOR_SIZE - 1) / config::VECTOR_SIZE;
 		// a compressed column is almost never larger than the column: start there, and take the size the library asks for otherwise

@@ -191,6 +191,22 @@ int alpgpu_compress_host_f32(alpgpu_ctx* ctx, const float* h_in, uint64_t n_valu
 int alpgpu_decompress_host_f64(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, double* h_out, uint64_t out_capacity_values, uint64_t* n_values);
 int alpgpu_decompress_host_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, float* h_out, uint64_t out_capacity_values, uint64_t* n_values);
 
+/* The same over SEVERAL contexts — normally one per GPU of the node, each with its own PCIe link (several contexts on one device work
+ * too): the column is cut into n_ctx contiguous whole-rowgroup shards (sizes differ by at most one rowgroup, the rule of
+ * alp_amd/sharding.py: rowgroup_shard), shard i runs through ctxs[i]'s pipeline on its own host thread, and the pieces become ONE blob —
+ * byte for byte the blob alpgpu_compress_host_* writes with a single context (the descriptors' stream offsets continue where the
+ * shards before ended: no collective, a host-side concatenation is the only exchange).  This is how a C / C++ caller that holds a
+ * host column (publication/source_code/bench_compression_ratio/alp.cpp:198-229; the worker loop of
+ * publication/source_code/bench_end_to_end/src/benchmarks/alp/run_query.cpp:233-305) uses all GPUs of a node from one process.
+ * Capacity and *written as above (regions of the caller's buffer serve as the shards' staging: the worst-case size always suffices).
+ * A context must not be used by anything else during the call; ctxs[i] must be distinct. */
+int alpgpu_compress_host_multi_f64(alpgpu_ctx* const* ctxs, int n_ctx, const double* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);
+int alpgpu_compress_host_multi_f32(alpgpu_ctx* const* ctxs, int n_ctx, const float* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);
+int alpgpu_decompress_host_multi_f64(alpgpu_ctx* const* ctxs, int n_ctx, const void* h_blob, uint64_t size, double* h_out, uint64_t out_capacity_values,
+                                     uint64_t* n_values);
+int alpgpu_decompress_host_multi_f32(alpgpu_ctx* const* ctxs, int n_ctx, const void* h_blob, uint64_t size, float* h_out, uint64_t out_capacity_values,
+                                     uint64_t* n_values);
+
 /* Measurement aid, not part of the codec: launches the memory traffic of the single-pass encode without its arithmetic — the same
  * launch shape, every 8 KiB vector of d_in read once, write_bytes_per_vector (a multiple of 16, <= 8192) written per vector at
  * d_out + v * write_bytes_per_vector, stored data depending on all loaded data.  bench.py times it to put a measured ceiling for the

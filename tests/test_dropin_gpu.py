@@ -58,3 +58,14 @@ def test_rowgroup_batched_cpp_surface_matches_the_per_vector_functions(tmp_path)
     p = subprocess.run([str(exe), "2"], capture_output=True, text=True, timeout=900)
     print(p.stdout)
     assert p.returncode == 0 and "batch_test: 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_one_host_column_over_several_contexts(tmp_path):
+    """include/alp/batch.hpp: alp::gpu::column<PT> over a device list = alpgpu_compress_host_multi_*: whole-rowgroup shards, one host thread and one
+    pipeline per context, ONE blob — byte for byte the single-context blob.  Three contexts on this box's one GPU stand in for three GPUs."""
+    exe = tmp_path / "multi_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", f"-I{ROOT}/include", "-o", str(exe), f"{ROOT}/tests/cpp/multi_test.cpp",
+                           f"-L{ROOT}/alp_amd", "-lalpgpu", f"-Wl,-rpath,{ROOT}/alp_amd"])
+    p = subprocess.run([str(exe), "0", "0", "0"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    assert p.returncode == 0 and "multi_test: 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]

@@ -111,3 +111,26 @@ def test_a_record_outside_its_chunks_stream_range_is_refused():
     assert n_values == x.numel()
     with pytest.raises(capi.AlpGpuError, match="chunk"):
         ctx.decompress_host(bad, out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_several_contexts_write_the_one_context_blob(dtype):
+    """alpgpu_compress_host_multi_* / alpgpu_decompress_host_multi_* through the C ABI: 1, 2, 3 and 5 contexts (all on GPU 0 here), pinned and pageable"""
+    ctxs = [capi.Context(0) for _ in range(5)]
+    n_values = 2 * CHUNK * 1024 + 7 * 1024 + 99
+    x = column(n_values, dtype, seed=31)
+    want = ctxs[0].compress_host(x)
+    for k in (1, 2, 3, 5):
+        blob = capi.Context.compress_host_multi(ctxs[:k], x)
+        assert torch.equal(blob, want), f"{k} contexts"
+        out = torch.full((n_values + 3,), 9, dtype=dtype, pin_memory=(k % 2 == 0))
+        assert capi.Context.decompress_host_multi(ctxs[:k], blob, out) == n_values
+        it = torch.int64 if dtype == torch.float64 else torch.int32
+        assert torch.equal(out[:n_values].view(it), x.view(it)) and bool((out[n_values:] == 9).all())
+    # a corrupt descriptor in the LAST shard is found by the context that owns it
+    nrg = ((n_values + 1023) // 1024 + 99) // 100
+    bad = want.clone()
+    n = (n_values + 1023) // 1024
+    bad.numpy()[64 + 32 * nrg: 64 + 32 * nrg + 32 * n].view(capi.VECTOR_DTYPE)[n - 5]["bw"] = 77
+    with pytest.raises(capi.AlpGpuError):
+        capi.Context.decompress_host_multi(ctxs[:3], bad, torch.empty(n_values, dtype=dtype))
