@@ -113,6 +113,8 @@ _sig("alpgpu_patch_f64", _int, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
 _sig("alpgpu_encode_simdized_f64", _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _u64)
 _sig("alpgpu_encode_values_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _u64)
 _sig("alpgpu_analyze_ffor_i64", _int, _vp, _vp, _vp, _vp, _u64)
+_sig("alpgpu_encode_value_f64", _int, _vp, _vp, _vp, C.c_uint8, C.c_uint8, _int, _u64)
+_sig("alpgpu_encode_value_f32", _int, _vp, _vp, _vp, C.c_uint8, C.c_uint8, _int, _u64)
 _sig("alpgpu_rd_encode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u64)
 _sig("alpgpu_rd_decode_vectors_f64", _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _u64)
 # single precision (same argument shapes; 32-bit words)
@@ -376,6 +378,15 @@ class Context:
     def encode_values(self, x, states, state_idx, exc, pos, cnt, enc, fac, exp):
         _check(lib.alpgpu_encode_values_f64(self.h, self._p(x), self._p(states), self._p(state_idx), self._p(exc), self._p(pos), exc.shape[1],
                                             self._p(cnt), self._p(enc), self._p(fac), self._p(exp), x.shape[0]), "alpgpu_encode_values_f64")
+
+    def encode_value(self, x, fac: int, exp: int, safe: bool = True):
+        """alpgpu_encode_value_f64 / _f32 on a 1-d device tensor: the encoded integers (int64 / int32)"""
+        import torch
+        f64 = x.dtype == torch.float64
+        out = torch.empty(x.numel(), dtype=torch.int64 if f64 else torch.int32, device=x.device)
+        fn = lib.alpgpu_encode_value_f64 if f64 else lib.alpgpu_encode_value_f32
+        _check(fn(self.h, self._p(x), self._p(out), fac, exp, 1 if safe else 0, x.numel()), "alpgpu_encode_value")
+        return out
 
     def analyze_ffor(self, enc, bw, base):
         _check(lib.alpgpu_analyze_ffor_i64(self.h, self._p(enc), self._p(bw), self._p(base), enc.shape[0]), "alpgpu_analyze_ffor_i64")

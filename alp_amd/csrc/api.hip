@@ -586,6 +586,21 @@ int alpgpu_encode_values_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_r
 	            alpgpu::launch_encode_values(ctx->stream, ctx->n_cus, d_in, d_states, d_state_idx, d_exc, d_pos, exc_stride, d_cnt, d_enc,
 	                                         d_fac, d_exp, n_vectors));
 }
+int alpgpu_encode_value_f64(alpgpu_ctx* ctx, const double* d_in, int64_t* d_enc, uint8_t fac, uint8_t exp, int safe, uint64_t n_values) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (n_values && (!d_in || !d_enc)) { return fail(ALPGPU_ERR_INVALID, "null pointer argument"); }
+	if (exp > 18 || fac > exp) { return fail(ALPGPU_ERR_INVALID, "factor / exponent out of range (0 <= factor <= exponent <= 18)"); }
+	if (alpgpu::launch_encode_value(ctx->stream, d_in, d_enc, fac, exp, safe, n_values) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "kernel launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+int alpgpu_encode_value_f32(alpgpu_ctx* ctx, const float* d_in, int32_t* d_enc, uint8_t fac, uint8_t exp, int safe, uint64_t n_values) {
+	(void)safe; // the reference's float SAFE branch does not exist as built (include/alpgpu.h, single precision)
+	ALPGPU_CHECK_CTX(ctx);
+	if (n_values && (!d_in || !d_enc)) { return fail(ALPGPU_ERR_INVALID, "null pointer argument"); }
+	if (exp > 10 || fac > exp) { return fail(ALPGPU_ERR_INVALID, "factor / exponent out of range (0 <= factor <= exponent <= 10)"); }
+	if (alpgpu::launch_encode_value_f32(ctx->stream, d_in, d_enc, fac, exp, n_values) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "kernel launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
 int alpgpu_analyze_ffor_i64(alpgpu_ctx* ctx, const int64_t* d_enc, uint8_t* d_bw, int64_t* d_base, uint64_t n_vectors) {
 	ALPGPU_PRIM(d_enc && d_bw && d_base, alpgpu::launch_analyze_ffor(ctx->stream, ctx->n_cus, d_enc, d_bw, d_base, n_vectors));
 }

@@ -70,6 +70,8 @@ int launch_patch(hipStream_t stream, int n_cus, double* out, const double* exc, 
 int launch_analyze_ffor(hipStream_t stream, int n_cus, const int64_t* enc, uint8_t* bw, int64_t* base, uint64_t n);
 int launch_encode_simdized(hipStream_t stream, int n_cus, const double* in, double* exc, uint16_t* pos, size_t stride, uint16_t* cnt,
                            int64_t* enc, const uint8_t* fac, const uint8_t* exp, uint64_t n);
+int launch_encode_value(hipStream_t stream, const double* in, int64_t* enc, int fac, int exp, int safe, uint64_t n);
+int launch_encode_value_f32(hipStream_t stream, const float* in, int32_t* enc, int fac, int exp, uint64_t n);
 int launch_decode_probe(hipStream_t stream, const alpgpu_column* col, double* d_sums);
 int launch_traffic_probe(hipStream_t stream, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes);
 int launch_encode_values(hipStream_t stream, int n_cus, const double* in, const alpgpu_rowgroup_state* states, const uint32_t* idx,

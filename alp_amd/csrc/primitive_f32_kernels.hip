@@ -301,6 +301,19 @@ int launch_falp_f32(hipStream_t stream, int n_cus, const int32_t* packed, size_t
                     const uint8_t* fac, const uint8_t* exp, uint64_t n) {
 	PRIM_LAUNCH((k_unffor_i32<1>), packed, stride, static_cast<void*>(out), bw, base, fac, exp, n);
 }
+// alp::encoder<float>::encode_value<SAFE> on n values with one (factor, exponent) pair (as built by the reference's compiler the SAFE branch
+// does not exist for float: alp_device_f32.hpp)
+__global__ __launch_bounds__(256) void k_encode_value_f32(const float* __restrict__ in, int32_t* __restrict__ enc, int fac, int exp, uint64_t n) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+	if (i >= n) { return; }
+	enc[i] = encode_value_f32(in[i], kExpArrF[exp], kFracArrF[fac]);
+}
+int launch_encode_value_f32(hipStream_t stream, const float* in, int32_t* enc, int fac, int exp, uint64_t n) {
+	if (n == 0) { return ALPGPU_OK; }
+	hipLaunchKernelGGL(k_encode_value_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, in, enc, fac, exp, n);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
 int launch_decode_values_f32(hipStream_t stream, int n_cus, const int32_t* enc, float* out, const uint8_t* fac, const uint8_t* exp, uint64_t n) {
 	PRIM_LAUNCH(k_decode_values_f32, enc, out, fac, exp, n);
 }

@@ -423,6 +423,19 @@ int launch_ffor_u8(hipStream_t stream, int n_cus, const uint8_t* in, uint8_t* pa
 int launch_unffor_u8(hipStream_t stream, int n_cus, const uint8_t* packed, size_t stride, uint8_t* out, const uint8_t* bw, const uint8_t* base, uint64_t n) {
 	PRIM_LAUNCH(k_unffor_u8, packed, stride, out, bw, base, n);
 }
+// alp::encoder<double>::encode_value<SAFE> (include/alp/encoder.hpp:81-89) on n VALUES with one (factor, exponent) pair: the scalar helper of
+// the reference's public header, offered for source compatibility (include/alp/encoder.hpp here) — element-wise, one value per thread
+__global__ __launch_bounds__(256) void k_encode_value(const double* __restrict__ in, int64_t* __restrict__ enc, int fac, int exp, int safe, uint64_t n) {
+	const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+	if (i >= n) { return; }
+	enc[i] = safe ? encode_value_safe(in[i], kExpArr[exp], kFracArr[fac]) : encode_value_unsafe(in[i], kExpArr[exp], kFracArr[fac]);
+}
+int launch_encode_value(hipStream_t stream, const double* in, int64_t* enc, int fac, int exp, int safe, uint64_t n) {
+	if (n == 0) { return ALPGPU_OK; }
+	hipLaunchKernelGGL(k_encode_value, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, in, enc, fac, exp, safe, n);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
 int launch_decode_values(hipStream_t stream, int n_cus, const int64_t* enc, double* out, const uint8_t* fac, const uint8_t* exp,
                          uint64_t n) {
 	PRIM_LAUNCH(k_decode_values, enc, out, fac, exp, n);

@@ -144,10 +144,21 @@ struct encoder {
 		fetch_encoded(s, exceptions, exceptions_positions, exceptions_count, encoded_integers);
 	}
 
-	// encoder.hpp:75-106 upstream.  encode_value<SAFE> (one value -> its encoded integer) is an internal of the reference's encoder
-	// that no caller outside include/alp/ uses; its arithmetic lives only in the device code (alp_amd/csrc/alp_device.hpp,
-	// alp_device_f32.hpp) and is not offered per value.  The two helpers below are plain predicates / bit counting, kept for
-	// source compatibility:
+	//! encoder.hpp:81-89: one value -> its encoded integer.  Like decode_value in alp/decoder.hpp it goes through the device (one value up, one
+	//! integer down: a compatibility helper, not a fast path); SAFE = the sampling form with the ENCODING_UPPER_LIMIT sentinel.
+	template <bool SAFE = true>
+	static inline ST encode_value(const PT value, const uint8_t factor_idx, const uint8_t exponent_idx) {
+		auto& s = gpu::tls();
+		gpu::h2d(s.at<PT>(s.IN), &value, sizeof(PT));
+		if constexpr (sizeof(PT) == 8) {
+			gpu::check(alpgpu_encode_value_f64(gpu::context(), s.at<double>(s.IN), s.at<int64_t>(s.ENC), factor_idx, exponent_idx, SAFE ? 1 : 0, 1), "alpgpu_encode_value_f64");
+		} else {
+			gpu::check(alpgpu_encode_value_f32(gpu::context(), s.at<float>(s.IN), s.at<int32_t>(s.ENC), factor_idx, exponent_idx, SAFE ? 1 : 0, 1), "alpgpu_encode_value_f32");
+		}
+		ST out;
+		gpu::d2h(&out, s.at<ST>(s.ENC), sizeof(ST));
+		return out;
+	}
 	//! encoder.hpp:75-78
 	static inline bool is_impossible_to_encode(const PT n) {
 		return !(n == n) || n - n != PT(0) || n > ENCODING_UPPER_LIMIT || n < ENCODING_LOWER_LIMIT || (n == PT(0) && std::signbit(n));

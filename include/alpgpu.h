@@ -366,6 +366,12 @@ int alpgpu_encode_simdized_f64(alpgpu_ctx* ctx, const double* d_in, double* d_ex
 int alpgpu_encode_values_f64(alpgpu_ctx* ctx, const double* d_in, const alpgpu_rowgroup_state* d_states,
                              const uint32_t* d_state_idx, double* d_exc, uint16_t* d_pos, size_t exc_stride,
                              uint16_t* d_cnt, int64_t* d_enc, uint8_t* d_fac, uint8_t* d_exp, uint64_t n_vectors);
+/* encoder::encode_value<SAFE> (include/alp/encoder.hpp:81-89), the scalar helper of the reference's header, on n_values VALUES (not vectors)
+ * with ONE (factor, exponent) pair: d_enc[i] = the encoded integer of d_in[i]; safe != 0 gives the sampling form (the sentinel
+ * ENCODING_UPPER_LIMIT for values that cannot be encoded), 0 the plain one (x86 cast semantics).  _f32: `safe` is ignored, the float SAFE
+ * branch does not exist in the reference as built. */
+int alpgpu_encode_value_f64(alpgpu_ctx* ctx, const double* d_in, int64_t* d_enc, uint8_t fac, uint8_t exp, int safe, uint64_t n_values);
+int alpgpu_encode_value_f32(alpgpu_ctx* ctx, const float* d_in, int32_t* d_enc, uint8_t fac, uint8_t exp, int safe, uint64_t n_values);
 /* encoder::analyze_ffor */
 int alpgpu_analyze_ffor_i64(alpgpu_ctx* ctx, const int64_t* d_enc, uint8_t* d_bw, int64_t* d_base, uint64_t n_vectors);
 

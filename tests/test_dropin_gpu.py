@@ -69,3 +69,60 @@ def test_one_host_column_over_several_contexts(tmp_path):
     p = subprocess.run([str(exe), "0", "0", "0"], capture_output=True, text=True, timeout=900)
     print(p.stdout)
     assert p.returncode == 0 and "multi_test: 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_header_tables_are_the_devices_and_encode_value(tmp_path, ctx, oracle):
+    """alp::Constants<PT>::{FRAC_ARR, EXP_ARR, FACT_ARR} (host copies in include/alp/constants.hpp) against what the DEVICE computes with ITS tables,
+    and alp::encoder<PT>::encode_value<SAFE> (through alpgpu_encode_value_*) against the oracle."""
+    import ctypes
+    import torch
+    exe = tmp_path / "constants_dump"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", f"-I{ROOT}/include", "-o", str(exe), f"{ROOT}/tests/cpp/constants_dump.cpp", f"-L{ROOT}/alp_amd", "-lalpgpu",
+                           f"-Wl,-rpath,{ROOT}/alp_amd"])
+    probes = [("ev64", v, f, e) for v, f, e in ((123.45, 0, 2), (-0.0, 0, 0), (1e300, 0, 18), (92233.72, 12, 14), (float("nan"), 1, 3), (-7.125, 3, 3), (9.3e18, 0, 0))]
+    args = [str(a) for p in probes for a in p]
+    out = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    tab = {}
+    ev = []
+    for line in out.stdout.splitlines():
+        w = line.split()
+        if w[0].startswith("ev"):
+            ev.append((int(w[1]), int(w[2])))
+        else:
+            tab.setdefault(w[0], []).append(int(w[2], 16))
+    assert [len(tab[k]) for k in ("frac64", "exp64", "fact64", "frac32", "exp32", "fact32")] == [21, 24, 19, 11, 11, 10]
+    # double tables through the device: decode_values(1, fac, exp = 0) = (double)FACT[fac] * FRAC[0]; decode_values(1, 0, exp) = FRAC[exp];
+    # encode_value(1.0, 0, exp) = the integer EXP[exp] (exact for exp <= 18)
+    one = torch.ones(19, 1024, dtype=torch.int64, device="cuda")
+    outd = torch.empty(19, 1024, dtype=torch.float64, device="cuda")
+    idx = torch.arange(19, dtype=torch.uint8, device="cuda")
+    zero = torch.zeros(19, dtype=torch.uint8, device="cuda")
+    ctx.decode_values(one, outd, zero, idx)
+    ctx.synchronize()
+    assert [int(x) for x in outd[:, 0].cpu().numpy().view(np.uint64)] == tab["frac64"][:19]
+    ctx.decode_values(one, outd, idx, zero)
+    ctx.synchronize()
+    assert [int(x) for x in outd[:, 0].cpu().numpy()] == [int(np.array(b, dtype=np.uint64).view(np.int64)) for b in tab["fact64"]]
+    ones = torch.ones(4, dtype=torch.float64, device="cuda")
+    for e in range(19):
+        got = int(ctx.encode_value(ones, 0, e, safe=False)[0])
+        assert got == int(np.array(tab["exp64"][e], dtype=np.uint64).view(np.float64)) == 10 ** e
+    # the float tables and the rest of the double ones: correctly rounded powers of ten, as the reference's literals are
+    assert tab["frac64"] == [int(np.float64(f"1e-{i}").view(np.uint64)) for i in range(21)] and tab["exp64"] == [int(np.float64(f"1e{i}").view(np.uint64)) for i in range(24)]
+    assert tab["frac32"] == [int(np.float32(f"1e-{i}").view(np.uint32)) for i in range(11)] and tab["exp32"] == [int(np.float32(f"1e{i}").view(np.uint32)) for i in range(11)]
+    assert tab["fact32"] == [10 ** i for i in range(10)]
+    # encode_value<SAFE> / <!SAFE> of the header against the oracle
+    lib = oracle.lib
+    lib.alpo_encode_value_safe.restype = lib.alpo_encode_value_unsafe.restype = ctypes.c_int64
+    for (_, v, f, e), (safe, unsafe) in zip(probes, ev):
+        assert safe == lib.alpo_encode_value_safe(ctypes.c_double(v), f, e) and unsafe == lib.alpo_encode_value_unsafe(ctypes.c_double(v), f, e), (v, f, e)
+    # and a batch through the C ABI, boundary values included
+    import datagen
+    x = np.concatenate([datagen.search_boundary_values(), datagen.decimal_column(2, 3, seed=4)[:500]]) if hasattr(datagen, "search_boundary_values") else datagen.decimal_column(2, 3, seed=4)
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+    for f, e in ((0, 0), (2, 5), (12, 14), (0, 18)):
+        gs, gu = ctx.encode_value(xd, f, e, safe=True).cpu().numpy(), ctx.encode_value(xd, f, e, safe=False).cpu().numpy()
+        ws = np.array([lib.alpo_encode_value_safe(ctypes.c_double(float(v)), f, e) for v in x], dtype=np.int64)
+        wu = np.array([lib.alpo_encode_value_unsafe(ctypes.c_double(float(v)), f, e) for v in x], dtype=np.int64)
+        assert np.array_equal(gs, ws) and np.array_equal(gu, wu), (f, e)
