@@ -186,12 +186,31 @@ def _cpu_runner():
     return pyoracle.Oracle(), "port", model
 
 
-def _run_threads(work, nthreads):
+def _run_threads(work, nthreads, prepare=None):
+    """one host thread per unit of work, each PINNED to one of the cores this process may use (thread t -> core t mod cores).  prepare(t), if
+    given, runs on the pinned thread in front of a barrier and outside the clock: threads use it to make (first-touch) their own buffers, so
+    that the pages sit on the NUMA node of the core that streams them — with buffers touched by one thread the all-cores figure of a
+    two-socket host is the inter-socket link's (measured: 27 GB/s instead of hundreds)."""
     res = [0.0] * nthreads
-    ths = [threading.Thread(target=lambda t=t: res.__setitem__(t, work(t))) for t in range(nthreads)]
-    t0 = time.perf_counter()
+    ctxs = [None] * nthreads
+    cpus = sorted(os.sched_getaffinity(0))
+    gate = threading.Barrier(nthreads + 1)
+
+    def pinned(t):
+        if not os.environ.get("ALPGPU_BENCH_NO_PIN"):
+            try:
+                os.sched_setaffinity(0, {cpus[t % len(cpus)]})  # pid 0 = the calling thread
+            except OSError:
+                pass
+        if prepare is not None:
+            ctxs[t] = prepare(t)
+        gate.wait()
+        res[t] = work(t) if prepare is None else work(t, ctxs[t])
+    ths = [threading.Thread(target=pinned, args=(t,)) for t in range(nthreads)]
     for th in ths:
         th.start()
+    gate.wait()
+    t0 = time.perf_counter()
     for th in ths:
         th.join()
     return time.perf_counter() - t0, res
@@ -200,13 +219,14 @@ def _run_threads(work, nthreads):
 def cpu_decode_baseline(ctx, col, vec, gpu_out, budget_s: float = 10.0):
     """Times the REFERENCE's CPU decode (falp + patch_exceptions; oracle/_ref, built from /root/reference in the build
     container) on this box's host cores and checks the GPU result against it bit for bit.  Sample: every 8th rowgroup of
-    the benchmark column (8 and 53 are coprime: every bit width 1..53 is in it) = ~131 k vectors = 1 GiB of decoded
-    doubles, DRAM-resident; all-cores: the sample's vectors split over the threads, each writing its own part of one
-    output buffer.  A second, cache-resident figure (the first 1024 vectors, every thread its own copy of the output)
-    is reported next to it."""
+    the benchmark column sampled at every 2nd rowgroup (2 and 53 are coprime: every bit width 1..53 is in it) = ~524 k vectors = 4 GiB of
+    decoded doubles written and 1.8 GiB of packed words read per pass, against 2 x 256 MiB of L3 on the 2 x EPYC 9575F hosts: DRAM-resident
+    (round 2's 1 GiB sample was partly cache-resident).  All-cores: the sample's vectors split over pinned threads, each writing its own
+    part of one output buffer.  A second, cache-resident figure (the first 1024 vectors, every thread its own copy of the output) is
+    reported next to it."""
     runner, kind, model = _cpu_runner()
     n_rg = (vec.size + RG - 1) // RG
-    rgs = np.arange(0, n_rg, 8)
+    rgs = np.arange(0, n_rg, 2 if vec.size >= (1 << 19) else 1)
     idx = (rgs[:, None] * RG + np.arange(RG)[None, :]).reshape(-1)
     idx = idx[idx < vec.size]
     n = idx.size
@@ -232,16 +252,21 @@ def cpu_decode_baseline(ctx, col, vec, gpu_out, budget_s: float = 10.0):
     def sl(a, lo, hi):
         return a[lo:hi]
 
-    def one_pass(nthreads, reps):
+    def one_pass(nthreads, reps, local=False):
         bounds = np.linspace(0, n, nthreads + 1).astype(np.int64)
 
-        def work(t):
+        def prepare(t):  # the thread's own copies of its inputs and its own output: pages on its core's NUMA node
+            lo, hi = int(bounds[t]), int(bounds[t + 1])
+            return (packed[lo:hi].copy(), np.zeros((hi - lo) * 1024, np.float64)) if hi > lo else None
+
+        def work(t, mine=None):
             lo, hi = int(bounds[t]), int(bounds[t + 1])
             if hi <= lo:
                 return 0.0
-            return runner.time_falp_column(sl(packed, lo, hi), 1024, sl(bw, lo, hi), sl(e, lo, hi), sl(f, lo, hi), sl(base, lo, hi), sl(cnt, lo, hi),
-                                           sl(exc, lo, hi), sl(pos, lo, hi), 8, hi - lo, out[lo * 1024:hi * 1024], reps)
-        return _run_threads(work, nthreads)
+            pk, o = (mine[0], mine[1]) if mine is not None else (sl(packed, lo, hi), out[lo * 1024:hi * 1024])
+            return runner.time_falp_column(pk, 1024, sl(bw, lo, hi), sl(e, lo, hi), sl(f, lo, hi), sl(base, lo, hi), sl(cnt, lo, hi),
+                                           sl(exc, lo, hi), sl(pos, lo, hi), 8, hi - lo, o, reps)
+        return _run_threads(work, nthreads, prepare if local else None)
 
     t1, _ = one_pass(1, 1)  # single thread, also page-faults the output and produces the values for the bit check
     got = gpu_out.view(-1, 1024)[torch.from_numpy(idx).to(gpu_out.device)].cpu().numpy()
@@ -249,9 +274,9 @@ def cpu_decode_baseline(ctx, col, vec, gpu_out, budget_s: float = 10.0):
     widths = sorted(set(int(b) for b in bw))
     t1b, _ = one_pass(1, 1)
     single = n * 8192 / min(t1, t1b) / 1e9
-    wall, _ = one_pass(threads, 1)
-    reps = int(max(1, min(200, budget_s * 0.5 / max(wall, 1e-3))))
-    wall, _ = one_pass(threads, reps)
+    wall, _ = one_pass(threads, 1, local=True)
+    reps = int(max(3, min(200, budget_s * 0.5 / max(wall, 1e-3))))
+    wall, _ = one_pass(threads, reps, local=True)
     all_cores = n * 8192 * reps / wall / 1e9
     # cache-resident variant (what round 1 reported): 1024 vectors, private outputs
     m = min(1024, n)
@@ -265,12 +290,15 @@ def cpu_decode_baseline(ctx, col, vec, gpu_out, budget_s: float = 10.0):
     cache_all = threads * m * 8192 * creps / wc / 1e9
     return {
         "value": round(all_cores, 3), "unit": "GB/s decoded doubles", "cores": threads, "kind": kind,
-        "sample": f"falp+patch_exceptions on every 8th rowgroup of the same column ({n} vectors = {n * 8 // 1024} MiB decoded, bit widths "
-                  f"{widths[0]}..{widths[-1]} all present, DRAM-resident, one shared output buffer), {reps} passes, {threads} host threads "
-                  f"({os.path.basename(runner.path)}; cpu: {model})",
+        "sample": f"falp+patch_exceptions on every 2nd rowgroup of the same column ({n} vectors = {n * 8 // 1024} MiB decoded + {int(sizes.sum()) >> 20} MiB of packed "
+                  f"words per pass, bit widths {widths[0]}..{widths[-1]} all present, DRAM-resident, every thread's slice of input and output first-touched by that thread), {reps} passes, {threads} pinned host "
+                  f"threads ({os.path.basename(runner.path)}; cpu: {model})",
         "single_thread_value": round(single, 3), "cache_resident_all_cores_value": round(cache_all, 3),
         "cache_resident_sample": f"first {m} vectors ({m * 8 // 1024} MiB per thread, private outputs), {creps} passes",
         "gpu_matches_cpu_bit_exact": exact, "bit_widths_checked": len(widths),
+        "host_note": (f"{threads} pinned host threads deliver {all_cores / max(single, 1e-9):.1f} x one thread on this box: its host CPUs are shared or capped "
+                      "(seen in round 3: 27 GB/s on 256 threads where round 2's boxes gave 0.7-1.2 TB/s; tools/cpu_baseline_check.py shows the threads taking turns)"
+                      if all_cores < 8 * single and threads >= 16 else "host threads scale"),
     }
 
 
@@ -293,16 +321,20 @@ def cpu_encode_baseline(x_gpu: torch.Tensor, ecol, budget_s: float = 10.0):
     threads = min(threads, n_rg)
     bounds = (np.linspace(0, n_rg, threads + 1).astype(np.int64)) * RG
 
-    def work(t, reps):
+    def prepare(t):  # the thread's own (NUMA-local) copy of its slice of the input
         lo, hi = int(bounds[t]), int(bounds[t + 1])
-        return runner.time_encode_column(col[lo * VEC:hi * VEC], hi - lo, reps)[0] if hi > lo else 0.0
-    wall, _ = _run_threads(lambda t: work(t, 1), threads)
+        return col[lo * VEC:hi * VEC].copy() if hi > lo else None
+
+    def work(t, mine, reps):
+        lo, hi = int(bounds[t]), int(bounds[t + 1])
+        return runner.time_encode_column(mine, hi - lo, reps)[0] if hi > lo else 0.0
+    wall, _ = _run_threads(lambda t, m: work(t, m, 1), threads, prepare)
     reps = int(max(1, min(100, budget_s * 0.6 / max(wall, 1e-3))))
-    wall, _ = _run_threads(lambda t: work(t, reps), threads)
+    wall, _ = _run_threads(lambda t, m: work(t, m, reps), threads, prepare)
     return {"value": round(n * 8192 * reps / wall / 1e9, 3), "unit": "GB/s input doubles", "cores": threads, "kind": kind,
             "single_thread_value": round(single, 3),
             "sample": f"encoder::init + encode + analyze_ffor + ffor on the first {n} vectors ({n * 8 // 1024} MiB, DRAM-resident) of the mixed column, "
-                      f"{reps} passes, {threads} host threads over disjoint rowgroup ranges ({os.path.basename(runner.path)}; cpu: {model})",
+                      f"{reps} passes, {threads} pinned host threads over disjoint rowgroup ranges ({os.path.basename(runner.path)}; cpu: {model})",
             "gpu_bit_width_sum_matches_cpu": bool(gpu_sum == sum_bw)}
 
 
@@ -546,7 +578,7 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
         "value": round(total_in * e_steps / e_elapsed / 1e9, 2), "unit": "GB/s input doubles (whole job)", "per_gpu_value": round(n * 8192 * e_steps / e_elapsed / 1e9, 2),
         "ms_per_step": round(e_elapsed / e_steps * 1e3, 4), "steps": e_steps,
         "roofline": {"bound": "hbm", "achieved": round(e_alg / e_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(e_alg / e_ms / 1e6 / HBM_PEAK_GBPS, 4),
-                     "kernels": "k_rowgroup_init + k_encode_fused (+ gated recovery launches)", "ms": round(e_ms, 4), "algorithmic_bytes_per_step": e_alg},
+                     "kernels": "k_rowgroup_init (persistent, beside) || k_encode_fused (+ gated recovery launches)", "ms": round(e_ms, 4), "algorithmic_bytes_per_step": e_alg},
         "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2), "overflow": int(ov),
         "decode_of_the_encoded_shard": {"value": round(total_in * e_steps / d_elapsed / 1e9, 2), "unit": "GB/s decoded doubles (whole job)",
                                         "roofline_frac_algorithmic": round((n * 8192 + pb + eb + 13 * n) / d_ms / 1e6 / HBM_PEAK_GBPS, 4)},
@@ -608,24 +640,39 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     read_bytes = alg_bytes - n * 8192 + n * 8
     extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
                                   "roofline_frac_algorithmic": frac(read_bytes, med),
-                                  "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector"}
-    # the same kernel with its unpack arithmetic left out (alpgpu_debug_decode_probe_f64): what the chain descriptor -> packed words ->
-    # barrier -> reduction costs on its own, i.e. the floor of this launch shape
-    pmed, _ = time_launches(lambda: ctx.decode_probe(col, sums), 7, 10)
-    extras["decode_sum_fused"]["loads_only_probe"] = {"ms": round(pmed, 3), "roofline_frac_algorithmic": frac(read_bytes, pmed), "sum_vs_probe": round(pmed / med, 4)}
-    del sums
+                                  "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector. "
+                                          "VALU-bound, not latency-bound: 506 vector instructions per vector at 73-83 % VALU utilisation (profiles/r03_consumers.txt)"}
+    # the column's total (alpgpu_column_sum_f64: per-vector sums + the documented tree) and the predicate consumer
+    tot = torch.empty(1, dtype=torch.float64, device=dev)
+    cmed, _ = time_launches(lambda: ctx.column_sum(col, tot), 7, 10)
+    extras["decode_sum_fused"]["column_sum"] = {"ms": round(cmed, 3), "roofline_frac_algorithmic": frac(read_bytes, cmed)}
+    cnts = torch.empty(n, dtype=torch.int32, device=dev)
+    kmed, _ = time_launches(lambda: ctx.decode_count_range(col, -1.0, 1.0, cnts), 7, 10)
+    extras["decode_sum_fused"]["count_range"] = {"ms": round(kmed, 3), "roofline_frac_algorithmic": frac(read_bytes - 4 * n, kmed)}
+    # the persistent, LDS-ring kernel built for the consumers in round 3 (ALPGPU_OPT_CONSUMER_PIPELINED): measured, not the default
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 1)
+    pmed, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 10)
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
+    extras["decode_sum_fused"]["pipelined_kernel_option"] = {"ms": round(pmed, 3), "roofline_frac_algorithmic": frac(read_bytes, pmed)}
+    del sums, tot, cnts
     # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
     enc_cpu = None
     for kind, label in (("mixed", "encode_alp_mixed"), ("rd", "encode_alp_rd"), ("mixed_exc0", "encode_alp_mixed_exc0"), ("mixed_exc10", "encode_alp_mixed_exc10")):
         x = synthetic_input(kind, n, dev, seed=42)
         ecol = capi.DeviceColumn(n, local_rank)
-        med, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)
+        med, _ = time_launches(lambda: ctx.encode(x, ecol), 7, 3)  # rowgroup search BESIDE the vector encode (second stream; the default)
+        ctx.set_option(capi.OPT_ENCODE_ASYNC_INIT, 0)
+        fmed, _ = time_launches(lambda: ctx.encode(x, ecol), 5, 2)  # ... in front of it (round 2's form)
+        ctx.set_option(capi.OPT_ENCODE_ASYNC_INIT, 1)
         imed, _ = time_launches(lambda: ctx.rowgroup_init(x, ecol), 5, 1)
+        vmed, _ = time_launches(lambda: ctx.encode_vectors(x, ecol), 5, 2)
         ctx.encode(x, ecol)
         pb, eb, ov = ctx.column_totals(ecol)
         dmed, _ = time_launches(lambda: ctx.decode(ecol, out), 7, 10)
         rt = bool(torch.equal(out[: n * VEC].view(torch.int64), x.view(torch.int64)))
-        extras[label] = {"input_GBps": round(n * 8192 / med / 1e6, 1), "ms": round(med, 3), "rowgroup_init_ms": round(imed, 3), "vectors": n,
+        extras[label] = {"input_GBps": round(n * 8192 / med / 1e6, 1), "ms": round(med, 3), "rowgroup_init_ms": round(imed, 3), "vector_encode_ms": round(vmed, 3),
+                         "search_in_front_ms": round(fmed, 3), "search_in_front_roofline_frac_algorithmic": frac(encode_alg_bytes(n, pb, eb), fmed), "vectors": n,
+                         "note": "ms = alpgpu_encode_f64 with the rowgroup search as a persistent kernel beside the single-pass vector encode (profiles/r03_async_init.txt)",
                          "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
                          "roofline_frac_algorithmic": frac(encode_alg_bytes(n, pb, eb), med),
                          "decode_GBps": round(n * 8192 / dmed / 1e6, 1), "decode_roofline_frac_algorithmic": frac(encode_alg_bytes(n, pb, eb), dmed),
@@ -653,7 +700,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     for label in ("encode_alp_mixed", "encode_alp_rd"):
         wb = int(extras[label]["compressed_bits_per_value"] * VEC / 8) // 16 * 16
         pmed, _ = time_launches(lambda: ctx.traffic_probe(probe_in, out, n, wb), 7, 5)
-        vec_ms = extras[label]["ms"] - extras[label]["rowgroup_init_ms"]
+        vec_ms = extras[label]["vector_encode_ms"]
         extras[label]["traffic_only_probe"] = {"ms": round(pmed, 3), "GBps_read_plus_write": round(n * (8192 + wb) / pmed / 1e6, 1), "written_bytes_per_vector": wb,
                                                "vector_encode_ms": round(vec_ms, 3), "vector_encode_vs_probe": round(pmed / vec_ms, 4),
                                                "note": "same launch shape as k_encode_fused, loads + dependent stores only; the encode cannot be faster than this plus the rowgroup search"}
