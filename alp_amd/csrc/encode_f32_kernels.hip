@@ -22,6 +22,9 @@
 namespace alpgpu {
 
 enum FusedMode { kSinglePass = 0, kAnalyze = 1, kPack = 2 };
+#ifndef ALPGPU_F32_ENC_OCC
+#define ALPGPU_F32_ENC_OCC 5 // __launch_bounds__' second argument for the single pass: wavefronts per SIMD the register budget is sized for
+#endif
 constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors per tile of the two-pass scan
 
 // kSinglePass: `status` = look-back words.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only), `gate` as in
@@ -29,7 +32,7 @@ constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors
 // (the single pass is held to 96 VGPRs — __launch_bounds__' second argument, wavefronts per SIMD: four of them per SIMD then leave the 96
 // registers the persistent rowgroup search needs to share the CU)
 template <int MODE>
-__global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? 5 : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+__global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_ENC_OCC : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                        uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
                                                                        uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,

@@ -4,6 +4,9 @@
 #   dec : python bench.py --steps 20 --warmup 10 --no-extras          (k_decode_column on the benchmark column)
 #   enc : python tools/prof_encode.py mixed 1048576                    (k_rowgroup_init, k_encode_fused)
 #   encf: python tools/prof_encode_f32.py decimal1 1048576             (k_rowgroup_init<f32>, k_encode_fused_f32) + float decode
+#   encrd: python tools/prof_encode.py rd 1048576                      (the all-ALP_RD encode)
+#   cons: python tools/prof_consumers.py 0 1048576                     (k_decode_column<2, false, kSinkSum>, then k_consume_column: the fused SUM consumer, both shapes)
+#   narrow: python tools/time_one.py 8:1048576                         (k_decode_column<2, true>: the two-vectors-per-workgroup decode of a narrow column)
 # raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_* (run the summary LOCALLY on the
 # merged directory, and remove a stale local gpurun_out/<tag>_prof first: rocprofv3 names its files after process ids, a second run
 # does not overwrite the first)
@@ -21,6 +24,9 @@ run() { # name, command...
 run dec python $ROOT/bench.py --steps 20 --warmup 10 --no-extras
 run enc python $ROOT/tools/prof_encode.py mixed 1048576
 run encf python $ROOT/tools/prof_float.py 1048576
+run encrd python $ROOT/tools/prof_encode.py rd 1048576
+run cons python $ROOT/tools/prof_consumers.py 0 1048576
+run narrow python $ROOT/tools/time_one.py 8:1048576
 cd $ROOT
 grep -h '"metric"' $OUT/dec_stats.log | tail -1 > $OUT/bench_under_rocprof.json
 python tools/summarize_round.py $TAG $OUT
