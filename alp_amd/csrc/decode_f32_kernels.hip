@@ -24,7 +24,7 @@ constexpr int kExcStageF    = 128;
 struct __attribute__((aligned(16))) DecodeLdsF32 {
 	uint8_t  stage[kStageBytesF];
 	uint32_t mask[32];
-	uint32_t excv[kExcStageF];
+	uint8_t  excv[4 * kExcStageF]; // the head of the exception record as it lies in the stream (values first), brought in by LDS-DMA
 };
 
 struct ExcMaskF {
@@ -48,10 +48,12 @@ __device__ __forceinline__ ExcMaskF load_exception_mask_f32(const DecodeLdsF32& 
 
 template <int VAL_BYTES>
 __device__ __forceinline__ uint32_t fetch_exception_f32(const DecodeLdsF32& L, const uint8_t* __restrict__ rec, int rank) {
-	if (rank < kExcStageF) { return L.excv[rank]; }
+	constexpr int kStaged = 4 * kExcStageF / VAL_BYTES;
 	if constexpr (VAL_BYTES == 4) {
+		if (rank < kStaged) { return reinterpret_cast<const uint32_t*>(L.excv)[rank]; }
 		return reinterpret_cast<const uint32_t*>(rec)[rank];
 	} else {
+		if (rank < kStaged) { return reinterpret_cast<const uint16_t*>(L.excv)[rank]; }
 		return reinterpret_cast<const uint16_t*>(rec)[rank];
 	}
 }
@@ -65,12 +67,8 @@ __device__ __forceinline__ void store_quad(float* __restrict__ p, const u32x4& b
 	}
 }
 
-struct ExcRegsF {
-	uint32_t pos;
-	uint32_t val;
-};
-
-__device__ __forceinline__ ExcRegsF issue_vector_loads_f32(DecodeLdsF32& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
+// packed words and exception values by LDS-DMA, positions into a register (decode_kernels.hip: issue_vector_loads)
+__device__ __forceinline__ uint32_t issue_vector_loads_f32(DecodeLdsF32& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
                                                            const uint8_t* __restrict__ rec, int tid, int wave) {
 	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 	const bool  is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
@@ -81,22 +79,21 @@ __device__ __forceinline__ ExcRegsF issue_vector_loads_f32(DecodeLdsF32& L, cons
 		const int c = tid + kDecThreadsF * j;
 		if (c < n_units) { __builtin_amdgcn_global_load_lds(g + c, reinterpret_cast<ull2*>(L.stage) + (kDecThreadsF * j + 64 * wave), 16, 0, 0); }
 	}
-	ExcRegsF  e {0u, 0u};
+	uint32_t  pos = 0u;
 	const int cnt = d.exc_cnt;
-	if (tid < cnt) {
-		const int vb = is_alp ? 4 : 2;
-		e.pos        = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * vb)[tid];
-		if (tid < kExcStageF) { e.val = is_alp ? reinterpret_cast<const uint32_t*>(rec)[tid] : static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(rec)[tid]); }
+	if (cnt > 0) { // wave-uniform
+		const uint32_t val_bytes = (is_alp ? 4u : 2u) * static_cast<uint32_t>(cnt);
+		const int      dwords    = static_cast<int>(((val_bytes < 4u * kExcStageF ? val_bytes : 4u * kExcStageF) + 3u) >> 2); // (records are 8-byte multiples)
+		static_assert(kExcStageF <= kDecThreadsF, "one load per thread covers the stage");
+		if (tid < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + tid, reinterpret_cast<uint32_t*>(L.excv) + 64 * wave, 4, 0, 0); }
+		if (tid < cnt) { pos = reinterpret_cast<const uint16_t*>(rec + val_bytes)[tid]; }
 	}
-	return e;
+	return pos;
 }
 
-__device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, const ExcRegsF& e, int tid) {
+__device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, uint32_t pos, int tid) {
 	const int cnt = d.exc_cnt;
-	if (tid < cnt) {
-		atomicOr(&L.mask[e.pos >> 5], 1u << (e.pos & 31));
-		if (tid < kExcStageF) { L.excv[tid] = e.val; }
-	}
+	if (tid < cnt) { atomicOr(&L.mask[pos >> 5], 1u << (pos & 31)); }
 	if (cnt > kDecThreadsF) {
 		const uint16_t* poss = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * (d.scheme == ALPGPU_SCHEME_ALP ? 4 : 2));
 		for (int j = tid + kDecThreadsF; j < cnt; j += kDecThreadsF) {
@@ -208,11 +205,9 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 	const int      wave = wave_in_wg();
 	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
 	if (v0 >= n_vectors) { return; }
-	if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
-	__syncthreads(); // before anything waits on memory
 
 	alpgpu_vector_desc d[V];
-	ExcRegsF           e[V];
+	uint32_t           pos[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // tail vectors of the last workgroup are simply loaded again
@@ -222,9 +217,17 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 #pragma unroll
 	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts_f32(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
 #pragma unroll
-	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads_f32(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+	for (int i = 0; i < V; ++i) { pos[i] = issue_vector_loads_f32(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+	// only a workgroup with exceptions zeroes its masks, behind the issue of its loads (decode_kernels.hip: k_decode_column)
+	bool any_exc = false;
 #pragma unroll
-	for (int i = 0; i < V; ++i) { land_exceptions_f32(L[i], d[i], excs + d[i].exc_off, e[i], tid); }
+	for (int i = 0; i < V; ++i) { any_exc |= d[i].exc_cnt != 0; }
+	if (any_exc) { // workgroup-uniform
+		if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
+#pragma unroll
+		for (int i = 0; i < V; ++i) { land_exceptions_f32(L[i], d[i], excs + d[i].exc_off, pos[i], tid); }
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if constexpr (SINK != kSinkStoreF) {

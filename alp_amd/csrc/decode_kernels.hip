@@ -38,12 +38,13 @@ namespace alpgpu {
 constexpr int kDecWaves     = ALPGPU_DEC_WAVES; // wavefronts cooperating on one vector
 constexpr int kStepsPerWave = 8 / kDecWaves;
 constexpr int kStageBytes   = 8704; // >= 63*128 (RD right) + 3*128 (RD left) + 128 pad, and >= 64*128 + 128 (ALP bw 64)
-constexpr int kExcStage     = 128;  // exception values staged in LDS per vector; the rest are read from HBM on use
+constexpr int kExcStage     = 128;  // 8-byte exception values staged in LDS per vector (512 2-byte ALP_RD ones); the rest are read from HBM on use
+constexpr uint32_t kExcStageBytes = 8u * kExcStage;
 
 struct __attribute__((aligned(16))) DecodeLds {
 	uint8_t  stage[kStageBytes];
 	uint32_t mask[32];
-	uint64_t excv[kExcStage];
+	uint8_t  excv[kExcStageBytes]; // the head of the exception record as it lies in the stream (its values come first), brought in by LDS-DMA
 };
 
 // The exception mask (32 words) as seen by one wavefront: lane l < 32 holds word l and the number of exceptions in the
@@ -67,12 +68,15 @@ __device__ __forceinline__ ExcMask load_exception_mask(const DecodeLds& L, int l
 	return m;
 }
 
+// the value of the exception of that rank: staged (LDS) or, past the stage, from HBM
 template <int VAL_BYTES>
 __device__ __forceinline__ uint64_t fetch_exception(const DecodeLds& L, const uint8_t* __restrict__ rec, int rank) {
-	if (rank < kExcStage) { return L.excv[rank]; }
+	constexpr int kStaged = static_cast<int>(kExcStageBytes) / VAL_BYTES;
 	if constexpr (VAL_BYTES == 8) {
+		if (rank < kStaged) { return reinterpret_cast<const uint64_t*>(L.excv)[rank]; }
 		return reinterpret_cast<const uint64_t*>(rec)[rank];
 	} else {
+		if (rank < kStaged) { return reinterpret_cast<const uint16_t*>(L.excv)[rank]; }
 		return reinterpret_cast<const uint16_t*>(rec)[rank];
 	}
 }
@@ -236,14 +240,12 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 	}
 }
 
-// Issues every load of one vector: packed words straight into LDS (global_load_lds, 16 B per lane, no VGPR round trip),
-// exception position + value into registers.
-struct ExcRegs {
-	uint32_t pos;
-	uint64_t val;
-};
-__device__ __forceinline__ ExcRegs issue_vector_loads(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
-                                                      const uint8_t* __restrict__ rec, int tid, int wave) {
+// Issues every load of one vector: packed words and the values of its exceptions straight into LDS (global_load_lds, 16 resp. 4 bytes per
+// lane, no VGPR round trip), exception positions into registers.  (Until round 3 the values went through registers too, behind a branch on the
+// scheme for their width — and the compiler's wait-count pass put an s_waitcnt vmcnt(0) between the two arms, i.e. a whole HBM round trip in
+// front of the packed loads of every vector with exceptions of one of the two schemes.)
+__device__ __forceinline__ uint32_t issue_vector_loads(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
+                                                       const uint8_t* __restrict__ rec, int tid, int wave) {
 	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 	constexpr int T       = 64 * kDecWaves;
 	const bool    is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
@@ -256,23 +258,22 @@ __device__ __forceinline__ ExcRegs issue_vector_loads(DecodeLds& L, const alpgpu
 			__builtin_amdgcn_global_load_lds(g + c, reinterpret_cast<ull2*>(L.stage) + (T * j + 64 * wave), 16, 0, 0);
 		}
 	}
-	ExcRegs   e {0u, 0ull};
+	uint32_t  pos = 0u;
 	const int cnt = d.exc_cnt;
-	if (tid < cnt) {
-		const int vb = is_alp ? 8 : 2;
-		e.pos        = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * vb)[tid];
-		if (tid < kExcStage) { e.val = is_alp ? reinterpret_cast<const uint64_t*>(rec)[tid] : static_cast<uint64_t>(reinterpret_cast<const uint16_t*>(rec)[tid]); }
+	if (cnt > 0) { // wave-uniform
+		const uint32_t val_bytes = (is_alp ? 8u : 2u) * static_cast<uint32_t>(cnt);
+		const int      dwords    = static_cast<int>(((val_bytes < kExcStageBytes ? val_bytes : kExcStageBytes) + 3u) >> 2); // (records are 8-byte multiples)
+		static_assert(kExcStageBytes / 4 <= T, "one load per thread covers the stage");
+		if (tid < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + tid, reinterpret_cast<uint32_t*>(L.excv) + 64 * wave, 4, 0, 0); }
+		if (tid < cnt) { pos = reinterpret_cast<const uint16_t*>(rec + val_bytes)[tid]; }
 	}
-	return e;
+	return pos;
 }
 
-__device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, const ExcRegs& e, int tid) {
+__device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, uint32_t pos, int tid) {
 	constexpr int T   = 64 * kDecWaves;
 	const int     cnt = d.exc_cnt;
-	if (tid < cnt) {
-		atomicOr(&L.mask[e.pos >> 5], 1u << (e.pos & 31));
-		if (tid < kExcStage) { L.excv[tid] = e.val; }
-	}
+	if (tid < cnt) { atomicOr(&L.mask[pos >> 5], 1u << (pos & 31)); }
 	if (cnt > T) { // more exceptions than threads in one vector: rare
 		const uint16_t* poss = reinterpret_cast<const uint16_t*>(rec + static_cast<size_t>(cnt) * (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2));
 		for (int j = tid + T; j < cnt; j += T) {
@@ -291,20 +292,14 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
                                                                   const uint8_t* __restrict__ excs, double* __restrict__ out,
                                                                   uint64_t n_vectors, uint64_t wg_offset, double lo, double hi) {
 	__shared__ DecodeLds L[V];
-	static_assert(kDecWaves >= 2, "exception staging assumes at least kExcStage threads");
-	const int      tid  = static_cast<int>(threadIdx.x);
+		const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
 	const int      wave = wave_in_wg();
 	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
 	if (v0 >= n_vectors) { return; }
 
-	// The exception masks are zeroed and that write is fenced BEFORE anything waits on memory, so that the only
-	// barrier that sits behind HBM latency is the single one after all loads have landed.
-	if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
-	__syncthreads();
-
 	alpgpu_vector_desc d[V];
-	ExcRegs            e[V];
+	uint32_t           pos[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // the odd tail vector is simply loaded twice
@@ -314,9 +309,19 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 #pragma unroll
 	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
 #pragma unroll
-	for (int i = 0; i < V; ++i) { e[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+	for (int i = 0; i < V; ++i) { pos[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+	// Only a workgroup that has exceptions zeroes its masks, and it does so behind the issue of all its loads: the barrier that fences the
+	// zeroes from the atomics waits for LDS only, so it falls into the shadow of the HBM round trip.  (Until round 3 every workgroup,
+	// exceptions or not, began with the zeroing write and a barrier in front of its first load.)
+	bool any_exc = false;
 #pragma unroll
-	for (int i = 0; i < V; ++i) { land_exceptions(L[i], d[i], excs + d[i].exc_off, e[i], tid); }
+	for (int i = 0; i < V; ++i) { any_exc |= d[i].exc_cnt != 0; }
+	if (any_exc) { // workgroup-uniform
+		if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
+#pragma unroll
+		for (int i = 0; i < V; ++i) { land_exceptions(L[i], d[i], excs + d[i].exc_off, pos[i], tid); }
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
 	__syncthreads();
 
