@@ -27,37 +27,40 @@ enum FusedMode { kSinglePass = 0, kAnalyze = 1, kPack = 2 };
 #endif
 constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors per tile of the two-pass scan
 
-// kSinglePass: `status` = look-back words.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only), `gate` as in
-// encode_kernels.hip, v_first = 0.
-// (the single pass is held to 96 VGPRs — __launch_bounds__' second argument, wavefronts per SIMD: four of them per SIMD then leave the 96
-// registers the persistent rowgroup search needs to share the CU)
+struct FusedSharedF32 {
+	EncodeLdsF32 lds[kFusedWaves];
+	uint64_t     s_size[kFusedWaves];
+	uint64_t     s_excl;
+	uint32_t     s_count;
+	uint32_t     s_ready;
+};
+
+// one tile (kFusedWaves vectors, one per wavefront) of k_encode_fused_f32
 template <int MODE>
-__global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_ENC_OCC : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                                       alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
-                                                                       uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
-                                                                       uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
-                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order,
-                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate, uint32_t async_states) {
-	if (MODE != kSinglePass && gate != nullptr && *gate == 0) { return; }
-	__builtin_amdgcn_s_setprio(2); // over the persistent rowgroup search that may share the CU (see k_encode_fused)
+__device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_t tile, const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed, uint8_t* __restrict__ excs,
+                                                uint64_t* __restrict__ status, uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
+                                                uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order, uint32_t spin_limit,
+                                                uint32_t async_states) {
 	if (MODE == kPack && totals[2] != 0) { // capacity overflow (reported through alpgpu_column_totals): no stream bytes, descriptors a decoder can follow
-		const uint64_t vo = v_first + static_cast<uint64_t>(blockIdx.x) * kFusedWaves + (threadIdx.x >> 6);
+		const uint64_t vo = v_first + tile * kFusedWaves + (threadIdx.x >> 6);
 		if ((threadIdx.x & 63) == 0 && vo < v_first + n_vectors_launch) { descs[vo] = empty_descriptor(); }
 		return;
 	}
-	__shared__ EncodeLdsF32 lds[kFusedWaves];
-	__shared__ uint64_t     s_size[kFusedWaves];
-	__shared__ uint64_t     s_excl;
-	__shared__ uint32_t     s_count;
-	__shared__ uint32_t     s_ready;
-	const int               lane = lane_id();
-	const int               wave = wave_in_wg();
-	const uint64_t          tile = blockIdx.x;
-	if (threadIdx.x == 0) {
-		s_count = 0;
-		s_ready = 0;
+	EncodeLdsF32 (&lds)[kFusedWaves] = S.lds;
+	uint64_t (&s_size)[kFusedWaves]  = S.s_size;
+	uint64_t& s_excl                 = S.s_excl;
+	uint32_t& s_count                = S.s_count;
+	uint32_t& s_ready                = S.s_ready;
+	const int lane = lane_id();
+	const int wave = wave_in_wg();
+	if (MODE == kSinglePass) { // (the other two modes share nothing between wavefronts)
+		if (threadIdx.x == 0) {
+			s_count = 0;
+			s_ready = 0;
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 
 	EncodeLdsF32&  L    = lds[wave];
 	const uint64_t vl   = tile * kFusedWaves + wave;
@@ -257,6 +260,34 @@ __global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_
 	if (lane == 0) { descs[v] = d; }
 }
 
+// kSinglePass: `status` = look-back words, one workgroup per tile.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only),
+// `gate` as in encode_kernels.hip, v_first = 0; the grid may be smaller than the number of tiles (the workgroups stride over them): behind a
+// single-pass encode these two are launched with a closed gate every time, and a grid of one workgroup per tile cost 16 us per 256 Ki
+// vectors just to find the gate closed (profiles/r03_float_encode.txt).
+// (the single pass is held to 96 VGPRs — __launch_bounds__' second argument, wavefronts per SIMD: four of them per SIMD then leave the 96
+// registers the persistent rowgroup search needs to share the CU)
+template <int MODE>
+__global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_ENC_OCC : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                       alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
+                                                                       uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
+                                                                       uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
+                                                                       uint64_t v_first, uint64_t n_vectors_launch, const uint16_t* __restrict__ rd_order,
+                                                                       uint32_t spin_limit, const uint64_t* __restrict__ gate, uint32_t async_states) {
+	if (MODE != kSinglePass && gate != nullptr && *gate == 0) { return; }
+	__builtin_amdgcn_s_setprio(2); // over the persistent rowgroup search that may share the CU (see k_encode_fused)
+	__shared__ FusedSharedF32 S;
+	if constexpr (MODE == kSinglePass) {
+		encode_tile_f32<MODE>(S, blockIdx.x, in, rgs, descs, packed, excs, status, totals, packed_capacity, exc_capacity, v_first, n_vectors_launch, rd_order, spin_limit,
+		                      async_states);
+	} else {
+		const uint64_t n_tiles = (n_vectors_launch + kFusedWaves - 1) / kFusedWaves;
+		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+			encode_tile_f32<MODE>(S, tile, in, rgs, descs, packed, excs, status, totals, packed_capacity, exc_capacity, v_first, n_vectors_launch, rd_order, spin_limit,
+			                      async_states);
+		}
+	}
+}
+
 // (see k_fused_finish in encode_kernels.hip)
 __global__ __launch_bounds__(256) void k_fused_finish_f32(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear) {
 	if (threadIdx.x == 0) {
@@ -304,7 +335,11 @@ int launch_encode_vectors_f32(hipStream_t stream, const float* d_in, uint64_t n_
 		if (gate == nullptr) { (void)hipMemsetAsync(col->d_totals, 0, 64, stream); }
 		return ALPGPU_OK;
 	}
-	const dim3 grid(static_cast<unsigned>((n_vectors + kFusedWaves - 1) / kFusedWaves)), block(64 * kFusedWaves);
+	// gate != nullptr: the recovery route behind a single-pass encode — a capped grid (the workgroups stride over the tiles), so that the
+	// launches cost microseconds when the gate is closed, which is always unless the look-back stalled
+	const uint64_t n_tiles = (n_vectors + kFusedWaves - 1) / kFusedWaves;
+	const uint64_t cap     = gate != nullptr ? 4096ull : (1ull << 30);
+	const dim3     grid(static_cast<unsigned>(n_tiles < cap ? n_tiles : cap)), block(64 * kFusedWaves);
 	hipLaunchKernelGGL(k_encode_fused_f32<kAnalyze>, grid, block, 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
 	                   col->d_totals, col->packed_capacity, col->exc_capacity, 0ull, n_vectors, col->d_rd_order, 0u, gate, 0u);
 	if (launch_scan_offsets(stream, col, n_vectors, d_workspace, true, gate) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
