@@ -66,36 +66,55 @@ __device__ __forceinline__ double dpp_f64(double v) {
 	hi                = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
 	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
 }
-// wavefront-wide NaN-ignoring min and max; the result is returned wave-uniform (read from lane 63)
+// the same where EVERY lane has a source lane (rotations inside a 16-lane row): no old value to keep, so no register copy in front
+template <int CTRL>
+__device__ __forceinline__ double dpp_all_f64(double v) {
+	const uint64_t b  = static_cast<uint64_t>(__double_as_longlong(v));
+	int            lo = static_cast<int>(static_cast<uint32_t>(b)), hi = static_cast<int>(static_cast<uint32_t>(b >> 32));
+	lo                = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+	hi                = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+	return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo)));
+}
+// NaN-ignoring minimum over each 16-lane row, left in every lane of the row (row_ror 1, 2, 4, 8: 3 instructions per step)
+__device__ __forceinline__ double row_min_f64(double t) {
+	t = fmin_num(t, dpp_all_f64<0x121>(t));
+	t = fmin_num(t, dpp_all_f64<0x122>(t));
+	t = fmin_num(t, dpp_all_f64<0x124>(t));
+	t = fmin_num(t, dpp_all_f64<0x128>(t));
+	return t;
+}
+__device__ __forceinline__ double f64_from_words(uint32_t lo, uint32_t hi) { return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo)); }
+
+// Wavefront-wide NaN-ignoring min and max, returned wave-uniform.  ONE reduction chain for both: max = -min(-x); v_permlane32_swap (CDNA4)
+// puts the minimum candidates of lane pairs (i, i + 32) side by side in lanes 0..31 and the negated maximum candidates in lanes 32..63, so a
+// single v_min_f64 folds 64 -> 32 for both, four row rotations reduce every 16-lane row, and one row_bcast:15 joins rows (0,1) and (2,3):
+// lane 31 holds the minimum, lane 63 minus the maximum.  25 vector instructions; two separate row_shr / row_bcast scans were 64, a third of
+// them register copies (a DPP move that leaves some lanes unwritten is tied to its old value).
 __device__ __forceinline__ void wave_minmax_f64(double& mn, double& mx) {
-#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
-	mn = fmin_num(mn, dpp_f64<CTRL, ROWS>(mn));                                                                         \
-	mx = fmax_num(mx, dpp_f64<CTRL, ROWS>(mx));
-	ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
-	ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
-	ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
-	ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8   -> lane 15 of every 16-lane row holds the row's result
-	ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
-	ALPGPU_MINMAX_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's result
-#undef ALPGPU_MINMAX_STEP
-	const uint64_t a = static_cast<uint64_t>(__double_as_longlong(mn)), b = static_cast<uint64_t>(__double_as_longlong(mx));
-	const uint32_t a0 = __builtin_amdgcn_readlane(static_cast<uint32_t>(a), 63), a1 = __builtin_amdgcn_readlane(static_cast<uint32_t>(a >> 32), 63);
-	const uint32_t b0 = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), 63), b1 = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), 63);
-	mn = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(a1) << 32) | a0));
-	mx = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(b1) << 32) | b0));
+	const uint64_t a = static_cast<uint64_t>(__double_as_longlong(mn)), b = static_cast<uint64_t>(__double_as_longlong(mx)) ^ 0x8000000000000000ull;
+	const auto     lo = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(a), static_cast<uint32_t>(b), false, false);
+	const auto     hi = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(a >> 32), static_cast<uint32_t>(b >> 32), false, false);
+	double         t  = fmin_num(f64_from_words(lo[0], hi[0]), f64_from_words(lo[1], hi[1]));
+	t                 = row_min_f64(t);
+	t                 = fmin_num(t, dpp_f64<0x142, 0xa>(t)); // row_bcast:15 into rows 1 and 3
+	const uint64_t r  = static_cast<uint64_t>(__double_as_longlong(t));
+	const uint32_t a0 = __builtin_amdgcn_readlane(static_cast<uint32_t>(r), 31), a1 = __builtin_amdgcn_readlane(static_cast<uint32_t>(r >> 32), 31);
+	const uint32_t b0 = __builtin_amdgcn_readlane(static_cast<uint32_t>(r), 63), b1 = __builtin_amdgcn_readlane(static_cast<uint32_t>(r >> 32), 63);
+	mn = f64_from_words(a0, a1);
+	mx = f64_from_words(b0, b1 ^ 0x80000000u);
 }
 
-// the same reduction inside each 32-lane half: lane 31 ends up with the result of lanes 0..31, lane 63 with that of lanes 32..63
+// The same reduction inside each 32-lane half: LANE 31 ends up with min and max of lanes 0..31, LANE 63 with those of lanes 32..63 (the other
+// lanes hold nothing meaningful).  v_permlane16_swap folds rows (0,1) and (2,3): rows 0 / 2 then carry the halves' minimum candidates, rows
+// 1 / 3 their negated maximum candidates; four row rotations; rows 1 / 3 fetch the minimum from the row below (row_bcast:15).
 __device__ __forceinline__ void half_minmax_f64(double& mn, double& mx) {
-#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
-	mn = fmin_num(mn, dpp_f64<CTRL, ROWS>(mn));                                                                         \
-	mx = fmax_num(mx, dpp_f64<CTRL, ROWS>(mx));
-	ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
-	ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
-	ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
-	ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8
-	ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
-#undef ALPGPU_MINMAX_STEP
+	const uint64_t a = static_cast<uint64_t>(__double_as_longlong(mn)), b = static_cast<uint64_t>(__double_as_longlong(mx)) ^ 0x8000000000000000ull;
+	const auto     lo = __builtin_amdgcn_permlane16_swap(static_cast<uint32_t>(a), static_cast<uint32_t>(b), false, false);
+	const auto     hi = __builtin_amdgcn_permlane16_swap(static_cast<uint32_t>(a >> 32), static_cast<uint32_t>(b >> 32), false, false);
+	double         t  = fmin_num(f64_from_words(lo[0], hi[0]), f64_from_words(lo[1], hi[1]));
+	t                 = row_min_f64(t);
+	mn                = dpp_f64<0x142, 0xa>(t);
+	mx                = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(__double_as_longlong(t)) ^ 0x8000000000000000ull));
 }
 
 __device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint64_t v, int lane) {

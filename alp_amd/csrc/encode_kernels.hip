@@ -330,7 +330,12 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	// started two memory round trips late — 20 % of a tile's life.  A wavefront past the end of the column reads the launch's
 	// first vector instead (nothing of it is stored).
 	const uint64_t v_read = live ? v : v_first;
+#ifdef ALPGPU_EXPERIMENT_ENC_WRAP_TRAFFIC // timing experiment (profiles/r03_encode_levers.txt): every vector's 8 KiB come from the first 8192 vectors and go
+	// to the first 64 MiB / 8 MiB of the streams — the same arithmetic on a column that repeats its first 8192 vectors, without the HBM traffic
+	x = load_vector(in, v_read & 8191ull, lane);
+#else
 	x                     = load_vector(in, v_read, lane);
+#endif
 	// the rowgroup's state, once, into registers (alp_device.hpp); its read is in flight together with the input's
 	// async_states (alpgpu_encode_f64 on a long column): the states are being published by the persistent rowgroup search that runs
 	// beside this kernel on a second stream; a wavefront polls its rowgroup's tag (nearly always set long before: the search runs
@@ -486,8 +491,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 		}
 		return;
 	}
+#ifdef ALPGPU_EXPERIMENT_ENC_WRAP_TRAFFIC
+	uint8_t* dst = packed + (d.packed_off & ((64ull << 20) - 1));
+	uint8_t* rec = excs + (d.exc_off & ((8ull << 20) - 1));
+#else
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
+#endif
 #ifdef ALPGPU_ABLATE_STORES // timing experiment: everything but the output stores
 	if (packed_capacity == 1) {
 #endif
