@@ -447,6 +447,43 @@ __device__ __forceinline__ void pack_u64_units(const uint64_t* vals, int bw, int
 		P.acc[t] = acc;
 	}
 }
+// The same packing as a SCATTER from the registers that hold the values (no staging of the values, no per-word gather loop): lane l holds,
+// for m = 0..7, the pair (row 8m + l/8, columns 2(l%8), 2(l%8) + 1) — one shift to its place in stream word k = (row * bw) >> 6, OR-ed into
+// the wavefront-private output image in LDS (ds_or_b64; a row that straddles a word boundary adds its upper bits to word k + 1), and the
+// image is read back as this lane's units.  ~11 vector instructions and 4 LDS atomics per pair; the gather form costs ~250 vector
+// instructions per vector at 25 bits (profiles/r03_encode_levers.txt).  One wavefront's LDS operations execute in order: zero, OR, read.
+// vals[m][j] = value - base (< 2^bw); `image`: 8 KiB of wavefront-private LDS.
+__device__ __forceinline__ void pack_u64_scatter(uint64_t* image, const uint64_t (&vals)[8][2], int bw, int lane, PackedUnits& P) {
+	ull2v*    img2    = reinterpret_cast<ull2v*>(image);
+	const int n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		if (64 * t < n_units) { img2[lane + 64 * t] = ull2v {0ull, 0ull}; } // wave-uniform; whole 1-KiB blocks (the image has room for 512 units)
+	}
+	if (bw > 0) {
+		const int      a  = lane & 7;
+		const uint32_t p0 = static_cast<uint32_t>(lane >> 3) * static_cast<uint32_t>(bw);
+		uint64_t*      wa = image + 2 * a;
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			const uint32_t p = p0 + static_cast<uint32_t>(8 * m) * static_cast<uint32_t>(bw); // bit position of row 8m + l/8 in its column's stream
+			const uint32_t k = p >> 6, s = p & 63u;
+			uint64_t*      w = wa + 16 * k; // unit 8k + a
+			__hip_atomic_fetch_or(w, vals[m][0] << s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			__hip_atomic_fetch_or(w + 1, vals[m][1] << s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			if (s + static_cast<uint32_t>(bw) > 64u) { // the row's upper bits belong to word k + 1 (s >= 1 here)
+				__hip_atomic_fetch_or(w + 16, vals[m][0] >> (64u - s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				__hip_atomic_fetch_or(w + 17, vals[m][1] >> (64u - s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < 8; ++t) {
+		ull2v acc = {0ull, 0ull};
+		if (64 * t < n_units) { acc = img2[lane + 64 * t]; }
+		P.acc[t] = acc;
+	}
+}
 __device__ __forceinline__ void store_packed_units(const PackedUnits& P, int bw, ull2v* __restrict__ out, int lane) {
 	const int n_units = 8 * bw;
 #pragma unroll

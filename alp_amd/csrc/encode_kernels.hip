@@ -320,7 +320,10 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	alpgpu_vector_desc d;
 	uint64_t           acc0 = 0, acc1 = 0; // ALP_RD: packed left streams of this lane's two lane64 columns
 	uint64_t           ballots[8][2];
+	uint64_t           pvals[8][2]; // what gets packed: value - base (ALP), right parts (ALP_RD)
 	int                cnt = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) { pvals[m][0] = pvals[m][1] = 0; }
 	d.packed_off = d.exc_off = 0;
 	d.base                   = 0;
 	d.bw = d.e = d.f = d.lbw = 0;
@@ -371,27 +374,27 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 			PHASE_MARK(2);
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
 			cnt = R.cnt;
-			ulonglong2*    lv   = reinterpret_cast<ulonglong2*>(L.vals);
 			const uint64_t base = static_cast<uint64_t>(R.base);
 #pragma unroll
 			for (int m = 0; m < 8; ++m) {
-				lv[64 * m + lane] = make_ulonglong2(static_cast<uint64_t>(R.enc[m][0]) - base, static_cast<uint64_t>(R.enc[m][1]) - base);
-				ballots[m][0]     = R.ballot[m][0];
-				ballots[m][1]     = R.ballot[m][1];
+				pvals[m][0]   = static_cast<uint64_t>(R.enc[m][0]) - base;
+				pvals[m][1]   = static_cast<uint64_t>(R.enc[m][1]) - base;
+				ballots[m][0] = R.ballot[m][0];
+				ballots[m][1] = R.ballot[m][1];
 			}
 		} else {
 			RdEncoded R;
 			encode_rd_registers(x, *rgp, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, async_states != 0);
 			d.bw = rgp->rd_rbw, d.lbw = rgp->rd_lbw;
 			cnt = R.cnt;
-			ulonglong2*    lv    = reinterpret_cast<ulonglong2*>(L.vals);
 			const int      lbw   = d.lbw;
 			const uint64_t lmask = (1ull << lbw) - 1ull;
 #pragma unroll
 			for (int m = 0; m < 8; ++m) {
-				lv[64 * m + lane] = make_ulonglong2(R.right[m][0], R.right[m][1]);
-				ballots[m][0]     = R.ballot[m][0];
-				ballots[m][1]     = R.ballot[m][1];
+				pvals[m][0]   = R.right[m][0];
+				pvals[m][1]   = R.right[m][1];
+				ballots[m][0] = R.ballot[m][0];
+				ballots[m][1] = R.ballot[m][1];
 				const int row     = 2 * m + (lane >> 5);
 				acc0 |= (static_cast<uint64_t>(R.idx[m][0]) & lmask) << (row * lbw);
 				acc1 |= (static_cast<uint64_t>(R.idx[m][1]) & lmask) << (row * lbw);
@@ -423,12 +426,19 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	// first as well, its look-back then finds more of its predecessors already posted.
 	PHASE_MARK(3);
 	PackedUnits packed_units;
-	wave_lds_sync(); // this wavefront's staged values
 #ifdef ALPGPU_ABLATE_PACK
 #pragma unroll
 	for (int t = 0; t < 8; ++t) { packed_units.acc[t] = ull2v{0ull, 0ull}; }
+#elif defined(ALPGPU_PACK_GATHER) // the round-2 form (A/B): values staged in natural order, every output word gathers its rows
+	{
+		ulonglong2* lv = reinterpret_cast<ulonglong2*>(L.vals);
+#pragma unroll
+		for (int m = 0; m < 8; ++m) { lv[64 * m + lane] = make_ulonglong2(pvals[m][0], pvals[m][1]); }
+		wave_lds_sync();
+		pack_u64_units(L.vals, d.bw, lane, packed_units);
+	}
 #else
-	pack_u64_units(L.vals, d.bw, lane, packed_units);
+	pack_u64_scatter(L.vals, pvals, d.bw, lane, packed_units);
 #endif
 	PHASE_MARK(4);
 	// Likewise the exception record: its image is laid out in the (now free) staging area, so that after the wait it leaves as a

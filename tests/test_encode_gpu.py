@@ -334,3 +334,41 @@ def test_exception_record_pad_bytes_are_zero_whatever_was_in_the_buffer(ctx, ora
         ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
     for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"two_pass={two_pass}: {what}"
+
+
+def _column_with_spoiled_samples(dtype, spoiled, n_vectors=212, seed=5):
+    """Two-decimal values; `spoiled` = {sampled vector index: how many of its first-level samples (values 32*s of vector 12*sv) are
+    replaced by full-mantissa noise, from sample 0 on} — in both rowgroups of the column."""
+    rng = np.random.default_rng(seed)
+    col = np.round(rng.uniform(-500.0, 500.0, n_vectors * 1024), 2).astype(dtype)
+    noise = (rng.random(n_vectors * 1024) * 3.0 + 1.0 / 3.0).astype(dtype)
+    for rg0 in range(0, n_vectors, 100):
+        for sv, n_bad in spoiled.items():
+            v = rg0 + 12 * sv
+            if v < n_vectors:
+                idx = v * 1024 + 32 * np.arange(n_bad)
+                col[idx] = noise[idx]
+    return col
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("spoiled", [{1: 32}, {0: 32, 3: 32}, {2: 20, 5: 24}, {1: 19, 4: 15, 6: 14}, {0: 32, 1: 32, 2: 32, 3: 32, 4: 32, 5: 32, 6: 32, 7: 28, 8: 20},
+                                     {i: 32 for i in range(9)}], ids=lambda d: "-".join(f"{k}x{v}" for k, v in d.items()))
+def test_rowgroups_whose_sampled_vectors_disagree(ctx, oracle, dtype, spoiled):
+    """Rowgroups in which some sampled vectors are noise (every candidate of the (e,f) search far above the ALP_RD threshold) and the others
+    decimals: the rowgroup is ALP all the same, and the noise vectors' votes — the cheapest of their hopeless candidates, ties by larger e
+    then larger f — still count towards k and the candidate order.  Half-spoiled sampled vectors (19 / 20 / 24 noise samples of 32) sit on
+    both sides of the threshold; all noise: ALP_RD.  (Written for an early-exit of the search that was measured and not kept,
+    profiles/r03_encode_levers.txt; kept as a parity case of its own.)"""
+    from oracle.pyoracle import OracleF32
+    np_dtype = np.float64 if dtype == "f64" else np.float32
+    col_np = _column_with_spoiled_samples(np_dtype, spoiled)
+    orc = oracle if dtype == "f64" else OracleF32()
+    want = layout.compact(orc.encode_column(col_np), 8 if dtype == "f64" else 4)
+    from alp_amd import capi
+    x = torch.from_numpy(col_np).cuda()
+    dcol = capi.DeviceColumn(col_np.size // 1024, 0, dtype=dtype)
+    ctx.encode(x, dcol)
+    ctx.synchronize()
+    for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{dtype} {spoiled}: {what}"
