@@ -81,18 +81,14 @@ __device__ __forceinline__ uint64_t fetch_exception(const DecodeLds& L, const ui
 	}
 }
 
-// exception lookup for the pair (128*m + 2*lane, +1): 2-bit hit mask and the rank of the first hit.  m is wave-uniform.
+// exception lookup for the pair (128*m + 2*lane, +1): 2-bit hit mask and the rank of the first hit.  m is wave-uniform.  The pair's mask
+// word is 4m + (lane >> 4): word and prefix come from the lane that holds them by ds_bpermute (the LDS crossbar, no memory) — as eight
+// readlanes and six selects per step this lookup was a quarter of the vector instructions of a vector with exceptions, and the consumers
+// (SUM / COUNT sinks) are bound by exactly those (profiles/r03_consumers.txt).
 __device__ __forceinline__ uint32_t exception_hits(const ExcMask& em, int m, int lane, int& rank) {
-	const int g = lane >> 4; // the pair's mask word is 4m + g
-	uint32_t  word = __builtin_amdgcn_readlane(em.word, 4 * m);
-	int       pref = __builtin_amdgcn_readlane(em.excl, 4 * m);
-#pragma unroll
-	for (int k = 1; k < 4; ++k) {
-		const uint32_t wk = __builtin_amdgcn_readlane(em.word, 4 * m + k);
-		const int      pk = __builtin_amdgcn_readlane(em.excl, 4 * m + k);
-		word              = g == k ? wk : word;
-		pref              = g == k ? pk : pref;
-	}
+	const int      src  = (4 * m + (lane >> 4)) << 2; // byte address of the source lane
+	const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(em.word)));
+	const int      pref = __builtin_amdgcn_ds_bpermute(src, em.excl);
 	const int      b0   = (2 * lane) & 31;
 	const uint32_t hits = (word >> b0) & 3u;
 	rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
@@ -135,13 +131,23 @@ __device__ __forceinline__ void consume_pair(double ox, double oy, double* acc, 
 
 // The per-vector constants, read in front of the barrier: ALP_RD = the rowgroup's dictionary (RdDict, alp_device.hpp); ALP vectors use
 // the same two words for lo = FACT_ARR[f], hi = bits of FRAC_ARR[e] — table reads that depend only on the descriptor.
-__device__ __forceinline__ RdDict load_vector_consts(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
-	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict(rgs, v, true); } // wave-uniform
-	return RdDict {static_cast<uint64_t>(kFactArr[d.f]), static_cast<uint64_t>(__double_as_longlong(kFracArr[d.e]))};
+// (plus, for ALP, 10^f as a double and the no-wrap limit of the conversion shortcut: every table read that depends on the descriptor is in
+// flight with the packed words instead of behind the barrier)
+struct VectorConsts {
+	uint64_t lo, hi;
+	uint64_t fact_d_bits, no_wrap;
+};
+__device__ __forceinline__ VectorConsts load_vector_consts(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
+	if (d.scheme != ALPGPU_SCHEME_ALP) { // wave-uniform
+		const RdDict r = load_rd_dict(rgs, v, true);
+		return VectorConsts {r.lo, r.hi, 0ull, 0ull};
+	}
+	return VectorConsts {static_cast<uint64_t>(kFactArr[d.f]), static_cast<uint64_t>(__double_as_longlong(kFracArr[d.e])),
+	                     static_cast<uint64_t>(__double_as_longlong(kExpArr[d.f])), kNoWrapLimit[d.f]};
 }
 
 template <bool NT_STORE, int SINK = kSinkStore>
-__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const RdDict& dict,
+__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const VectorConsts& dict,
                                                      const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
                                                      double range_lo = 0.0, double range_hi = 0.0) {
 	const int      bw       = d.bw;
@@ -163,11 +169,14 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 		//     i.e. the IEEE product  (double)value * 10^f,
 		// which replaces the 64-bit integer multiply and the software int64->double conversion (src/falp.cpp:114-121 does
 		// them per value) and yields the same bits.  Anything else takes the literal path.
-		const int64_t lo     = d.base;
-		const double  fact_d = kExpArr[d.f];
-		const bool    narrow = bw <= 50 && lo > -(1ll << 51) && lo < (1ll << 51) && lo + static_cast<int64_t>(mask) < (1ll << 51);
-		const double  maxabs = narrow ? __builtin_fmax(__builtin_fabs(static_cast<double>(lo)), __builtin_fabs(static_cast<double>(lo + static_cast<int64_t>(mask)))) : 0.0;
-		const bool    shortcut = narrow && maxabs * fact_d < 9.2233720368547e18;
+		// (decided in integers on wave-uniform values: as doubles — two software int64 -> double conversions, |.|, max, a product — the
+		//  decision alone was ~35 vector instructions per wavefront and vector)
+		const int64_t  lo       = d.base;
+		const int64_t  hi       = lo + static_cast<int64_t>(mask);
+		const double   fact_d   = __longlong_as_double(static_cast<long long>(dict.fact_d_bits));
+		const bool     narrow   = bw <= 50 && lo > -(1ll << 51) && lo < (1ll << 51) && hi < (1ll << 51);
+		const uint64_t alo      = static_cast<uint64_t>(lo < 0 ? -lo : lo), ahi = static_cast<uint64_t>(hi < 0 ? -hi : hi);
+		const bool     shortcut = narrow && (alo > ahi ? alo : ahi) <= dict.no_wrap;
 		const uint64_t kbits   = 0x4338000000000000ull + base;
 #pragma unroll
 		for (int mm = 0; mm < kStepsPerWave; ++mm) {
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		const uint64_t v = v0 + i < n_vectors ? v0 + i : v0; // the odd tail vector is simply loaded twice
 		d[i]             = descs[v];
 	}
-	RdDict dict[V];
+	VectorConsts dict[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
 #pragma unroll
