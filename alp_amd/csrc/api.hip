@@ -423,9 +423,13 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
 		const double n        = static_cast<double>(col->n_vectors);
 		const bool   hinted   = col->packed_bytes_hint != 0 || col->exc_bytes_hint != 0;
-		const bool   narrow   = static_cast<double>(col->packed_bytes_hint) <= 17.0 * 128.0 * n; // crossover measured between 16 and 18 bits (tools/sweep_vpw.py)
+		// Two vectors per workgroup pay off while the vectors are narrow: up to 17 packed bits per value without exceptions (crossover
+		// measured between 16 and 18, tools/sweep_vpw.py), up to 26 with ~2 or more exceptions per vector (between 24 and 28,
+		// tools/sweep_vpw_exc.py, profiles/r03_decode_floor_experiment.txt); wider vectors — every ALP_RD column — do better one per
+		// workgroup whatever their exceptions (ALP_RD column of bench.py: 0.82 against 0.73 of peak).
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
-		variant               = (variant & ~1) | ((hinted && (narrow || with_exc)) ? 0 : 1);
+		const bool   narrow   = static_cast<double>(col->packed_bytes_hint) <= (with_exc ? 26.0 : 17.0) * 128.0 * n;
+		variant               = (variant & ~1) | ((hinted && narrow) ? 0 : 1);
 	}
 	return variant;
 }

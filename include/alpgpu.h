@@ -144,8 +144,8 @@ int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 or 2 consecutive vectors per decode
  * workgroup, or 0 (default) = choose from the column's size hints: 2 keeps twice the bytes in flight and is faster for
- * narrow columns (average bit width <= 17) and for columns with exceptions, 1 for wide exception-free ones and when no
- * hint is present.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
+ * narrow columns (average packed width <= 17 bits; <= 26 bits when there are about two or more exceptions per vector),
+ * 1 for wider ones — every ALP_RD column — and when no hint is present.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
 #define ALPGPU_OPT_DECODE_VECTORS_PER_WG 1
 #define ALPGPU_OPT_DECODE_PLAIN_STORES 2
 /* ALPGPU_OPT_ENCODE_TWO_PASS: 1 = analysis pass + scan + pack pass (reads the input twice) instead of the default
