@@ -167,3 +167,37 @@ def adversarial_vectors_f32():
     a = (np.random.default_rng(6).integers(-2**24, 2**24, VEC)).astype(np.float32); cases["exact_integers"] = a
     a = np.random.default_rng(7).integers(0, 1 << 23, VEC).astype(np.uint32).view(np.float32).copy(); cases["denormals"] = a
     return cases
+
+
+def every_bit_width_column(n_vectors=208, seed=77, exceptions=True):
+    """ALP vectors of every packed width 0..64 inside ALP rowgroups.  The sampled vectors (index % 12 == 0 inside a rowgroup) hold
+    2^62 + 1024 m, m < 2^30: only (e,f) = (0,0) encodes them (times ten they leave int64) and their range needs 40 bits, so the rowgroup is
+    ALP with k = 1 and (0,0).  Under (0,0) every integer-valued double below 2^63 encodes exactly, so the other vectors choose their width:
+    vector j gets width (j mod 65) from integers B + m (m < 2^w, w <= 52) or multiples of 2^(w-52) spanning 2^w (w >= 53), extremes present;
+    with `exceptions`, every third vector also carries NaN / fraction / -0.0 values (exceptions, and the filler at their slots)."""
+    rng = np.random.default_rng(seed)
+    col = np.empty(n_vectors * 1024, np.float64)
+    for v in range(n_vectors):
+        o = v * 1024
+        if (v % 100) % 12 == 0:
+            col[o:o + 1024] = 2.0**62 + 1024.0 * rng.integers(0, 2**30, 1024).astype(np.float64)
+            continue
+        w = v % 65
+        if w == 0:
+            vals = np.full(1024, float(rng.integers(-2**40, 2**40)))
+        elif w <= 52:
+            base = int(rng.integers(-2**52, 2**52 - 2**w)) if w < 52 else -2**51
+            m = rng.integers(0, 2**w, 1024, dtype=np.uint64).astype(np.int64) if w < 63 else None
+            m[0], m[1] = 0, 2**w - 1
+            vals = (base + m).astype(np.float64)
+        else:
+            step = 2 ** (w - 52)
+            m = rng.integers(-2**51 + 1, 2**51, 1024)
+            m[0], m[1] = -2**51 + 1, 2**51 - 1  # range 2^52 - 2 steps: needs w bits (2^(w-1) < (2^52 - 2) * step < 2^w)
+            vals = m.astype(np.float64) * float(step)
+        rng.shuffle(vals)
+        if exceptions and v % 3 == 1:
+            idx = rng.choice(1024, int(rng.integers(1, 40)), replace=False)
+            vals[idx] = rng.choice([np.nan, 0.5, -0.0, 1e300, -2.5e-7], idx.size)
+        col[o:o + 1024] = vals
+    return col

@@ -372,3 +372,29 @@ def test_rowgroups_whose_sampled_vectors_disagree(ctx, oracle, dtype, spoiled):
     ctx.synchronize()
     for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{dtype} {spoiled}: {what}"
+
+
+@pytest.mark.parametrize("exceptions", [False, True], ids=["clean", "with_exceptions"])
+@pytest.mark.parametrize("route", ["single_pass", "two_pass"])
+def test_alp_vectors_of_every_packed_width(ctx, oracle, route, exceptions):
+    """ffor (src/fastlanes_generated_ffor.cpp) at every width 0..64 THROUGH the column encoders — the single pass packs by scattering each
+    lane's pairs into an LDS image (encode_device.hpp: pack_u64_scatter), the two-pass route by gathering per output word — on vectors
+    whose width is chosen freely under an (e,f) = (0,0) rowgroup state the reference's search itself arrives at (datagen)."""
+    from alp_amd import capi
+    col_np = datagen.every_bit_width_column(exceptions=exceptions)
+    want_o = oracle.encode_column(col_np)
+    assert sorted(set(want_o["bw"].tolist())) == list(range(65)) and (want_o["scheme"] == 2).all()
+    want = layout.compact(want_o)
+    ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 1 if route == "two_pass" else 0)
+    try:
+        dcol, x = gpu_encode(ctx, col_np)
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
+    for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{route}: {what}"
+    for vpw in (1, 2):
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+        out = ctx.decode(dcol)
+        ctx.synchronize()
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+        assert torch.equal(out.view(torch.int64), x.view(torch.int64)), f"decode, {vpw} vectors per workgroup"
