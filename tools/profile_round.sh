@@ -6,17 +6,22 @@
 #   encf: python tools/prof_encode_f32.py decimal1 1048576             (k_rowgroup_init<f32>, k_encode_fused_f32) + float decode
 #   encrd: python tools/prof_encode.py rd 1048576                      (the all-ALP_RD encode)
 #   cons: python tools/prof_consumers.py 0 1048576                     (k_decode_column<2, false, kSinkSum>, then k_consume_column: the fused SUM consumer, both shapes)
-#   narrow: python tools/time_one.py 8:1048576                         (k_decode_column<2, true>: the two-vectors-per-workgroup decode of a narrow column)
+#   narrow: python tools/time_one.py 8:1048576:2                         (k_decode_column<2, true>: the two-vectors-per-workgroup decode of a narrow column)
 # raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_* (run the summary LOCALLY on the
 # merged directory, and remove a stale local gpurun_out/<tag>_prof first: rocprofv3 names its files after process ids, a second run
 # does not overwrite the first)
-TAG=$1
+# tools/profile_round.sh <tag> <name>... re-runs only the named commands (into the same directory; fetch the directory back and summarize again)
+TAG=$1; shift
+ONLY="$*"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${TAG}_prof
-rm -rf $OUT; mkdir -p $OUT
+if [ -z "$ONLY" ]; then rm -rf $OUT; fi
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, command...
   name=$1; shift
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi
+  rm -rf $OUT/${name}_stats $OUT/${name}_fetch $OUT/${name}_write
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_stats -- "$@" > $OUT/${name}_stats.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${name}_fetch -- "$@" > $OUT/${name}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${name}_write -- "$@" > $OUT/${name}_write.log 2>&1
@@ -26,7 +31,7 @@ run enc python $ROOT/tools/prof_encode.py mixed 1048576
 run encf python $ROOT/tools/prof_float.py 1048576
 run encrd python $ROOT/tools/prof_encode.py rd 1048576
 run cons python $ROOT/tools/prof_consumers.py 0 1048576
-run narrow python $ROOT/tools/time_one.py 8:1048576
+run narrow python $ROOT/tools/time_one.py 8:1048576:2
 cd $ROOT
-grep -h '"metric"' $OUT/dec_stats.log | tail -1 > $OUT/bench_under_rocprof.json
+if [ -f $OUT/dec_stats.log ]; then grep -h '"metric"' $OUT/dec_stats.log | tail -1 > $OUT/bench_under_rocprof.json; fi
 python tools/summarize_round.py $TAG $OUT

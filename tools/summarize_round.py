@@ -23,7 +23,7 @@ def short(name):
 
 
 cmds = {"dec": "python bench.py --steps 20 --warmup 10 --no-extras", "enc": "python tools/prof_encode.py mixed 1048576", "encf": "python tools/prof_float.py 1048576",
-        "encrd": "python tools/prof_encode.py rd 1048576", "cons": "python tools/prof_consumers.py 0 1048576", "narrow": "python tools/time_one.py 8:1048576"}
+        "encrd": "python tools/prof_encode.py rd 1048576", "cons": "python tools/prof_consumers.py 0 1048576", "narrow": "python tools/time_one.py 8:1048576:2"}
 with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w") as w:
     w.write(f"# rocprofv3 --kernel-trace --stats --output-format csv; library sha256[:16] = {sha}; tree = {head}\n")
     w.write("Command,Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
@@ -32,7 +32,7 @@ with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w") as w:
         if not fs:
             continue
         for r in csv.DictReader(open(fs[0])):
-            if "alpgpu" in r["Name"] or any(k in r["Name"] for k in ("k_rowgroup_init", "k_scan", "k_encode", "k_decode", "k_consume", "k_fused", "k_tree_sum")):
+            if "alpgpu::" in r["Name"]:
                 w.write(",".join([json.dumps(cmd), json.dumps(short(r["Name"]))] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
 print(open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read())
 
@@ -47,7 +47,7 @@ for key, cmd in cmds.items():
             continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(fs[0])):
-            if r["Counter_Name"] == ctr and ("alpgpu" in r["Kernel_Name"] or any(k in r["Kernel_Name"] for k in ("k_rowgroup_init", "k_encode", "k_decode", "k_consume"))):
+            if r["Counter_Name"] == ctr and "alpgpu::" in r["Kernel_Name"]:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             res.setdefault(k, {})[ctr + "_KB_mean"] = sum(v) / len(v)

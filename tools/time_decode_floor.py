@@ -12,7 +12,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 19
 ctx = capi.Context(0)
 out = torch.empty(n * 1024, dtype=torch.float64, device="cuda")
 sums = torch.empty(n, dtype=torch.float64, device="cuda")
-print("lib", os.environ.get("ALPGPU_LIB", "default"))
+vpw = int(os.environ.get("VPW", "0"))  # hand-built columns carry no size hints: 0 = one vector per workgroup for all of them
+ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+print("lib", os.environ.get("ALPGPU_LIB", "default"), "vectors per workgroup:", vpw or "auto (1 without hints)")
 for bw, exc in [(1, 0), (2, 0), (3, 0), (4, 0), (8, 0), (16, 0), (28, 0), (48, 0), (16, 20), (28, 20), (28, 100), (16, 200)]:
     col, rec = make_column(n, bw, exc, seed=bw)
     ms, mn = timeit(lambda: ctx.decode(col, out), iters=9, warmup=3)
