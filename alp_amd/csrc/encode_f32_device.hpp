@@ -268,6 +268,40 @@ __device__ __forceinline__ void pack_u32_units(const EncodeLdsF32& L, int bw, in
 		P.acc[t] = acc;
 	}
 }
+// The packing as a scatter from the registers that hold the values (encode_device.hpp: pack_u64_scatter): lane l holds, for m = 0..3, the
+// quad (row 8m + l/8, columns 4(l%8) .. +3) — shifted to its place in stream word k = (row * bw) >> 5 and OR-ed into the wavefront-private
+// image in LDS (ds_or_b32), upper bits of a straddling row into word k + 1; the image is read back as this lane's units.
+// vals[m][j] = value - base (< 2^bw); `image`: 4 KiB of wavefront-private LDS.
+__device__ __forceinline__ void pack_u32_scatter(uint32_t* image, const uint32_t (&vals)[4][4], int bw, int lane, PackedUnitsF32& P) {
+	u32x4*    img4    = reinterpret_cast<u32x4*>(image);
+	const int n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		if (64 * t < n_units) { img4[lane + 64 * t] = u32x4 {0u, 0u, 0u, 0u}; } // wave-uniform; whole 1-KiB blocks (the image has room for 256 units)
+	}
+	if (bw > 0) {
+		const uint32_t p0 = static_cast<uint32_t>(lane >> 3) * static_cast<uint32_t>(bw);
+		uint32_t*      wa = image + 4 * (lane & 7);
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			const uint32_t p = p0 + static_cast<uint32_t>(8 * m) * static_cast<uint32_t>(bw); // bit position of row 8m + l/8 in its column's stream
+			const uint32_t k = p >> 5, s = p & 31u;
+			uint32_t*      w = wa + 32 * k; // unit 8k + a
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { __hip_atomic_fetch_or(w + j, vals[m][j] << s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+			if (s + static_cast<uint32_t>(bw) > 32u) { // the row's upper bits belong to word k + 1 (s >= 1 here)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { __hip_atomic_fetch_or(w + 32 + j, vals[m][j] >> (32u - s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+			}
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		u32x4 acc = {0u, 0u, 0u, 0u};
+		if (64 * t < n_units) { acc = img4[lane + 64 * t]; }
+		P.acc[t] = acc;
+	}
+}
 __device__ __forceinline__ void store_packed_units_f32(const PackedUnitsF32& P, int bw, u32x4* __restrict__ out, int lane) {
 	const int n_units = 8 * bw;
 #pragma unroll

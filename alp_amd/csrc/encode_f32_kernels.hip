@@ -70,6 +70,9 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	alpgpu_vector_desc d;
 	uint64_t           lacc[4] = {0, 0, 0, 0}; // ALP_RD: packed left streams of this lane's four lane64 columns
 	uint64_t           ballots[4][4];
+	uint32_t           pvals[4][4]; // what gets packed: value - base (ALP), right parts (ALP_RD)
+#pragma unroll
+	for (int m = 0; m < 4; ++m) { pvals[m][0] = pvals[m][1] = pvals[m][2] = pvals[m][3] = 0u; }
 	int                cnt = 0;
 	d.packed_off = d.exc_off = 0;
 	d.base                   = 0;
@@ -90,7 +93,6 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	if (live) {
 		x        = load_vector_f32(in, v, lane);
 		d.scheme = rgp->scheme;
-		u32x4* lv = reinterpret_cast<u32x4*>(L.vals);
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
 			if (rgp->k > 1) {
@@ -112,7 +114,8 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 					q[j]          = static_cast<uint32_t>(R.enc[m][j]) - base;
 					ballots[m][j] = R.ballot[m][j];
 				}
-				lv[64 * m + lane] = q;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { pvals[m][j] = q[j]; }
 			}
 		} else {
 			// rd.hpp:109-147: right = bits & mask, left = bits >> rbw; left -> dictionary index, not found = exception.
@@ -150,7 +153,8 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 					cnt += __builtin_popcountll(ballots[m][j]);
 					lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
 				}
-				lv[64 * m + lane] = q;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { pvals[m][j] = q[j]; }
 			}
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
@@ -178,8 +182,17 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	}
 	// pack into registers while the ordered offset is on its way (see k_encode_fused)
 	PackedUnitsF32 packed_units;
-	wave_lds_sync();
-	pack_u32_units(L, d.bw, lane, packed_units);
+#ifdef ALPGPU_PACK_GATHER // the round-2 form (A/B): values staged in natural order, every output word gathers its rows
+	{
+		u32x4* lv = reinterpret_cast<u32x4*>(L.vals);
+#pragma unroll
+		for (int m = 0; m < 4; ++m) { lv[64 * m + lane] = u32x4 {pvals[m][0], pvals[m][1], pvals[m][2], pvals[m][3]}; }
+		wave_lds_sync();
+		pack_u32_units(L, d.bw, lane, packed_units);
+	}
+#else
+	pack_u32_scatter(reinterpret_cast<uint32_t*>(L.vals), pvals, d.bw, lane, packed_units);
+#endif
 	// the exception record's image goes to the (now free) staging area and leaves as contiguous stores after the wait, see
 	// k_encode_fused: values always fit (4 B x 1024), the positions follow them when the whole record does (<= 682 exceptions;
 	// always for ALP_RD), else they are written from the ballots after the wait.  Pad bytes are zero.
