@@ -102,9 +102,6 @@ __device__ __constant__ const int64_t kFactArr[19] = {1LL,
                                                       100000000000000000LL,
                                                       1000000000000000000LL};
 
-// floor((2^63 - 1) / 10^f): the largest |integer| whose product with FACT_ARR[f] stays inside int64 (decode_kernels.hip: conversion shortcut)
-__device__ __constant__ const uint64_t kNoWrapLimit[19] = {9223372036854775807ull, 922337203685477580ull, 92233720368547758ull, 9223372036854775ull, 922337203685477ull, 92233720368547ull, 9223372036854ull, 922337203685ull, 92233720368ull, 9223372036ull, 922337203ull, 92233720ull, 9223372ull, 922337ull, 92233ull, 9223ull, 922ull, 92ull, 9ull};
-
 constexpr double kMagic      = 6755399441055744.0;     // 2^52 + 2^51, constants.hpp:70
 constexpr double kUpperLimit = 9223372036854774784.0;  // constants.hpp:17
 constexpr double kLowerLimit = -9223372036854774784.0; // constants.hpp:18

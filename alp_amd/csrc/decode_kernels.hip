@@ -68,17 +68,28 @@ __device__ __forceinline__ ExcMask load_exception_mask(const DecodeLds& L, int l
 	return m;
 }
 
-// the value of the exception of that rank: staged (LDS) or, past the stage, from HBM
+// the value of the exception of that rank: staged (LDS) or, past the stage, from HBM.  all_staged (wave-uniform: the vector's count fits the
+// stage) keeps the common case to the LDS read alone — written as "LDS if rank < kStaged else HBM" the compiler selects between the two
+// ADDRESSES and issues one flat load (slower, and it waits for every counter).
 template <int VAL_BYTES>
-__device__ __forceinline__ uint64_t fetch_exception(const DecodeLds& L, const uint8_t* __restrict__ rec, int rank) {
+__device__ __forceinline__ uint64_t fetch_exception(const DecodeLds& L, const uint8_t* __restrict__ rec, int rank, bool all_staged) {
 	constexpr int kStaged = static_cast<int>(kExcStageBytes) / VAL_BYTES;
+	const int     at      = rank < kStaged ? rank : kStaged - 1;
+	uint64_t      v;
 	if constexpr (VAL_BYTES == 8) {
-		if (rank < kStaged) { return reinterpret_cast<const uint64_t*>(L.excv)[rank]; }
-		return reinterpret_cast<const uint64_t*>(rec)[rank];
+		v = reinterpret_cast<const uint64_t*>(L.excv)[at];
+		asm volatile("" : "+v"(v)); // keeps the two loads two loads
+		if (!all_staged) {
+			if (rank >= kStaged) { v = reinterpret_cast<const uint64_t*>(rec)[rank]; }
+		}
 	} else {
-		if (rank < kStaged) { return reinterpret_cast<const uint16_t*>(L.excv)[rank]; }
-		return reinterpret_cast<const uint16_t*>(rec)[rank];
+		v = reinterpret_cast<const uint16_t*>(L.excv)[at];
+		asm volatile("" : "+v"(v)); // keeps the two loads two loads
+		if (!all_staged) {
+			if (rank >= kStaged) { v = reinterpret_cast<const uint16_t*>(rec)[rank]; }
+		}
 	}
+	return v;
 }
 
 // exception lookup for the pair (128*m + 2*lane, +1): 2-bit hit mask and the rank of the first hit.  m is wave-uniform.  The pair's mask
@@ -129,21 +140,57 @@ __device__ __forceinline__ void consume_pair(double ox, double oy, double* acc, 
 	}
 }
 
+// One table for everything the ALP decode reads by descriptor: entry i = {FACT_ARR[i], 10^i as a double, the conversion shortcut's bound for
+// f = i, FRAC_ARR[i]} — one address computation on the scalar unit instead of four (the decode kernels run eight wavefronts per SIMD, each
+// repeating the same wave-uniform prologue, and the scalar unit is what saturates first: profiles/r03_consumers.txt).  The bound is
+// min(2^51 - 1, floor((2^63 - 1) / 10^i)): the largest |integer| that is exact as a double in the shortcut's range AND whose product with
+// 10^i stays inside int64.  Literals as in alp_device.hpp (constants.hpp:66-154).
+struct DecodeTabEntry {
+	int64_t  fact;
+	double   fact_d;
+	uint64_t shortcut_bound;
+	double   frac;
+};
+__device__ __constant__ const DecodeTabEntry kDecodeTab[21] = {
+    {1ll, 1.0, 2251799813685247ull, 1.0},
+    {10ll, 10.0, 2251799813685247ull, 0.1},
+    {100ll, 100.0, 2251799813685247ull, 0.01},
+    {1000ll, 1000.0, 2251799813685247ull, 0.001},
+    {10000ll, 10000.0, 922337203685477ull, 0.0001},
+    {100000ll, 100000.0, 92233720368547ull, 0.00001},
+    {1000000ll, 1000000.0, 9223372036854ull, 0.000001},
+    {10000000ll, 10000000.0, 922337203685ull, 0.0000001},
+    {100000000ll, 100000000.0, 92233720368ull, 0.00000001},
+    {1000000000ll, 1000000000.0, 9223372036ull, 0.000000001},
+    {10000000000ll, 10000000000.0, 922337203ull, 0.0000000001},
+    {100000000000ll, 100000000000.0, 92233720ull, 0.00000000001},
+    {1000000000000ll, 1000000000000.0, 9223372ull, 0.000000000001},
+    {10000000000000ll, 10000000000000.0, 922337ull, 0.0000000000001},
+    {100000000000000ll, 100000000000000.0, 92233ull, 0.00000000000001},
+    {1000000000000000ll, 1000000000000000.0, 9223ull, 0.000000000000001},
+    {10000000000000000ll, 10000000000000000.0, 922ull, 0.0000000000000001},
+    {100000000000000000ll, 100000000000000000.0, 92ull, 0.00000000000000001},
+    {1000000000000000000ll, 1000000000000000000.0, 9ull, 0.000000000000000001},
+    {0ll, 0.0, 0ull, 0.0000000000000000001},
+    {0ll, 0.0, 0ull, 0.00000000000000000001},
+};
+
 // The per-vector constants, read in front of the barrier: ALP_RD = the rowgroup's dictionary (RdDict, alp_device.hpp); ALP vectors use
 // the same two words for lo = FACT_ARR[f], hi = bits of FRAC_ARR[e] — table reads that depend only on the descriptor.
 // (plus, for ALP, 10^f as a double and the no-wrap limit of the conversion shortcut: every table read that depends on the descriptor is in
 // flight with the packed words instead of behind the barrier)
 struct VectorConsts {
 	uint64_t lo, hi;
-	uint64_t fact_d_bits, no_wrap;
+	uint64_t fact_d_bits, shortcut_bound;
 };
 __device__ __forceinline__ VectorConsts load_vector_consts(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
 	if (d.scheme != ALPGPU_SCHEME_ALP) { // wave-uniform
 		const RdDict r = load_rd_dict(rgs, v, true);
 		return VectorConsts {r.lo, r.hi, 0ull, 0ull};
 	}
-	return VectorConsts {static_cast<uint64_t>(kFactArr[d.f]), static_cast<uint64_t>(__double_as_longlong(kFracArr[d.e])),
-	                     static_cast<uint64_t>(__double_as_longlong(kExpArr[d.f])), kNoWrapLimit[d.f]};
+	const DecodeTabEntry& by_f = kDecodeTab[d.f];
+	return VectorConsts {static_cast<uint64_t>(by_f.fact), static_cast<uint64_t>(__double_as_longlong(kDecodeTab[d.e].frac)),
+	                     static_cast<uint64_t>(__double_as_longlong(by_f.fact_d)), by_f.shortcut_bound};
 }
 
 template <bool NT_STORE, int SINK = kSinkStore>
@@ -152,6 +199,7 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
                                                      double range_lo = 0.0, double range_hi = 0.0) {
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
+	const bool     all_staged = cnt <= static_cast<int>(kExcStageBytes) / (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2); // wave-uniform
 	ExcMask        em {0u, 0};
 	if (cnt > 0) { em = load_exception_mask(L, lane); }
 	const int      a        = lane & 7;
@@ -169,40 +217,45 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 		//     i.e. the IEEE product  (double)value * 10^f,
 		// which replaces the 64-bit integer multiply and the software int64->double conversion (src/falp.cpp:114-121 does
 		// them per value) and yields the same bits.  Anything else takes the literal path.
-		// (decided in integers on wave-uniform values: as doubles — two software int64 -> double conversions, |.|, max, a product — the
-		//  decision alone was ~35 vector instructions per wavefront and vector)
+		// (decided in integers on wave-uniform values against ONE table entry, kDecodeTab: as doubles — two software int64 -> double
+		//  conversions, |.|, max, a product — the decision alone was ~35 vector instructions per wavefront and vector)
 		const int64_t  lo       = d.base;
-		const int64_t  hi       = lo + static_cast<int64_t>(mask);
+		const int64_t  bound    = static_cast<int64_t>(dict.shortcut_bound); // <= 2^51 - 1
 		const double   fact_d   = __longlong_as_double(static_cast<long long>(dict.fact_d_bits));
-		const bool     narrow   = bw <= 50 && lo > -(1ll << 51) && lo < (1ll << 51) && hi < (1ll << 51);
-		const uint64_t alo      = static_cast<uint64_t>(lo < 0 ? -lo : lo), ahi = static_cast<uint64_t>(hi < 0 ? -hi : hi);
-		const bool     shortcut = narrow && (alo > ahi ? alo : ahi) <= dict.no_wrap;
+		// |lo| <= bound first: lo + mask cannot overflow then (mask < 2^50); lo <= lo + mask, so the two ends bound everything between
+		const bool     shortcut = bw <= 50 && lo >= -bound && lo <= bound && static_cast<int64_t>(static_cast<uint64_t>(lo) + mask) <= bound;
 		const uint64_t kbits   = 0x4338000000000000ull + base;
-#pragma unroll
-		for (int mm = 0; mm < kStepsPerWave; ++mm) {
-			const int     m = kStepsPerWave * wave + mm;
-			const U64Pair u = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
-			double        ox, oy;
-			if (shortcut) { // wave-uniform
-				ox = ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac;
-				oy = ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac;
-			} else {
-				ox = decode_value(static_cast<int64_t>(u.x + base), fact, frac);
-				oy = decode_value(static_cast<int64_t>(u.y + base), fact, frac);
-			}
+		// what follows the conversion of a pair: exceptions patched in, then the sink
+		auto finish_pair = [&](int m, double ox, double oy) {
 			if (cnt > 0) {
 				int            rank;
 				const uint32_t hits = exception_hits(em, m, lane, rank);
 				if (hits & 1u) {
-					ox = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank)));
+					ox = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, all_staged)));
 					++rank;
 				}
-				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank))); }
+				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, all_staged))); }
 			}
 			if constexpr (SINK != kSinkStore) {
 				consume_pair<SINK>(ox, oy, acc, range_lo, range_hi);
 			} else {
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
+			}
+		};
+		if (shortcut) { // wave-uniform; ONE branch per vector, not one per step (scalar instructions are the scarce ones here)
+#pragma unroll
+			for (int mm = 0; mm < kStepsPerWave; ++mm) {
+				const int     m = kStepsPerWave * wave + mm;
+				const U64Pair u = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
+				finish_pair(m, ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac,
+				            ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac);
+			}
+		} else {
+#pragma unroll
+			for (int mm = 0; mm < kStepsPerWave; ++mm) {
+				const int     m = kStepsPerWave * wave + mm;
+				const U64Pair u = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
+				finish_pair(m, decode_value(static_cast<int64_t>(u.x + base), fact, frac), decode_value(static_cast<int64_t>(u.y + base), fact, frac));
 			}
 		}
 	} else {
@@ -233,10 +286,10 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 				int            rank;
 				const uint32_t hits = exception_hits(em, m, lane, rank);
 				if (hits & 1u) {
-					l0 = fetch_exception<2>(L, rec, rank);
+					l0 = fetch_exception<2>(L, rec, rank, all_staged);
 					++rank;
 				}
-				if (hits & 2u) { l1 = fetch_exception<2>(L, rec, rank); }
+				if (hits & 2u) { l1 = fetch_exception<2>(L, rec, rank, all_staged); }
 			}
 			const double ox = __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x));
 			const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
@@ -335,41 +388,48 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	__syncthreads();
 
 	if constexpr (SINK != kSinkStore) {
-		// per-vector sums: lane partial (step order) -> adjacent-lane tree per wavefront -> (w0 + w1) + (w2 + w3)
-		// (counts take the same route; they are small integers, so the order does not matter)
-		__shared__ double s_part[V][kDecWaves];
+		// Per-vector sums: lane partial (step order) in each of the four wavefronts -> the four partials of a lane position combined as
+		// (w0 + w1) + (w2 + w3) -> ONE adjacent-lane tree over the 64 results, by one wavefront per vector.  (Counts take the same route; they
+		// are small integers, so the order does not matter.)  Until late in round 3 every wavefront ran its own tree first: 18 of the ~125
+		// vector instructions per wavefront and vector of a kernel whose VALU is 100 % busy (profiles/r03_consumers.txt).  The lane partials
+		// travel through the vectors' packed-word stages, which every wavefront is done with behind the barrier below.
+		double acc[V];
 #pragma unroll
 		for (int i = 0; i < V; ++i) {
-			double acc = 0.0;
+			acc[i] = 0.0;
 			if (v0 + i < n_vectors) {
 				if constexpr (SINK == kSinkProbe) {
 					const int       n_units = 8 * (d[i].bw + (d[i].scheme == ALPGPU_SCHEME_ALP ? 0 : d[i].lbw));
 					const uint64_t* st      = reinterpret_cast<const uint64_t*>(L[i].stage);
 					uint64_t        sum     = 0;
 					for (int c = tid; c < n_units; c += 64 * kDecWaves) { sum += st[2 * c] + st[2 * c + 1]; }
-					acc = static_cast<double>(sum & 0xFFFFFu);
+					acc[i] = static_cast<double>(sum & 0xFFFFFu);
 				} else {
-					decode_staged_vector<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, wave, lane, &acc, lo, hi);
+					decode_staged_vector<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, wave, lane, &acc[i], lo, hi);
 				}
 			}
-			// the wavefront's 64 lane partials: balanced tree over adjacent lanes (DPP, alp_device.hpp) — round 2 used a ds_bpermute butterfly
-			// here, 12 LDS round trips and ~30 vector instructions per vector in a kernel that is VALU-bound (profiles/r03_consumers.txt)
-			acc = wave_tree_sum_f64(acc);
-			if (lane == 0) { s_part[i][wave] = acc; }
 		}
+		__syncthreads(); // nobody reads packed words any more
+		static_assert(kStageBytes >= 8 * 64 * kDecWaves, "the lane partials of a vector fit its stage");
+#pragma unroll
+		for (int i = 0; i < V; ++i) { reinterpret_cast<double*>(L[i].stage)[64 * wave + lane] = acc[i]; }
 		__syncthreads();
-		if (tid < V && v0 + tid < n_vectors) {
+		if (wave < V && v0 + wave < n_vectors) { // wave-uniform: wavefront w finishes vector w
+			const double* part = reinterpret_cast<const double*>(L[wave].stage) + lane;
 #ifdef ALPGPU_EXPERIMENT_DEC_WAVES // timing experiments with another number of wavefronts per vector: the sums follow another order
 			double total = 0.0;
-			for (int w = 0; w < kDecWaves; ++w) { total += s_part[tid][w]; }
+			for (int w = 0; w < kDecWaves; ++w) { total += part[64 * w]; }
 #else
 			static_assert(kDecWaves == 4, "the documented summation order is for 4 wavefronts per vector");
-			const double total = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
+			double total = (part[0] + part[64]) + (part[128] + part[192]);
 #endif
-			if constexpr (SINK == kSinkCount) {
-				reinterpret_cast<uint32_t*>(out)[v0 + tid] = static_cast<uint32_t>(total);
-			} else {
-				out[v0 + tid] = total;
+			total = wave_tree_sum_f64(total); // balanced tree over adjacent lanes (DPP, alp_device.hpp)
+			if (lane == 0) {
+				if constexpr (SINK == kSinkCount) {
+					reinterpret_cast<uint32_t*>(out)[v0 + wave] = static_cast<uint32_t>(total);
+				} else {
+					out[v0 + wave] = total;
+				}
 			}
 		}
 		return;

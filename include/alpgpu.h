@@ -271,10 +271,11 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out);
 /* Decode fused into a consumer (the SCAN/SUM shape of the reference's end-to-end bench,
  * publication/source_code/bench_end_to_end/src/benchmarks/alp/queries/q1.cpp:63-104): d_sums[v] = sum of the 1024 decoded
  * values of vector v, exceptions patched in; the doubles themselves never reach HBM.  Summation order (so that the result can
- * be reproduced bit for bit): wavefront q of 4 owns values 256q..256q+255; lane L adds its values 256q+2L, +1, 256q+128+2L, +1
- * in that order starting from +0.0; the 64 lane sums of a wavefront combine by a balanced binary tree over ADJACENT lanes —
- * (0,1), (2,3), ...; then (0..1, 2..3), ...; six levels (round 3; round 2 used a butterfly, partner L^32 first) — and the four
- * wavefront sums as (w0 + w1) + (w2 + w3). */
+ * be reproduced bit for bit): wavefront q of 4 owns values 256q..256q+255; lane L of it adds its values 256q+2L, +1, 256q+128+2L,
+ * +1 in that order starting from +0.0, giving p[q][L]; then s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]) for L = 0..63; then the
+ * 64 s[L] combine by a balanced binary tree over ADJACENT lanes — (0,1), (2,3), ...; then (0..1, 2..3), ...; six levels.
+ * (Earlier in round 3 each wavefront ran that tree over its own 64 partials first and the four results were combined last; round 2
+ * used a butterfly.  The order is a property of the library version: tests/test_decode_sum_gpu.py holds the host replica.) */
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 /* The other consumer named there, a predicate pushed into the scan: d_counts[v] = number of decoded values x of vector v with
  * lo <= x <= hi (exceptions patched in; NaN never qualifies; -0.0 == 0.0 as in C).  Nothing but 4 bytes per vector is written. */

@@ -19,7 +19,8 @@ def pairwise_tree(p):
 
 def host_sums(values):
     """values [n, 1024] -> the order documented in include/alpgpu.h: wavefront q of 4 owns values 256q..256q+255; lane L adds
-    256q+2L, +1, 256q+128+2L, +1 in that order from +0.0; adjacent-lane tree over the 64 lane sums; (w0 + w1) + (w2 + w3)"""
+    256q+2L, +1, 256q+128+2L, +1 in that order from +0.0 -> p[q][L]; s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); adjacent-lane
+    tree over the 64 s[L]"""
     n = values.shape[0]
     v = values.reshape(n, 4, 2, 64, 2)  # vector, wavefront q, step mm, lane L, pair element
     p = np.zeros((n, 4, 64))
@@ -27,8 +28,8 @@ def host_sums(values):
         for mm in range(2):
             p = p + v[:, :, mm, :, 0]
             p = p + v[:, :, mm, :, 1]
-        w = pairwise_tree(p)
-        return (w[:, 0] + w[:, 1]) + (w[:, 2] + w[:, 3])
+        s = (p[:, 0] + p[:, 1]) + (p[:, 2] + p[:, 3])
+        return pairwise_tree(s)
 
 
 def host_sums_pipelined(values):
