@@ -47,7 +47,7 @@ class CColumn(C.Structure):
     _fields_ = [
         ("n_vectors", C.c_uint64), ("n_rowgroups", C.c_uint64), ("d_rowgroups", C.c_void_p), ("d_vectors", C.c_void_p),
         ("d_packed", C.c_void_p), ("packed_capacity", C.c_uint64), ("d_exc", C.c_void_p), ("exc_capacity", C.c_uint64),
-        ("d_totals", C.c_void_p), ("packed_bytes_hint", C.c_uint64), ("exc_bytes_hint", C.c_uint64), ("d_rd_order", C.c_void_p),
+        ("d_totals", C.c_void_p), ("packed_bytes_hint", C.c_uint64), ("exc_bytes_hint", C.c_uint64), ("d_rd_order", C.c_void_p), ("alp_rd_rowgroups_hint", C.c_uint64),
     ]
 
 
@@ -529,6 +529,7 @@ class DeviceColumn:
         col.totals[0] = packed.size
         col.totals[1] = exc.size
         col.c.packed_bytes_hint, col.c.exc_bytes_hint = packed.size, exc.size
+        col.c.alp_rd_rowgroups_hint = 1 + int((rowgroups["scheme"] == SCHEME_ALP_RD).sum())
         return col
 
     def to_host(self):

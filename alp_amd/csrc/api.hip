@@ -191,7 +191,8 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		ctx->async_init = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_CONSUMER_PIPELINED:
-		ctx->pipelined_consumer = value ? 1 : 0;
+		if (value < 0 || value > 3) { return fail(ALPGPU_ERR_INVALID, "consumer kernel: 0 (chosen per column), 1 (persistent LDS-ring kernel), 2 (one wavefront per vector, no stage) or 3 (four wavefronts per vector)"); }
+		ctx->pipelined_consumer = static_cast<int>(value);
 		return ALPGPU_OK;
 	default:
 		return fail(ALPGPU_ERR_INVALID, "unknown option");
@@ -462,12 +463,25 @@ int alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, u
 	return ALPGPU_OK;
 }
 
+// which kernel computes the per-vector sums (ALPGPU_OPT_CONSUMER_PIPELINED)
+// 0 (default): one wavefront per vector when the column is known to hold no ALP_RD rowgroup (alp_rd_rowgroups_hint == 1), else the staged
+// four-wavefront kernel — the one-wavefront kernel runs ALP_RD vectors a quarter at a time out of too few registers (3.7 x slower on an
+// all-ALP_RD column); 1: the persistent LDS-ring kernel; 2 / 3: force the one-wavefront / the four-wavefront kernel.
+static bool use_direct_sink(const alpgpu_ctx* ctx, const alpgpu_column* col) {
+	return ctx->pipelined_consumer == 2 || (ctx->pipelined_consumer == 0 && col->alp_rd_rowgroups_hint == 1);
+}
+static int sum_launch(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
+	if (ctx->pipelined_consumer == 1) { return alpgpu::launch_consume_sum(ctx->stream, col, d_sums, ctx->n_cus); }
+	if (use_direct_sink(ctx, col)) { return alpgpu::launch_sink_direct(ctx->stream, col, 0.0, 0.0, d_sums, false); }
+	return alpgpu::launch_decode_sum(ctx->stream, col, d_sums, 2);
+}
+
 int alpgpu_decode_sum_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	const int rc = ctx->pipelined_consumer ? alpgpu::launch_consume_sum(ctx->stream, col, d_sums, ctx->n_cus) : alpgpu::launch_decode_sum(ctx->stream, col, d_sums, 2);
+	const int rc = sum_launch(ctx, col, d_sums);
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode-sum launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
@@ -487,7 +501,7 @@ static int column_sum(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_total
 	if (int rc = ensure_workspace(ctx, 8ull * (n + 2 * l1) + 64)) { return rc; }
 	double* sums = static_cast<double*>(ctx->workspace);
 	int     rc   = f32 ? alpgpu::launch_decode_sum_f32(ctx->stream, col, sums)
-	                   : (ctx->pipelined_consumer ? alpgpu::launch_consume_sum(ctx->stream, col, sums, ctx->n_cus) : alpgpu::launch_decode_sum(ctx->stream, col, sums, 2));
+	                   : sum_launch(ctx, col, sums);
 	if (rc == ALPGPU_OK) { rc = alpgpu::launch_tree_sum(ctx->stream, sums, n, sums + n, d_total); }
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "column-sum launch failed", hipGetLastError()); }
 	return workspace_used(ctx);
@@ -511,8 +525,9 @@ int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, dou
 	if (!col || (!d_counts && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	const int rc = ctx->pipelined_consumer ? alpgpu::launch_consume_count_range(ctx->stream, col, lo, hi, d_counts, ctx->n_cus)
-	                                       : alpgpu::launch_decode_count_range(ctx->stream, col, lo, hi, d_counts);
+	const int rc = ctx->pipelined_consumer == 1 ? alpgpu::launch_consume_count_range(ctx->stream, col, lo, hi, d_counts, ctx->n_cus)
+	               : use_direct_sink(ctx, col)  ? alpgpu::launch_sink_direct(ctx->stream, col, lo, hi, d_counts, true)
+	                                            : alpgpu::launch_decode_count_range(ctx->stream, col, lo, hi, d_counts);
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
@@ -782,6 +797,12 @@ static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
 	col->packed_bytes_hint = h.packed_bytes;
 	col->exc_bytes_hint    = h.exc_bytes;
+	{
+		uint64_t n_rd = 0;
+		const alpgpu_rowgroup_state* rgs_h = reinterpret_cast<const alpgpu_rowgroup_state*>(p);
+		for (uint64_t r = 0; r < h.n_rowgroups; ++r) { n_rd += rgs_h[r].scheme == ALPGPU_SCHEME_ALP_RD ? 1 : 0; }
+		col->alp_rd_rowgroups_hint = 1 + n_rd;
+	}
 	if (n_values) { *n_values = h.n_values; }
 	return ALPGPU_OK;
 }
@@ -817,10 +838,13 @@ int alpgpu_column_validate(alpgpu_ctx* ctx, const alpgpu_column* col, int value_
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col) { return fail(ALPGPU_ERR_INVALID, "null column"); }
-	uint64_t t[4] = {0, 0, 0, 0};
+	uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	if (col->d_totals) {
+		const bool count_rd = col->d_rowgroups != nullptr && col->n_rowgroups != 0;
+		if (count_rd && alpgpu::launch_count_rd_rowgroups(ctx->stream, col, col->d_totals + 7) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "rowgroup count launch failed", hipGetLastError()); }
 		ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
 		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+		col->alp_rd_rowgroups_hint = count_rd ? 1 + t[7] : (col->n_vectors == 0 ? 1 : 0);
 	} else if (col->n_vectors != 0) {
 		return fail(ALPGPU_ERR_INVALID, "column without d_totals");
 	}

@@ -37,6 +37,9 @@ namespace alpgpu {
 #endif
 constexpr int kDecWaves     = ALPGPU_DEC_WAVES; // wavefronts cooperating on one vector
 constexpr int kStepsPerWave = 8 / kDecWaves;
+#ifndef ALPGPU_DECODE_BATCH
+#define ALPGPU_DECODE_BATCH 4 // steps whose words are requested together (decode_vector_quarters)
+#endif
 constexpr int kStageBytes   = 8704; // >= 63*128 (RD right) + 3*128 (RD left) + 128 pad, and >= 64*128 + 128 (ALP bw 64)
 constexpr int kExcStage     = 128;  // 8-byte exception values staged in LDS per vector (512 2-byte ALP_RD ones); the rest are read from HBM on use
 constexpr uint32_t kExcStageBytes = 8u * kExcStage;
@@ -54,7 +57,8 @@ struct ExcMask {
 	uint32_t word; // mask word (lane & 31)
 	int      excl; // exceptions in words 0 .. (lane & 31) - 1
 };
-__device__ __forceinline__ ExcMask load_exception_mask(const DecodeLds& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ ExcMask load_exception_mask(const LDS& L, int lane) {
 	ExcMask   m;
 	m.word  = L.mask[lane & 31];
 	const int c = lane < 32 ? __builtin_popcount(m.word) : 0;
@@ -71,8 +75,8 @@ __device__ __forceinline__ ExcMask load_exception_mask(const DecodeLds& L, int l
 // the value of the exception of that rank: staged (LDS) or, past the stage, from HBM.  all_staged (wave-uniform: the vector's count fits the
 // stage) keeps the common case to the LDS read alone — written as "LDS if rank < kStaged else HBM" the compiler selects between the two
 // ADDRESSES and issues one flat load (slower, and it waits for every counter).
-template <int VAL_BYTES>
-__device__ __forceinline__ uint64_t fetch_exception(const DecodeLds& L, const uint8_t* __restrict__ rec, int rank, bool all_staged) {
+template <int VAL_BYTES, class LDS>
+__device__ __forceinline__ uint64_t fetch_exception(const LDS& L, const uint8_t* __restrict__ rec, int rank, bool all_staged) {
 	constexpr int kStaged = static_cast<int>(kExcStageBytes) / VAL_BYTES;
 	const int     at      = rank < kStaged ? rank : kStaged - 1;
 	uint64_t      v;
@@ -193,19 +197,65 @@ __device__ __forceinline__ VectorConsts load_vector_consts(const alpgpu_rowgroup
 	                     static_cast<uint64_t>(__double_as_longlong(by_f.fact_d)), by_f.shortcut_bound};
 }
 
-template <bool NT_STORE, int SINK = kSinkStore>
-__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const VectorConsts& dict,
-                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
-                                                     double range_lo = 0.0, double range_hi = 0.0) {
+// Where the packed words of a vector are read from: the workgroup's LDS stage (the column kernels), or HBM directly (k_sink_direct).
+struct WordPair {
+	ulonglong2 w0, w1;
+};
+struct StagedWords {
+	const uint8_t* stage;
+	__device__ __forceinline__ WordPair pair(int i) const { // units i and i + 8: stream words k and k + 1 of a column pair
+		return WordPair {reinterpret_cast<const ulonglong2*>(stage)[i], reinterpret_cast<const ulonglong2*>(stage)[i + 8]};
+	}
+	__device__ __forceinline__ uint2 left_pair(int rbw, int i) const { // left words i and i + 32
+		return make_uint2(reinterpret_cast<const uint32_t*>(stage + 128 * rbw)[i], reinterpret_cast<const uint32_t*>(stage + 128 * rbw)[i + 32]);
+	}
+};
+struct BufferWords { // HBM through buffer loads: the resources are sized to the vector's packed words, so reads past its last unit / last left
+	// word return 0 (what the unpack reads there is masked off anyway) without a clamp per load, and the second unit of a pair is the
+	// first one's address with an immediate offset
+	__amdgpu_buffer_rsrc_t units, lefts;
+	__device__ __forceinline__ WordPair pair(int i) const {
+		typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+		const uint32_t at = static_cast<uint32_t>(i) * 16u;
+		const u32x4    a = __builtin_amdgcn_raw_buffer_load_b128(units, at, 0, 0);
+		const u32x4    b = __builtin_amdgcn_raw_buffer_load_b128(units, at, 128, 0); // unit i + 8: the same address register, a scalar offset
+		return WordPair {make_ulonglong2((static_cast<uint64_t>(a[1]) << 32) | a[0], (static_cast<uint64_t>(a[3]) << 32) | a[2]),
+		                 make_ulonglong2((static_cast<uint64_t>(b[1]) << 32) | b[0], (static_cast<uint64_t>(b[3]) << 32) | b[2])};
+	}
+	__device__ __forceinline__ uint2 left_pair(int, int i) const {
+		const uint32_t at = static_cast<uint32_t>(i) * 4u;
+		return make_uint2(__builtin_amdgcn_raw_buffer_load_b32(lefts, at, 0, 0), __builtin_amdgcn_raw_buffer_load_b32(lefts, at, 128, 0));
+	}
+};
+
+// N_Q consecutive quarters of one vector, from quarter q0 on (a quarter = steps kStepsPerWave q .. + kStepsPerWave - 1 = what one wavefront of a
+// four-wavefront workgroup does; the sinks accumulate quarter q0 + i into acc[i]).  `em` = the vector's exception mask as this wavefront sees
+// it (ignored when the vector has none), L = where staged exception values live.
+// ONLY: 0 = either scheme (decided from the descriptor), 1 = the caller knows the vector is ALP, 2 = ALP_RD (only that arm is compiled in).
+template <bool NT_STORE, int SINK, int N_Q, int ONLY = 0, class LDS, class WORDS>
+__device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS& units, const alpgpu_vector_desc& d, const VectorConsts& dict, const ExcMask& em,
+                                                      const uint8_t* __restrict__ rec, double2* __restrict__ dst, int q0, int lane, double* acc,
+                                                       double range_lo, double range_hi) {
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
 	const bool     all_staged = cnt <= static_cast<int>(kExcStageBytes) / (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2); // wave-uniform
-	ExcMask        em {0u, 0};
-	if (cnt > 0) { em = load_exception_mask(L, lane); }
 	const int      a        = lane & 7;
 	const int      r0       = lane >> 3;
-	const UnitsPtr units {reinterpret_cast<const ulonglong2*>(L.stage)};
-	if (d.scheme == ALPGPU_SCHEME_ALP) {
+	// The pair (row, columns 2a, 2a + 1) out of its two stream words (alp_device.hpp: unpack_pair_u64), in two halves: the reads of a whole
+	// batch of steps are requested before the first of them is used — with the words in HBM (k_sink_direct) every step is otherwise its own
+	// dependent round trip.
+	constexpr int kSteps = N_Q * kStepsPerWave;
+	constexpr int kBatch = kSteps < ALPGPU_DECODE_BATCH ? kSteps : ALPGPU_DECODE_BATCH;
+	constexpr int kBatchRd = ONLY == 2 ? 1 : (kSteps < 2 ? kSteps : 2); // ALP_RD keeps the left words and the dictionary selects in registers as well
+	auto request = [&](int width, int row) { return units.pair(8 * ((row * width) >> 6) + a); };
+	auto extract = [&](int width, uint64_t wmask, int row, const WordPair w) {
+		const int s = (row * width) & 63;
+		U64Pair   r;
+		r.x = ((w.w0.x >> s) | ((w.w1.x << 1) << (63 - s))) & wmask; // (w1 << (64 - s)) without the undefined shift by 64 when s == 0
+		r.y = ((w.w0.y >> s) | ((w.w1.y << 1) << (63 - s))) & wmask;
+		return r;
+	};
+	if (ONLY == 1 || (ONLY == 0 && d.scheme == ALPGPU_SCHEME_ALP)) {
 		const uint64_t base = static_cast<uint64_t>(d.base);
 		const int64_t  fact = static_cast<int64_t>(dict.lo);
 		const double   frac = __longlong_as_double(static_cast<long long>(dict.hi));
@@ -226,7 +276,7 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 		const bool     shortcut = bw <= 50 && lo >= -bound && lo <= bound && static_cast<int64_t>(static_cast<uint64_t>(lo) + mask) <= bound;
 		const uint64_t kbits   = 0x4338000000000000ull + base;
 		// what follows the conversion of a pair: exceptions patched in, then the sink
-		auto finish_pair = [&](int m, double ox, double oy) {
+		auto finish_pair = [&](int m, double ox, double oy, double* acc_q) {
 			if (cnt > 0) {
 				int            rank;
 				const uint32_t hits = exception_hits(em, m, lane, rank);
@@ -237,25 +287,38 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, all_staged))); }
 			}
 			if constexpr (SINK != kSinkStore) {
-				consume_pair<SINK>(ox, oy, acc, range_lo, range_hi);
+				consume_pair<SINK>(ox, oy, acc_q, range_lo, range_hi);
 			} else {
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
 			}
 		};
 		if (shortcut) { // wave-uniform; ONE branch per vector, not one per step (scalar instructions are the scarce ones here)
 #pragma unroll
-			for (int mm = 0; mm < kStepsPerWave; ++mm) {
-				const int     m = kStepsPerWave * wave + mm;
-				const U64Pair u = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
-				finish_pair(m, ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac,
-				            ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac);
+			for (int b = 0; b < kSteps; b += kBatch) {
+				WordPair w[kBatch];
+#pragma unroll
+				for (int i = 0; i < kBatch; ++i) { w[i] = request(bw, 8 * (kStepsPerWave * q0 + b + i) + r0); }
+#pragma unroll
+				for (int i = 0; i < kBatch; ++i) {
+					const int     m = kStepsPerWave * q0 + b + i;
+					const U64Pair u = extract(bw, mask, 8 * m + r0, w[i]);
+					finish_pair(m, ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac,
+					            ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac, acc + (b + i) / kStepsPerWave);
+				}
 			}
 		} else {
 #pragma unroll
-			for (int mm = 0; mm < kStepsPerWave; ++mm) {
-				const int     m = kStepsPerWave * wave + mm;
-				const U64Pair u = unpack_pair_u64(units, bw, mask, 8 * m + r0, a);
-				finish_pair(m, decode_value(static_cast<int64_t>(u.x + base), fact, frac), decode_value(static_cast<int64_t>(u.y + base), fact, frac));
+			for (int b = 0; b < kSteps; b += kBatch) {
+				WordPair w[kBatch];
+#pragma unroll
+				for (int i = 0; i < kBatch; ++i) { w[i] = request(bw, 8 * (kStepsPerWave * q0 + b + i) + r0); }
+#pragma unroll
+				for (int i = 0; i < kBatch; ++i) {
+					const int     m = kStepsPerWave * q0 + b + i;
+					const U64Pair u = extract(bw, mask, 8 * m + r0, w[i]);
+					finish_pair(m, decode_value(static_cast<int64_t>(u.x + base), fact, frac), decode_value(static_cast<int64_t>(u.y + base), fact, frac),
+					            acc + (b + i) / kStepsPerWave);
+				}
 			}
 		}
 	} else {
@@ -267,17 +330,23 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 		const uint64_t mask = bw_mask(rbw);
 		const uint32_t lmsk = (1u << lbw) - 1u;
 		const uint64_t dlo = dict.lo, dhi = dict.hi;
-		const uint32_t* lsrc = reinterpret_cast<const uint32_t*>(L.stage + 128 * rbw);
 #pragma unroll
-		for (int mm = 0; mm < kStepsPerWave; ++mm) {
-			const int      m   = kStepsPerWave * wave + mm;
-			const U64Pair  u   = unpack_pair_u64(units, rbw, mask, 8 * m + r0, a);
-			const int      row = 2 * m + (lane >> 5);
-			const int      p   = row * lbw;
-			const int      k   = p >> 4;
-			const int      s   = p & 15;
-			const uint32_t w0  = lsrc[32 * k + (lane & 31)];
-			const uint32_t w1  = lsrc[32 * k + 32 + (lane & 31)];
+		for (int b = 0; b < kSteps; b += kBatchRd) {
+		WordPair rw[kBatchRd];
+		uint2    lw[kBatchRd];
+#pragma unroll
+		for (int i = 0; i < kBatchRd; ++i) {
+			const int m = kStepsPerWave * q0 + b + i;
+			rw[i]       = request(rbw, 8 * m + r0);
+			lw[i]       = units.left_pair(rbw, 32 * (((2 * m + (lane >> 5)) * lbw) >> 4) + (lane & 31));
+		}
+#pragma unroll
+		for (int i = 0; i < kBatchRd; ++i) {
+			const int      m   = kStepsPerWave * q0 + b + i;
+			double*        acc_q = acc + (b + i) / kStepsPerWave;
+			const U64Pair  u   = extract(rbw, mask, 8 * m + r0, rw[i]);
+			const int      s   = ((2 * m + (lane >> 5)) * lbw) & 15;
+			const uint32_t w0 = lw[i].x, w1 = lw[i].y;
 			const uint32_t i0  = (((w0 & 0xFFFFu) >> s) | ((w1 & 0xFFFFu) << (16 - s))) & lmsk;
 			const uint32_t i1  = (((w0 >> 16) >> s) | ((w1 >> 16) << (16 - s))) & lmsk;
 			uint64_t       l0  = ((i0 < 4 ? dlo >> (16 * i0) : dhi >> (16 * (i0 & 3))) & 0xFFFFull);
@@ -294,12 +363,24 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 			const double ox = __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x));
 			const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
 			if constexpr (SINK != kSinkStore) {
-				consume_pair<SINK>(ox, oy, acc, range_lo, range_hi);
+				consume_pair<SINK>(ox, oy, acc_q, range_lo, range_hi);
 			} else {
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
 			}
 		}
+		if constexpr (ONLY == 2) { asm volatile("" ::: "memory"); } // (k_sink_direct) the next step's requests stay behind this one's use
+		} // batch
 	}
+}
+
+// one wavefront's share of a staged vector (the column kernels: four wavefronts per vector)
+template <bool NT_STORE, int SINK = kSinkStore>
+__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const VectorConsts& dict,
+                                                     const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
+                                                     double range_lo = 0.0, double range_hi = 0.0) {
+	ExcMask em {0u, 0};
+	if (d.exc_cnt > 0) { em = load_exception_mask(L, lane); }
+	decode_vector_quarters<NT_STORE, SINK, 1>(L, StagedWords {L.stage}, d, dict, em, rec, dst, wave, lane, acc, range_lo, range_hi);
 }
 
 // Issues every load of one vector: packed words and the values of its exceptions straight into LDS (global_load_lds, 16 resp. 4 bytes per
@@ -441,6 +522,97 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 			                               reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
 		}
 	}
+}
+
+// ---- the sinks with ONE wavefront per vector, packed words read from HBM as they are needed (no stage, no barrier) ---------------------
+// What the four-wavefront sinks run out of is instruction issue — the scalar unit first, the VALU right behind — because every wavefront of a
+// workgroup repeats the wave-uniform prologue of both its vectors (profiles/r03_consumers.txt).  Here a wavefront owns a vector: one
+// prologue per vector, no cross-wavefront reduction, no barrier; without a stage its LDS is the exception mask and values only (1.2 KiB), so
+// eight wavefronts per SIMD stay resident and hide the two dependent round trips (descriptor -> packed words) between them.  A lane reads
+// the two 16-byte units of each of its eight pairs straight from HBM (buffer loads bounded to the vector's words): 16 loads per wavefront
+// whatever the width; the 64 lanes of a load touch 8 runs of 128 bytes.  Results are bit-identical to k_decode_column's sinks: the lane keeps the four quarter partials p[q][L] apart,
+// then (p0 + p1) + (p2 + p3), then the adjacent-lane tree (include/alpgpu.h).
+#ifndef ALPGPU_SINK_DIRECT_OCC
+#define ALPGPU_SINK_DIRECT_OCC 8 // wavefronts per SIMD the register budget is sized for (8 -> <= 64 VGPRs; measured against 5 and 6: profiles/r03_consumers.txt)
+#endif
+struct SinkWaveLds {
+	uint32_t mask[32];
+	uint8_t  excv[kExcStageBytes];
+};
+template <int SINK>
+__global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink_direct(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                   const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
+                                                                   uint64_t n_vectors, uint64_t wg_offset, double lo, double hi) {
+	__shared__ SinkWaveLds S[kDecWaves];
+	const int      lane = static_cast<int>(threadIdx.x) & 63;
+	const int      wave = wave_in_wg();
+	const uint64_t v    = (wg_offset + blockIdx.x) * kDecWaves + wave;
+	if (v >= n_vectors) { return; } // wave-uniform; no barrier anywhere in this kernel
+	SinkWaveLds&             L    = S[wave];
+	const alpgpu_vector_desc d    = descs[v];
+	const VectorConsts       dict = load_vector_consts(rgs, v, d);
+	const uint8_t*           rec  = excs + d.exc_off;
+	const bool               is_alp = d.scheme == ALPGPU_SCHEME_ALP;
+	const int                cnt  = d.exc_cnt;
+	ExcMask                  em {0u, 0};
+	if (cnt > 0) { // wave-uniform: values of the first kExcStage exceptions by LDS-DMA, the mask from the positions
+		const uint32_t val_bytes = (is_alp ? 8u : 2u) * static_cast<uint32_t>(cnt);
+		const int      dwords    = static_cast<int>(((val_bytes < kExcStageBytes ? val_bytes : kExcStageBytes) + 3u) >> 2);
+		for (int q = 0; 64 * q < dwords; ++q) { // wave-uniform trip count; LDS destination = wave-uniform base + 4 * lane
+			if (64 * q + lane < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + 64 * q + lane, reinterpret_cast<uint32_t*>(L.excv) + 64 * q, 4, 0, 0); }
+		}
+		if (lane < 32) { L.mask[lane] = 0u; }
+		wave_lds_sync();
+		const uint16_t* poss = reinterpret_cast<const uint16_t*>(rec + val_bytes);
+		for (int j = lane; j < cnt; j += 64) {
+			const uint32_t p = poss[j];
+			atomicOr(&L.mask[p >> 5], 1u << (p & 31u));
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd values (LDS-DMA completion is not tracked through the LDS for the compiler)
+		wave_lds_sync();
+		em = load_exception_mask(L, lane);
+	}
+	uint8_t*          first   = const_cast<uint8_t*>(packed + d.packed_off);
+	constexpr int     kRsrcFlags = 0x00020000; // gfx9 raw buffer, 32-bit data format
+	const BufferWords words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d.bw, kRsrcFlags),
+	                         __builtin_amdgcn_make_buffer_rsrc(first + 128u * d.bw, 0, is_alp ? 0 : 128 * d.lbw, kRsrcFlags)};
+	double part[kDecWaves] = {0.0, 0.0, 0.0, 0.0};
+	if (is_alp) { // wave-uniform
+		decode_vector_quarters<false, SINK, kDecWaves, 1>(L, words, d, dict, em, rec, nullptr, 0, lane, part, lo, hi);
+	} else {
+		// ALP_RD a quarter at a time: the right AND left words of eight steps in flight at once do not fit this kernel's 64 registers (built that
+		// way it spilled them and ran 3.7 x slower than the staged kernel on an all-ALP_RD column)
+#pragma unroll
+		for (int q = 0; q < kDecWaves; ++q) {
+			decode_vector_quarters<false, SINK, 1, 2>(L, words, d, dict, em, rec, nullptr, q, lane, &part[q], lo, hi);
+			asm volatile("" ::: "memory"); // the next quarter's requests stay behind this one's use
+		}
+	}
+	static_assert(kDecWaves == 4, "the documented summation order is for 4 quarters per vector");
+	double total = (part[0] + part[1]) + (part[2] + part[3]);
+	total        = wave_tree_sum_f64(total);
+	if (lane == 0) {
+		if constexpr (SINK == kSinkCount) {
+			reinterpret_cast<uint32_t*>(out)[v] = static_cast<uint32_t>(total);
+		} else {
+			out[v] = total;
+		}
+	}
+}
+
+int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, double hi, void* d_out, bool count) {
+	const uint64_t n        = col->n_vectors;
+	const uint64_t n_wg     = (n + kDecWaves - 1) / kDecWaves;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
+		if (count) {
+			hipLaunchKernelGGL((k_sink_direct<kSinkCount>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, lo, hi);
+		} else {
+			hipLaunchKernelGGL((k_sink_direct<kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, 0.0, 0.0);
+		}
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus) {

@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void k_validate_column(const alpgpu_vector_des
 	if (!ok) { atomicMin(first_bad, static_cast<unsigned long long>(v)); }
 }
 
+// How many rowgroups of the column are ALP_RD: one workgroup, *count written once (alpgpu_column_totals -> alpgpu_column::alp_rd_rowgroups_hint)
+__global__ __launch_bounds__(256) void k_count_rd_rowgroups(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t n_rowgroups, uint64_t* __restrict__ count) {
+	__shared__ unsigned int s_n;
+	if (threadIdx.x == 0) { s_n = 0u; }
+	__syncthreads();
+	unsigned int mine = 0u;
+	for (uint64_t r = threadIdx.x; r < n_rowgroups; r += 256) { mine += rgs[r].scheme == ALPGPU_SCHEME_ALP_RD ? 1u : 0u; }
+	if (mine) { atomicAdd(&s_n, mine); }
+	__syncthreads();
+	if (threadIdx.x == 0) { *count = s_n; }
+}
+int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint64_t* d_count) {
+	hipLaunchKernelGGL(k_count_rd_rowgroups, dim3(1), dim3(256), 0, stream, col->d_rowgroups, col->n_rowgroups, d_count);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
 int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_t value_bytes, unsigned long long* d_first_bad) {
 	const uint64_t n = col->n_vectors;
 	hipLaunchKernelGGL(k_validate_column, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, col->d_vectors, col->d_rowgroups, col->d_exc, n,

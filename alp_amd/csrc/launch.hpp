@@ -11,6 +11,8 @@ namespace alpgpu {
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus);
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg);
 int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
+// the same sinks, one wavefront per vector, packed words straight from HBM (no stage, no barrier); count = false: per-vector sums (double), true: counts (u32)
+int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, double hi, void* d_out, bool count);
 int launch_decode_sum_f32(hipStream_t stream, const alpgpu_column* col, double* d_sums);
 int launch_decode_count_range_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
 
@@ -21,6 +23,7 @@ int launch_tree_sum(hipStream_t stream, const double* d_in, uint64_t n, double* 
 
 // guard_kernels.hip
 int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_t value_bytes, unsigned long long* d_first_bad);
+int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint64_t* d_count);
 
 // init_kernels.hip
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first = 0,

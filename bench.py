@@ -103,6 +103,7 @@ def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=N
     col.totals[0] = packed_bytes
     col.totals[1] = n_vectors * rec
     col.c.packed_bytes_hint, col.c.exc_bytes_hint = packed_bytes, n_vectors * rec  # what alpgpu_column_totals would report
+    col.c.alp_rd_rowgroups_hint = 1  # ... "no ALP_RD rowgroup": the fused consumers choose their kernel by it
     # algorithmic bytes per launch: read 128*bw + 10*exc + 13, write 8192, per vector
     alg_bytes = int((128 * bw + 10 * exc_per_vec + 13 + 8192).sum())
     return col, vec, alg_bytes
@@ -654,6 +655,11 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     pmed, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 10)
     ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
     extras["decode_sum_fused"]["pipelined_kernel_option"] = {"ms": round(pmed, 3), "roofline_frac_algorithmic": frac(read_bytes, pmed)}
+    # the staged four-wavefront kernel (the default until late in round 3; still what columns with ALP_RD rowgroups take)
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 3)
+    fmed, _ = time_launches(lambda: ctx.decode_sum(col, sums), 7, 10)
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
+    extras["decode_sum_fused"]["four_wavefronts_per_vector_kernel"] = {"ms": round(fmed, 3), "roofline_frac_algorithmic": frac(read_bytes, fmed)}
     del sums, tot, cnts
     # encode legs (BASELINE.json configs[2], configs[3]): rowgroup init + vector encode, input resident in HBM
     enc_cpu = None

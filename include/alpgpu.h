@@ -116,7 +116,8 @@ typedef struct alpgpu_column {
 	uint64_t               exc_capacity;    /* bytes; worst case n_vectors * 10240 */
 	uint64_t*              d_totals;        /* [8]: [0] packed bytes used, [1] exception bytes used, [2] overflow flag, [3] look-back stall flag of the
 	                                           single-pass encode (always 0 once alpgpu_encode_* has drained: the recovery route clears it),
-	                                           [4..5] running totals of the encode launch in flight, [6] recovery gate (latched from [3]), [7] unused */
+	                                           [4..5] running totals of the encode launch in flight, [6] recovery gate (latched from [3]),
+	                                           [7] ALP_RD rowgroups as last counted by alpgpu_column_totals */
 	/* host-side hints (0 = unknown): stream sizes as last seen by the host.  Filled by alpgpu_column_totals and
 	 * alpgpu_column_from_blob; decode uses them only to pick its launch shape (ALPGPU_OPT_DECODE_VECTORS_PER_WG = 0 "auto") */
 	uint64_t               packed_bytes_hint;
@@ -128,6 +129,10 @@ typedef struct alpgpu_column {
 	 * carry the dictionary size.  No decoder reads these bits; a table that does not start with the rowgroup's dictionary
 	 * (e.g. states supplied by the caller) is ignored. */
 	uint16_t*              d_rd_order;
+	/* host-side hint (ABI version 3; zero-initialise it): 0 = unknown, else 1 + the number of ALP_RD rowgroups of the column, as counted by
+	 * alpgpu_column_totals (a small kernel over d_rowgroups) or alpgpu_column_from_blob.  The fused consumers (alpgpu_decode_sum_f64, ...)
+	 * take their one-wavefront-per-vector kernel when it says "none" and the staged four-wavefront kernel otherwise. */
+	uint64_t               alp_rd_rowgroups_hint;
 } alpgpu_column;
 #define ALPGPU_RD_ORDER_STRIDE 296u
 
@@ -162,13 +167,18 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * 2 = beside the encode for float columns as well (measured slower there: the float tiles leave the search no room).  Results are
  * identical in every mode. */
 #define ALPGPU_OPT_ENCODE_ASYNC_INIT 6
-/* ALPGPU_OPT_CONSUMER_PIPELINED: 1 = alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 / alpgpu_column_sum_f64 through the
- * persistent, software-pipelined kernel of alp_amd/csrc/consume_kernels.hip (one wavefront per vector, packed words, exception
- * records and descriptors prefetched into per-wavefront LDS rings by LDS-DMA) instead of the default (one short-lived workgroup per
- * two vectors).  Measured in round 3: the consumers are VALU-bound, not latency-bound — the default executes 506 vector instructions
- * per vector at 83 % VALU utilisation; the pipelined form needs 362-408 but keeps 16 wavefronts per CU and ends within +-5 % of the
- * default (profiles/r03_consumers.txt) — so it stays an option.  Its summation order is its own: lane L adds its 16 values
- * 128m + 2L, 128m + 2L + 1 (m = 0..7) in ascending order from +0.0, then the adjacent-lane tree over the 64 lane sums. */
+/* ALPGPU_OPT_CONSUMER_PIPELINED: which kernel runs alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 / alpgpu_column_sum_f64.
+ * 0 (default) = chosen per column: ONE wavefront per vector, packed words read straight from HBM with bounded buffer loads (no LDS stage,
+ *     no barrier, one wave-uniform prologue per vector, eight wavefronts per SIMD) when the column is known to hold no ALP_RD rowgroup
+ *     (alpgpu_column::alp_rd_rowgroups_hint == 1), else the staged kernel of 3; both give the same bits (the order documented at
+ *     alpgpu_decode_sum_f64);
+ * 2 / 3 = force the one-wavefront kernel / the staged one (four wavefronts per vector, one short-lived workgroup per two vectors);
+ * 1 = the persistent, software-pipelined kernel of alp_amd/csrc/consume_kernels.hip (one wavefront per vector, packed words, exception
+ *     records and descriptors prefetched into per-wavefront LDS rings by LDS-DMA).  Its summation order is its own: lane L adds its 16
+ *     values 128m + 2L, 128m + 2L + 1 (m = 0..7) in ascending order from +0.0, then the adjacent-lane tree over the 64 lane sums.
+ * Measured in round 3 (profiles/r03_consumers.txt): what the staged kernel runs out of is instruction issue, the scalar unit first; the
+ * one-wavefront kernel does a quarter of its scalar work per vector and is 15-30 % faster on ALP columns, but spills on ALP_RD vectors
+ * (3.7 x slower on an all-ALP_RD column), hence the per-column choice; the ring kernel is slower than both. */
 #define ALPGPU_OPT_CONSUMER_PIPELINED 5
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode

@@ -45,11 +45,13 @@ def host_sums_pipelined(values):
         return pairwise_tree(p)
 
 
-@pytest.fixture(params=["default", "pipelined"])
+@pytest.fixture(params=["default", "pipelined", "one_wavefront_per_vector", "four_wavefronts_per_vector"])
 def shape(request, ctx):
-    """both kernels behind alpgpu_decode_sum_f64 / _count_range_f64 / alpgpu_column_sum_f64, each with its documented order"""
+    """the kernels behind alpgpu_decode_sum_f64 / _count_range_f64 / alpgpu_column_sum_f64, each with its documented order: the default
+    picks between the one-wavefront and the four-wavefront kernel per column (no ALP_RD rowgroup known / otherwise), and those two give the
+    same bits"""
     from alp_amd import capi
-    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 1 if request.param == "pipelined" else 0)
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, {"default": 0, "pipelined": 1, "one_wavefront_per_vector": 2, "four_wavefronts_per_vector": 3}[request.param])
     yield host_sums_pipelined if request.param == "pipelined" else host_sums
     ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
 
@@ -262,3 +264,19 @@ def test_decode_count_range_f32_matches_numpy(ctx, of32, name):
         with np.errstate(invalid="ignore"):
             want = ((v >= lo32) & (v <= hi32)).sum(axis=1)
         assert np.array_equal(got.cpu().numpy().astype(np.int64), want), (name, lo, hi)
+
+
+def test_alp_rd_rowgroup_count_reaches_the_column_hint(ctx):
+    """alpgpu_column_totals counts the column's ALP_RD rowgroups on the device (d_totals[7]) and leaves 1 + that in alp_rd_rowgroups_hint:
+    what the fused consumers choose their kernel by"""
+    col_np = np.concatenate([datagen.decimal_column(200, 2, seed=1), datagen.rd_column(200, seed=2), datagen.decimal_column(70, 1, seed=3)])
+    x = torch.from_numpy(col_np).cuda()
+    dcol = ctx.encode(x)
+    ctx.synchronize()
+    ctx.column_totals(dcol)
+    rg = dcol.to_host()[0]
+    n_rd = int((rg["scheme"] == 1).sum())
+    assert n_rd >= 1 and dcol.c.alp_rd_rowgroups_hint == 1 + n_rd
+    clean = ctx.encode(torch.from_numpy(datagen.decimal_column(120, 2, seed=4)).cuda())
+    ctx.column_totals(clean)
+    assert clean.c.alp_rd_rowgroups_hint == 1
