@@ -5,7 +5,7 @@
 #   enc : python tools/prof_encode.py mixed 1048576                    (k_rowgroup_init, k_encode_fused)
 #   encf: python tools/prof_encode_f32.py decimal1 1048576             (k_rowgroup_init<f32>, k_encode_fused_f32) + float decode
 #   encrd: python tools/prof_encode.py rd 1048576                      (the all-ALP_RD encode)
-#   cons: python tools/prof_consumers.py 0 1048576                     (k_decode_column<2, false, kSinkSum>, then k_consume_column: the fused SUM consumer, both shapes)
+#   cons: python tools/prof_consumers.py 0 1048576                     (k_sink_direct, k_decode_column<2, false, kSinkSum>, k_consume_column: the fused SUM consumer, all three kernels)
 #   narrow: python tools/time_one.py 8:1048576:2                         (k_decode_column<2, true>: the two-vectors-per-workgroup decode of a narrow column)
 # raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_* (run the summary LOCALLY on the
 # merged directory, and remove a stale local gpurun_out/<tag>_prof first: rocprofv3 names its files after process ids, a second run
