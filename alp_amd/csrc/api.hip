@@ -68,7 +68,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 extern "C" {
 
-int alpgpu_abi_version(void) { return 2; } // 2: alpgpu_column.d_rd_order
+int alpgpu_abi_version(void) { return 3; } // 2: alpgpu_column.d_rd_order; 3: alpgpu_column.alp_rd_rowgroups_hint
 
 const char* alpgpu_last_error(void) { return g_err; }
 

@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
 def test_record_sizes_match_header():
     from alp_amd import capi
     assert capi.ROWGROUP_DTYPE.itemsize == 32 and capi.VECTOR_DTYPE.itemsize == 32
-    assert ctypes.sizeof(capi.CColumn) == 96  # ABI version 2: + d_rd_order
-    assert capi.lib.alpgpu_abi_version() == 2
+    assert ctypes.sizeof(capi.CColumn) == 104  # ABI version 3: + alp_rd_rowgroups_hint (version 2: + d_rd_order, 96)
+    assert capi.lib.alpgpu_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():
