@@ -344,6 +344,7 @@ static int encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
+	col->alp_rd_rowgroups_hint = 0; // the column is being rewritten: unknown until alpgpu_column_totals counts again
 	if (n_vectors == 0) {
 		if (col->d_totals) { ALPGPU_HIP(hipMemsetAsync(col->d_totals, 0, 64, ctx->stream)); }
 		return ALPGPU_OK;
@@ -895,6 +896,7 @@ static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vec
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_in && n_vectors) { return fail(ALPGPU_ERR_INVALID, "null input"); }
 	if (int rc = check_column(col, n_vectors)) { return rc; }
+	col->alp_rd_rowgroups_hint = 0; // the column is being rewritten: unknown until alpgpu_column_totals counts again
 	if (n_vectors == 0) {
 		if (col->d_totals) { ALPGPU_HIP(hipMemsetAsync(col->d_totals, 0, 64, ctx->stream)); }
 		return ALPGPU_OK;
