@@ -32,7 +32,8 @@ struct ExcMaskF {
 	int      excl;
 };
 // lane l < 32: mask word l and the number of exceptions in the words before it (DPP row scan, see decode_kernels.hip)
-__device__ __forceinline__ ExcMaskF load_exception_mask_f32(const DecodeLdsF32& L, int lane) {
+template <class LDS>
+__device__ __forceinline__ ExcMaskF load_exception_mask_f32(const LDS& L, int lane) {
 	ExcMaskF  m;
 	m.word      = L.mask[lane & 31];
 	const int c = lane < 32 ? __builtin_popcount(m.word) : 0;
@@ -46,8 +47,8 @@ __device__ __forceinline__ ExcMaskF load_exception_mask_f32(const DecodeLdsF32& 
 	return m;
 }
 
-template <int VAL_BYTES>
-__device__ __forceinline__ uint32_t fetch_exception_f32(const DecodeLdsF32& L, const uint8_t* __restrict__ rec, int rank) {
+template <int VAL_BYTES, class LDS>
+__device__ __forceinline__ uint32_t fetch_exception_f32(const LDS& L, const uint8_t* __restrict__ rec, int rank) {
 	constexpr int kStaged = 4 * kExcStageF / VAL_BYTES;
 	if constexpr (VAL_BYTES == 4) {
 		if (rank < kStaged) { return reinterpret_cast<const uint32_t*>(L.excv)[rank]; }
@@ -110,23 +111,64 @@ __device__ __forceinline__ RdDict load_vector_consts_f32(const alpgpu_rowgroup_s
 	return RdDict {static_cast<uint64_t>(kFactArrF[d.f]), static_cast<uint64_t>(__float_as_uint(kFracArrF[d.e]))};
 }
 
-// one vector, after its packed words / exception mask are visible in L; thread tid owns values 4*tid .. 4*tid+3
+// Where a quad's words come from: the workgroup's LDS stage (k_decode_column_f32), or HBM directly through buffer loads bounded to the
+// vector's words (k_sink_direct_f32; decode_kernels.hip: BufferWords).
+struct QuadWords {
+	u32x4    w0, w1; // units 8k + a and 8k + 8 + a: stream words k, k + 1 of the quad's four columns
+	uint64_t l0, l1; // ALP_RD: left words (16 k' + group) and + 16
+};
+struct StagedWordsF {
+	const uint8_t* stage;
+	__device__ __forceinline__ void units(int i, u32x4& w0, u32x4& w1) const {
+		w0 = reinterpret_cast<const u32x4*>(stage)[i];
+		w1 = reinterpret_cast<const u32x4*>(stage)[i + 8];
+	}
+	__device__ __forceinline__ void lefts(int rbw, int i, uint64_t& l0, uint64_t& l1) const {
+		l0 = reinterpret_cast<const uint64_t*>(stage + 128 * rbw)[i];
+		l1 = reinterpret_cast<const uint64_t*>(stage + 128 * rbw)[i + 16];
+	}
+};
+struct BufferWordsF {
+	__amdgpu_buffer_rsrc_t right, left;
+	__device__ __forceinline__ void units(int i, u32x4& w0, u32x4& w1) const {
+		const uint32_t at = static_cast<uint32_t>(i) * 16u;
+		w0 = __builtin_amdgcn_raw_buffer_load_b128(right, at, 0, 0);
+		w1 = __builtin_amdgcn_raw_buffer_load_b128(right, at, 128, 0);
+	}
+	__device__ __forceinline__ void lefts(int, int i, uint64_t& l0, uint64_t& l1) const {
+		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+		const uint32_t at = static_cast<uint32_t>(i) * 8u;
+		const u32x2    a = __builtin_amdgcn_raw_buffer_load_b64(left, at, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b64(left, at, 128, 0);
+		l0 = (static_cast<uint64_t>(a[1]) << 32) | a[0];
+		l1 = (static_cast<uint64_t>(b[1]) << 32) | b[0];
+	}
+};
+// the requests of the quad 4 tid .. 4 tid + 3 (row = tid >> 3, a = tid & 7; ALP_RD: left row tid >> 4, group tid & 15)
+template <class WORDS>
+__device__ __forceinline__ QuadWords request_quad_f32(const WORDS& words, const alpgpu_vector_desc& d, int tid) {
+	QuadWords q;
+	q.l0 = q.l1 = 0;
+	words.units(8 * (((tid >> 3) * d.bw) >> 5) + (tid & 7), q.w0, q.w1);
+	if (d.scheme != ALPGPU_SCHEME_ALP) { words.lefts(d.bw, 16 * (((tid >> 4) * d.lbw) >> 4) + (tid & 15), q.l0, q.l1); }
+	return q;
+}
+
+// one quad, after its words have arrived: thread tid (of 256: wavefront `wave`, lane) owns values 4*tid .. 4*tid+3; `em` = the vector's
+// exception mask as this wavefront sees it (ignored when the vector has none), L = where staged exception values live.
 // SINK (as in decode_kernels.hip) = kSinkStoreF: the quad is stored.  kSinkSumF: its four values are widened to double
 // (exact) and added to `acc` in index order.  kSinkCountF: `acc` counts the values v with lo <= v <= hi (NaN never does).
 constexpr int kSinkStoreF = 0, kSinkSumF = 1, kSinkCountF = 2;
-template <bool NT_STORE, int SINK = kSinkStoreF>
-__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const RdDict& dict,
-                                                         const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane,
-                                                         double* acc = nullptr, float range_lo = 0.0f, float range_hi = 0.0f) {
-	const int    bw    = d.bw;
-	const int    cnt   = d.exc_cnt;
-	const int    a     = tid & 7;
-	const int    row   = tid >> 3;
-	const u32x4* units = reinterpret_cast<const u32x4*>(L.stage);
-	uint32_t     hits  = 0;
-	int          rank  = 0;
+template <bool NT_STORE, int SINK, class LDS>
+__device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w, const alpgpu_vector_desc& d, const RdDict& dict, const ExcMaskF& em,
+                                                const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane, double* acc,
+                                                float range_lo, float range_hi) {
+	const int bw   = d.bw;
+	const int cnt  = d.exc_cnt;
+	const int a    = tid & 7;
+	const int row  = tid >> 3;
+	uint32_t  hits = 0;
+	int       rank = 0;
 	if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
-		const ExcMaskF em   = load_exception_mask_f32(L, lane);
 		const int      wi   = 8 * wave + (lane >> 3);
 		const uint32_t word = static_cast<uint32_t>(__shfl(static_cast<int>(em.word), wi));
 		const int      pref = __shfl(em.excl, wi);
@@ -134,12 +176,14 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 		hits                = (word >> b0) & 0xFu;
 		rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
 	}
-	u32x4 out;
+	// FastLanes u32 unpack (alp_device_f32.hpp: unpack_quad_u32): (w1 << (32 - s)) without the undefined shift by 32 when s == 0
+	const uint32_t s = static_cast<uint32_t>(row * bw) & 31u;
+	const u32x4    q = ((w.w0 >> s) | ((w.w1 << 1u) << (31u - s))) & bw_mask32(bw);
+	u32x4          out;
 	if (d.scheme == ALPGPU_SCHEME_ALP) {
 		const uint32_t base = static_cast<uint32_t>(d.base);
 		const uint32_t fact = static_cast<uint32_t>(dict.lo);
 		const float    frac = __uint_as_float(static_cast<uint32_t>(dict.hi));
-		const u32x4    q    = unpack_quad_u32(units, bw, bw_mask32(bw), row, a);
 #pragma unroll
 		for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint(decode_value_f32(static_cast<int32_t>(q[c] + base), fact, frac)); }
 		if (hits) {
@@ -159,18 +203,12 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 		const int      lbw  = d.lbw;
 		const uint32_t lmsk = (1u << lbw) - 1u;
 		const uint64_t dlo = dict.lo, dhi = dict.hi;
-		const u32x4     q    = unpack_quad_u32(units, rbw, bw_mask32(rbw), row, a);
-		const uint64_t* lsrc = reinterpret_cast<const uint64_t*>(L.stage + 128 * rbw);
-		const int       p    = (tid >> 4) * lbw;
-		const int       k    = p >> 4;
-		const int       s    = p & 15;
-		const uint64_t  w0   = lsrc[16 * k + (tid & 15)];
-		const uint64_t  w1   = lsrc[16 * k + 16 + (tid & 15)];
+		const int      ls   = ((tid >> 4) * lbw) & 15;
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
-			const uint32_t f0  = static_cast<uint32_t>(w0 >> (16 * c)) & 0xFFFFu;
-			const uint32_t f1  = static_cast<uint32_t>(w1 >> (16 * c)) & 0xFFFFu;
-			const uint32_t idx = ((f0 >> s) | (f1 << (16 - s))) & lmsk;
+			const uint32_t f0  = static_cast<uint32_t>(w.l0 >> (16 * c)) & 0xFFFFu;
+			const uint32_t f1  = static_cast<uint32_t>(w.l1 >> (16 * c)) & 0xFFFFu;
+			const uint32_t idx = ((f0 >> ls) | (f1 << (16 - ls))) & lmsk;
 			uint32_t       l   = static_cast<uint32_t>((idx < 4 ? dlo >> (16 * idx) : dhi >> (16 * (idx & 3))) & 0xFFFFull);
 			if (hits & (1u << c)) {
 				l = fetch_exception_f32<2>(L, rec, rank);
@@ -191,6 +229,17 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 	} else {
 		store_quad<NT_STORE>(dst + 4 * tid, out);
 	}
+}
+
+// one vector of a staged workgroup, after its packed words / exception mask are visible in L
+template <bool NT_STORE, int SINK = kSinkStoreF>
+__device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, const alpgpu_vector_desc& d, const RdDict& dict,
+                                                         const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane,
+                                                         double* acc = nullptr, float range_lo = 0.0f, float range_hi = 0.0f) {
+	ExcMaskF em {0u, 0};
+	if (d.exc_cnt > 0) { em = load_exception_mask_f32(L, lane); }
+	const QuadWords w = request_quad_f32(StagedWordsF {L.stage}, d, tid);
+	finish_quad_f32<NT_STORE, SINK>(L, w, d, dict, em, rec, dst, tid, wave, lane, acc, range_lo, range_hi);
 }
 
 // SINK != kSinkStoreF: `out` is the per-vector result array instead (double sums / uint32 counts)
@@ -231,27 +280,33 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if constexpr (SINK != kSinkStoreF) {
-		// per-vector result: thread partial over its quad (index order, in double) -> wavefront butterfly (xor 32,16,..,1)
-		// -> (w0 + w1) + (w2 + w3); tests/test_decode_sum_gpu.py replays this order on the host
-		__shared__ double s_part[V][kDecThreadsF / 64];
+		// per-vector result: thread partial over its quad (index order, in double) -> the four partials of a lane position combined as
+		// (w0 + w1) + (w2 + w3) -> ONE adjacent-lane tree over the 64 results (decode_kernels.hip: the double sinks; the partials travel
+		// through the vectors' spent stages); tests/test_decode_sum_gpu.py replays this order on the host
+		double acc[V];
 #pragma unroll
 		for (int i = 0; i < V; ++i) {
-			double acc = 0.0;
+			acc[i] = 0.0;
 			if (v0 + i < n_vectors) {
-				decode_staged_vector_f32<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, tid, wave, lane, &acc, range_lo,
+				decode_staged_vector_f32<NT_STORE, SINK>(L[i], d[i], dict[i], excs + d[i].exc_off, nullptr, tid, wave, lane, &acc[i], range_lo,
 				                                         range_hi);
 			}
-			acc = wave_tree_sum_f64(acc); // balanced tree over adjacent lanes (alp_device.hpp), as in the double kernel
-			if (lane == 0) { s_part[i][wave] = acc; }
 		}
+		__syncthreads(); // nobody reads packed words any more
+		static_assert(kStageBytesF >= 8 * kDecThreadsF && kDecThreadsF == 256, "the lane partials of a vector fit its stage; four wavefronts per vector");
+#pragma unroll
+		for (int i = 0; i < V; ++i) { reinterpret_cast<double*>(L[i].stage)[tid] = acc[i]; }
 		__syncthreads();
-		if (tid < V && v0 + tid < n_vectors) {
-			static_assert(kDecThreadsF == 256, "the documented summation order is for 4 wavefronts per vector");
-			const double total = (s_part[tid][0] + s_part[tid][1]) + (s_part[tid][2] + s_part[tid][3]);
-			if constexpr (SINK == kSinkCountF) {
-				reinterpret_cast<uint32_t*>(out)[v0 + tid] = static_cast<uint32_t>(total);
-			} else {
-				reinterpret_cast<double*>(out)[v0 + tid] = total;
+		if (wave < V && v0 + wave < n_vectors) { // wave-uniform: wavefront w finishes vector w (V <= 4)
+			const double* part  = reinterpret_cast<const double*>(L[wave].stage) + lane;
+			double        total = (part[0] + part[64]) + (part[128] + part[192]);
+			total               = wave_tree_sum_f64(total);
+			if (lane == 0) {
+				if constexpr (SINK == kSinkCountF) {
+					reinterpret_cast<uint32_t*>(out)[v0 + wave] = static_cast<uint32_t>(total);
+				} else {
+					reinterpret_cast<double*>(out)[v0 + wave] = total;
+				}
 			}
 		}
 		return;
@@ -302,6 +357,84 @@ static int launch_sink_f32(hipStream_t stream, const alpgpu_column* col, void* d
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
 		hipLaunchKernelGGL((k_decode_column_f32<V, false, SINK>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc,
 		                   static_cast<float*>(d_result), n, off, lo, hi);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// ---- the float sinks with ONE wavefront per vector, packed words straight from HBM (decode_kernels.hip: k_sink_direct) ----------------
+// Lane L does what threads L, 64 + L, 128 + L, 192 + L of the staged kernel do: four quads, their partials kept apart (p[w][L]), all four
+// quads' words requested before the first is used; then (p0 + p1) + (p2 + p3) and the adjacent-lane tree: the same bits.
+struct SinkWaveLdsF32 {
+	uint32_t mask[32];
+	uint8_t  excv[4 * kExcStageF];
+};
+template <int SINK>
+__global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                      const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
+                                                                      uint64_t n_vectors, uint64_t wg_offset, float lo, float hi) {
+	__shared__ SinkWaveLdsF32 S[kDecThreadsF / 64];
+	const int      lane = static_cast<int>(threadIdx.x) & 63;
+	const int      wv   = wave_in_wg();
+	const uint64_t v    = (wg_offset + blockIdx.x) * (kDecThreadsF / 64) + wv;
+	if (v >= n_vectors) { return; } // wave-uniform; no barrier anywhere in this kernel
+	SinkWaveLdsF32&          L      = S[wv];
+	const alpgpu_vector_desc d      = descs[v];
+	const RdDict             dict   = load_vector_consts_f32(rgs, v, d);
+	const uint8_t*           rec    = excs + d.exc_off;
+	const bool               is_alp = d.scheme == ALPGPU_SCHEME_ALP;
+	const int                cnt    = d.exc_cnt;
+	ExcMaskF                 em {0u, 0};
+	if (cnt > 0) { // wave-uniform: values of the first kExcStageF exceptions by LDS-DMA, the mask from the positions
+		const uint32_t val_bytes = (is_alp ? 4u : 2u) * static_cast<uint32_t>(cnt);
+		const int      dwords    = static_cast<int>(((val_bytes < 4u * kExcStageF ? val_bytes : 4u * kExcStageF) + 3u) >> 2);
+		for (int q = 0; 64 * q < dwords; ++q) {
+			if (64 * q + lane < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + 64 * q + lane, reinterpret_cast<uint32_t*>(L.excv) + 64 * q, 4, 0, 0); }
+		}
+		if (lane < 32) { L.mask[lane] = 0u; }
+		wave_lds_sync();
+		const uint16_t* poss = reinterpret_cast<const uint16_t*>(rec + val_bytes);
+		for (int j = lane; j < cnt; j += 64) {
+			const uint32_t p = poss[j];
+			atomicOr(&L.mask[p >> 5], 1u << (p & 31u));
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd values
+		wave_lds_sync();
+		em = load_exception_mask_f32(L, lane);
+	}
+	uint8_t*           first      = const_cast<uint8_t*>(packed + d.packed_off);
+	constexpr int      kRsrcFlags = 0x00020000; // gfx9 raw buffer, 32-bit data format
+	const BufferWordsF words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d.bw, kRsrcFlags),
+	                          __builtin_amdgcn_make_buffer_rsrc(first + 128u * d.bw, 0, is_alp ? 0 : 128 * d.lbw, kRsrcFlags)};
+	QuadWords w[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) { w[q] = request_quad_f32(words, d, 64 * q + lane); }
+	double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int q = 0; q < 4; ++q) { finish_quad_f32<false, SINK>(L, w[q], d, dict, em, rec, nullptr, 64 * q + lane, q, lane, &part[q], lo, hi); }
+	double total = (part[0] + part[1]) + (part[2] + part[3]);
+	total        = wave_tree_sum_f64(total);
+	if (lane == 0) {
+		if constexpr (SINK == kSinkCountF) {
+			reinterpret_cast<uint32_t*>(out)[v] = static_cast<uint32_t>(total);
+		} else {
+			out[v] = total;
+		}
+	}
+}
+
+int launch_sink_direct_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, void* d_out, bool count) {
+	const uint64_t n = col->n_vectors;
+	if (n == 0) { return ALPGPU_OK; }
+	const uint64_t per_wg   = kDecThreadsF / 64;
+	const uint64_t n_wg     = (n + per_wg - 1) / per_wg;
+	const uint64_t kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
+		if (count) {
+			hipLaunchKernelGGL((k_sink_direct_f32<kSinkCountF>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, lo, hi);
+		} else {
+			hipLaunchKernelGGL((k_sink_direct_f32<kSinkSumF>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, 0.0f, 0.0f);
+		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

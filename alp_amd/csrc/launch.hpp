@@ -15,6 +15,7 @@ int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, doub
 int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, double hi, void* d_out, bool count);
 int launch_decode_sum_f32(hipStream_t stream, const alpgpu_column* col, double* d_sums);
 int launch_decode_count_range_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
+int launch_sink_direct_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, void* d_out, bool count);
 
 // consume_kernels.hip: decode fused into SUM / COUNT consumers (persistent, software-pipelined), and the column total's tree
 int launch_consume_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int n_cus);

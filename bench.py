@@ -735,7 +735,12 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
         dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
         rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
         fsums = torch.empty(n, dtype=torch.float64, device=dev)
-        smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)
+        smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)  # kernel chosen per column (alp_rd_rowgroups_hint, set by column_totals above)
+        by_kernel = {}
+        for label, mode in (("one_wavefront_per_vector_ms", 2), ("four_wavefronts_per_vector_ms", 3)):
+            ctx.set_option(capi.OPT_CONSUMER_PIPELINED, mode)
+            by_kernel[label] = round(time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 5)[0], 3)
+        ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
         del fsums
         f_alg = n * (4096 + 13) + pb + eb
         fl[kind] = {"vectors": n, "encode_input_GBps": round(n * 4096 / emed / 1e6, 1), "encode_ms": round(emed, 3),
@@ -744,7 +749,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
                     "decode_GBps_decoded_floats": round(n * 4096 / dmed / 1e6, 1), "decode_ms": round(dmed, 3),
                     "decode_roofline_frac_algorithmic": frac(f_alg, dmed),
                     "decode_sum_fused_ms": round(smed, 3), "decode_sum_roofline_frac_algorithmic": frac(f_alg - n * 4096 + n * 8, smed),
-                    "gpu_roundtrip_bit_exact": rt}
+                    "decode_sum_by_kernel": by_kernel, "gpu_roundtrip_bit_exact": rt}
         del xf, fcol
     extras["float_path"] = fl
     result["extras"] = extras

@@ -425,8 +425,10 @@ int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, al
 /* ALPGPU_OPT_DECODE_VECTORS_PER_WG applies with values 0 (auto), 1, 2 and, for float only, 4 */
 int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
 /* The fused consumers of alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 for float columns.  Sums accumulate in double
- * (every float widens exactly): thread t of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0; the 64
- * threads of a wavefront combine by the balanced tree over adjacent lanes (as above); the four wavefront sums as (w0 + w1) + (w2 + w3). */
+ * (every float widens exactly): thread t = 64 w + L of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0, giving
+ * p[w][L]; then s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); then the balanced tree over adjacent lanes over the 64 s[L] (as for
+ * double; earlier in round 3 each wavefront ran the tree first).  ALPGPU_OPT_CONSUMER_PIPELINED: 0 / 2 = one wavefront per vector (the
+ * default for float columns whatever they hold), 1 / 3 = the staged four-wavefront kernel; same bits. */
 int alpgpu_decode_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 int alpgpu_decode_count_range_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
 int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values);

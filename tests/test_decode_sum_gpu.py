@@ -205,16 +205,15 @@ def test_decode_count_range_matches_numpy(ctx, oracle, name, shape):
 # ---- float columns (alpgpu_decode_sum_f32 / alpgpu_decode_count_range_f32) -------------------------------------------------
 
 def host_sums_f32(values):
-    """values [n, 1024] float32 -> the order documented in include/alpgpu.h: thread t adds values 4t..4t+3 (in double),
-    adjacent-lane tree over the 64 threads of a wavefront, (w0 + w1) + (w2 + w3)"""
+    """values [n, 1024] float32 -> the order documented in include/alpgpu.h: thread t = 64 w + L adds values 4t..4t+3 (in double) -> p[w][L];
+    s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); adjacent-lane tree over the 64 s[L]"""
     n = values.shape[0]
     v = values.astype(np.float64).reshape(n, 4, 64, 4)  # vector, wavefront, lane, quad element
     p = np.zeros((n, 4, 64))
     with np.errstate(invalid="ignore", over="ignore"):
         for c in range(4):
             p = p + v[:, :, :, c]
-        w = pairwise_tree(p)
-        return (w[:, 0] + w[:, 1]) + (w[:, 2] + w[:, 3])
+        return pairwise_tree((p[:, 0] + p[:, 1]) + (p[:, 2] + p[:, 3]))
 
 
 COLUMNS_F32 = {
@@ -231,8 +230,17 @@ def of32():
     return OracleF32()
 
 
+@pytest.fixture(params=["per_column", "one_wavefront_per_vector", "four_wavefronts_per_vector"])
+def kernel_f32(request, ctx):
+    """the two kernels behind the float consumers (same bits), and the per-column choice between them"""
+    from alp_amd import capi
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, {"per_column": 0, "one_wavefront_per_vector": 2, "four_wavefronts_per_vector": 3}[request.param])
+    yield request.param
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
+
+
 @pytest.mark.parametrize("name", list(COLUMNS_F32.keys()))
-def test_decode_sum_f32_matches_documented_order(ctx, of32, name):
+def test_decode_sum_f32_matches_documented_order(ctx, of32, name, kernel_f32):
     from alp_amd import capi
     col = COLUMNS_F32[name]()
     enc = of32.encode_column(col)
@@ -249,7 +257,7 @@ def test_decode_sum_f32_matches_documented_order(ctx, of32, name):
 
 
 @pytest.mark.parametrize("name", list(COLUMNS_F32.keys()))
-def test_decode_count_range_f32_matches_numpy(ctx, of32, name):
+def test_decode_count_range_f32_matches_numpy(ctx, of32, name, kernel_f32):
     from alp_amd import capi
     col = COLUMNS_F32[name]()
     enc = of32.encode_column(col)
