@@ -63,6 +63,24 @@ def fuzz_column(rng, dtype):
         return out.astype(dtype)
 
 
+def _sinks_agree(ctx, dcol):
+    """the fused consumers' two kernels (one wavefront per vector, words straight from HBM / four wavefronts over an LDS stage) document one
+    summation order: same bits (NaN where NaN), same counts, on whatever the fuzz column holds"""
+    from alp_amd import capi
+    got = {}
+    for mode in (2, 3):
+        ctx.set_option(capi.OPT_CONSUMER_PIPELINED, mode)
+        sums = ctx.decode_sum(dcol)
+        cnts = ctx.decode_count_range(dcol, -1.0e3, 1.0e3)
+        ctx.synchronize()
+        got[mode] = (sums.cpu().numpy(), cnts.cpu().numpy())
+    ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
+    a, b = got[2][0], got[3][0]
+    same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"sums differ between the two kernels at vectors {np.nonzero(~same)[0][:5]}"
+    assert np.array_equal(got[2][1], got[3][1]), "counts differ between the two kernels"
+
+
 @pytest.mark.parametrize("seed", list(range(ROUNDS)))
 def test_fuzz_double(ctx, oracle, seed):
     from alp_amd import capi
@@ -81,6 +99,7 @@ def test_fuzz_double(ctx, oracle, seed):
     out2 = ctx.decode(capi.DeviceColumn.from_host(*want))  # the decoder on the oracle's own encoding
     ctx.synchronize()
     assert torch.equal(out2.view(torch.int64), x.view(torch.int64))
+    _sinks_agree(ctx, dcol)
 
 
 @pytest.mark.parametrize("seed", list(range(ROUNDS)))
@@ -102,6 +121,7 @@ def test_fuzz_float(ctx, seed):
     out2 = ctx.decode(capi.DeviceColumn.from_host(*want, dtype="f32"))
     ctx.synchronize()
     assert torch.equal(out2.view(torch.int32), x.view(torch.int32))
+    _sinks_agree(ctx, dcol)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
