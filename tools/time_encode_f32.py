@@ -23,7 +23,7 @@ for kind in ("decimal_mixed", "rd"):
         del xd, sc, m
     cols, ms = {}, {}
     for mode in (0, 1, 0, 1):
-        ctx.set_option(capi.OPT_ENCODE_ASYNC_INIT, mode)
+        ctx.set_option(capi.OPT_ENCODE_ASYNC_INIT, 2 if mode else 0)  # (float columns take the side search only with value 2)
         col = capi.DeviceColumn(n, 0, dtype="f32")
         ms[mode], _ = bench.time_launches(lambda: ctx.encode(xf, col), 5, 2)
         cols[mode] = col
