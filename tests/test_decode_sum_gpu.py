@@ -106,6 +106,26 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name, shape):
     assert _same_bits(total.cpu().numpy(), host_column_total(want)).all(), name
 
 
+@pytest.mark.parametrize("neighbours", ["alone", "alp_rd", "no_exceptions", "specials"])
+def test_exception_carrying_vectors_across_a_full_chip(ctx, oracle, shape, neighbours):
+    """6000 vectors = more wavefronts than the chip holds at once, ~8 % exceptions in every other rowgroup, repeated: a build of the
+    one-wavefront kernel whose register allocation differed (no scratch, an experiment of round 3) returned wrong sums for ~4 % of exactly
+    these vectors, only past the first ~2000 and not the same ones from run to run — the small columns of the other tests never saw it."""
+    from alp_amd import capi
+    d1 = datagen.decimal_column(100, 1, seed=41)
+    d3 = datagen.decimal_column(100, 3, seed=43)
+    other = {"alone": [], "alp_rd": [datagen.rd_column(100, seed=51)], "no_exceptions": [datagen.decimal_column(100, 0, seed=40)],
+             "specials": [datagen.mixed_column(100, seed=50, exc_rate=0.05)]}[neighbours]
+    col = np.concatenate(([d1] + other + [d3] + other) * (30 if not other else 15))
+    enc = oracle.encode_column(col)
+    assert enc["exc_cnt"].max() > 60
+    dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
+    want = shape(col.reshape(-1, 1024))
+    for _ in range(3):
+        got = ctx.decode_sum(dcol).cpu().numpy()
+        assert _same_bits(got, want).all(), np.nonzero(~_same_bits(got, want))[0][:8]
+
+
 def test_many_vectors_per_wavefront_ring_wraps_and_every_width(ctx, oracle, shape):
     """A column long enough that every wavefront of the persistent kernel consumes many vectors (its LDS ring wraps, its prefetch queue
     fills and drains), with bit widths 0..52, exception-free and exception-carrying vectors, ALP and ALP_RD rowgroups interleaved."""
@@ -254,6 +274,20 @@ def test_decode_sum_f32_matches_documented_order(ctx, of32, name, kernel_f32):
     got = got.cpu().numpy()
     same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), f"{name}: {np.nonzero(~same)[0][:5]} {got[~same][:3]} {want[~same][:3]}"
+
+
+def test_exception_carrying_float_vectors_across_a_full_chip(ctx, of32, kernel_f32):
+    """the float kernels under the load of test_exception_carrying_vectors_across_a_full_chip: 6000 vectors, ~8 % exceptions, repeated"""
+    from alp_amd import capi
+    col = np.concatenate([datagen.mixed_column_f32(100, seed=60 + i, exc_rate=0.08, special_rate=0.0) for i in range(4)] * 15)
+    enc = of32.encode_column(col)
+    assert enc["exc_cnt"].max() > 60
+    dcol = capi.DeviceColumn.from_host(*layout.compact(enc, 4), dtype="f32")
+    want = host_sums_f32(col.reshape(-1, 1024))
+    for _ in range(3):
+        got = ctx.decode_sum(dcol).cpu().numpy()
+        same = got.view(np.uint64) == want.view(np.uint64)
+        assert same.all(), np.nonzero(~same)[0][:8]
 
 
 @pytest.mark.parametrize("name", list(COLUMNS_F32.keys()))
