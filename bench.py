@@ -642,7 +642,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     extras["decode_sum_fused"] = {"ms": round(med, 3), "decoded_GBps_equivalent": round(n * 8192 / med / 1e6, 1),
                                   "roofline_frac_algorithmic": frac(read_bytes, med),
                                   "note": "per-vector sums of the benchmark column; algorithmic bytes = packed words + 13 B metadata read, 8 B written per vector. "
-                                          "VALU-bound, not latency-bound: 506 vector instructions per vector at 73-83 % VALU utilisation (profiles/r03_consumers.txt)"}
+                                          "one wavefront per vector (k_sink_direct): 293 vector instructions per vector, the VALU ~saturated by the counters, yet one instruction per value fewer changed nothing (profiles/r03_consumers.txt)"}
     # the column's total (alpgpu_column_sum_f64: per-vector sums + the documented tree) and the predicate consumer
     tot = torch.empty(1, dtype=torch.float64, device=dev)
     cmed, _ = time_launches(lambda: ctx.column_sum(col, tot), 7, 10)
