@@ -465,12 +465,11 @@ int alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, u
 }
 
 // which kernel computes the per-vector sums (ALPGPU_OPT_CONSUMER_PIPELINED)
-// 0 (default): one wavefront per vector when the column is known to hold no ALP_RD rowgroup (alp_rd_rowgroups_hint == 1), else the staged
-// four-wavefront kernel — the one-wavefront kernel runs ALP_RD vectors a quarter at a time out of too few registers (3.7 x slower on an
-// all-ALP_RD column); 1: the persistent LDS-ring kernel; 2 / 3: force the one-wavefront / the four-wavefront kernel.
-static bool use_direct_sink(const alpgpu_ctx* ctx, const alpgpu_column* col) {
-	return ctx->pipelined_consumer == 2 || (ctx->pipelined_consumer == 0 && col->alp_rd_rowgroups_hint == 1);
-}
+// 0 (default) and 2: one wavefront per vector (k_sink_direct) whatever the column holds — ahead of the staged four-wavefront kernel on ALP
+// columns (0.81 against 0.91 ms per 1 Mi vectors of the benchmark column) and, since its ALP_RD arm stopped spilling, on ALP_RD columns too
+// (1.41 against 1.51 ms); 1: the persistent LDS-ring kernel; 3: the staged four-wavefront kernel.  (alp_rd_rowgroups_hint, which chose
+// between the two while the ALP_RD arm spilled, is still kept up to date in the column for callers that want to know.)
+static bool use_direct_sink(const alpgpu_ctx* ctx, const alpgpu_column*) { return ctx->pipelined_consumer == 0 || ctx->pipelined_consumer == 2; }
 static int sum_launch(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
 	if (ctx->pipelined_consumer == 1) { return alpgpu::launch_consume_sum(ctx->stream, col, d_sums, ctx->n_cus); }
 	if (use_direct_sink(ctx, col)) { return alpgpu::launch_sink_direct(ctx->stream, col, 0.0, 0.0, d_sums, false); }

@@ -22,6 +22,7 @@ constexpr int kStageBytesF  = 4480; // >= 31*128 (RD right) + 3*128 (RD left) + 
 constexpr int kExcStageF    = 128;
 
 struct __attribute__((aligned(16))) DecodeLdsF32 {
+	static constexpr bool kPrefixInLds = false; // exception lookup by ds_bpermute
 	uint8_t  stage[kStageBytesF];
 	uint32_t mask[32];
 	uint8_t  excv[4 * kExcStageF]; // the head of the exception record as it lies in the stream (values first), brought in by LDS-DMA
@@ -169,9 +170,16 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 	uint32_t  hits = 0;
 	int       rank = 0;
 	if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
-		const int      wi   = 8 * wave + (lane >> 3);
-		const uint32_t word = static_cast<uint32_t>(__shfl(static_cast<int>(em.word), wi));
-		const int      pref = __shfl(em.excl, wi);
+		const int wi = 8 * wave + (lane >> 3);
+		uint32_t  word;
+		int       pref;
+		if constexpr (LDS::kPrefixInLds) { // k_sink_direct_f32: out of the wavefront's LDS, not by ds_bpermute while its loads are in flight (decode_kernels.hip: exception_hits_lds)
+			word = L.mask[wi];
+			pref = static_cast<int>(L.pref[wi]);
+		} else {
+			word = static_cast<uint32_t>(__shfl(static_cast<int>(em.word), wi));
+			pref = __shfl(em.excl, wi);
+		}
 		const int      b0   = 4 * a;
 		hits                = (word >> b0) & 0xFu;
 		rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
@@ -365,8 +373,10 @@ static int launch_sink_f32(hipStream_t stream, const alpgpu_column* col, void* d
 // Lane L does what threads L, 64 + L, 128 + L, 192 + L of the staged kernel do: four quads, their partials kept apart (p[w][L]), all four
 // quads' words requested before the first is used; then (p0 + p1) + (p2 + p3) and the adjacent-lane tree: the same bits.
 struct SinkWaveLdsF32 {
+	static constexpr bool kPrefixInLds = true;
 	uint32_t mask[32];
 	uint8_t  excv[4 * kExcStageF];
+	uint32_t pref[32]; // exceptions in front of mask word i
 };
 template <int SINK>
 __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
@@ -400,6 +410,8 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd values
 		wave_lds_sync();
 		em = load_exception_mask_f32(L, lane);
+		if (lane < 32) { L.pref[lane] = static_cast<uint32_t>(em.excl); }
+		wave_lds_sync();
 	}
 	uint8_t*           first      = const_cast<uint8_t*>(packed + d.packed_off);
 	constexpr int      kRsrcFlags = 0x00020000; // gfx9 raw buffer, 32-bit data format

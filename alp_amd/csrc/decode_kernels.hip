@@ -45,6 +45,7 @@ constexpr int kExcStage     = 128;  // 8-byte exception values staged in LDS per
 constexpr uint32_t kExcStageBytes = 8u * kExcStage;
 
 struct __attribute__((aligned(16))) DecodeLds {
+	static constexpr bool kPrefixInLds = false; // exception lookup by ds_bpermute (exception_hits)
 	uint8_t  stage[kStageBytes];
 	uint32_t mask[32];
 	uint8_t  excv[kExcStageBytes]; // the head of the exception record as it lies in the stream (its values come first), brought in by LDS-DMA
@@ -100,6 +101,23 @@ __device__ __forceinline__ uint64_t fetch_exception(const LDS& L, const uint8_t*
 // word is 4m + (lane >> 4): word and prefix come from the lane that holds them by ds_bpermute (the LDS crossbar, no memory) — as eight
 // readlanes and six selects per step this lookup was a quarter of the vector instructions of a vector with exceptions, and the consumers
 // (SUM / COUNT sinks) are bound by exactly those (profiles/r03_consumers.txt).
+// The same lookup out of the wavefront's LDS (mask word and its prefix as two ds_read_b32 of one address per 16 lanes) — what k_sink_direct
+// uses.  There the ds_bpermute form is NOT safe: with the packed words' vector-memory loads returning into the wavefront's registers while
+// the two ds_bpermute of a step are in flight, rebuilds of that kernel (another register budget, another batch size, two compiler pins)
+// came back with a wrong extracted field in the FOLLOWING step — right words in the registers, wrong value — for ~5 % of the
+// exception-carrying vectors of a long column, never the same ones; every such build is clean with this form and wrong with the other
+// (profiles/r03_consumers.txt; tests/test_decode_sum_gpu.py::test_exception_records_that_change_nothing).  k_decode_column has no load
+// in flight at that point (its words are in LDS behind a barrier) and never showed it.
+template <class LDS>
+__device__ __forceinline__ uint32_t exception_hits_lds(const LDS& L, int m, int lane, int& rank) {
+	const int      q    = 4 * m + (lane >> 4);
+	const uint32_t word = L.mask[q];
+	const int      pref = static_cast<int>(L.pref[q]);
+	const int      b0   = (2 * lane) & 31;
+	const uint32_t hits = (word >> b0) & 3u;
+	rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
+	return hits;
+}
 __device__ __forceinline__ uint32_t exception_hits(const ExcMask& em, int m, int lane, int& rank) {
 	const int      src  = (4 * m + (lane >> 4)) << 2; // byte address of the source lane
 	const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(em.word)));
@@ -279,7 +297,8 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 		auto finish_pair = [&](int m, double ox, double oy, double* acc_q) {
 			if (cnt > 0) {
 				int            rank;
-				const uint32_t hits = exception_hits(em, m, lane, rank);
+				uint32_t       hits;
+				if constexpr (LDS::kPrefixInLds) { hits = exception_hits_lds(L, m, lane, rank); } else { hits = exception_hits(em, m, lane, rank); }
 				if (hits & 1u) {
 					ox = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, all_staged)));
 					++rank;
@@ -344,7 +363,8 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 		for (int i = 0; i < kBatchRd; ++i) {
 			const int      m   = kStepsPerWave * q0 + b + i;
 			double*        acc_q = acc + (b + i) / kStepsPerWave;
-			const U64Pair  u   = extract(rbw, mask, 8 * m + r0, rw[i]);
+			U64Pair        u   = extract(rbw, mask, 8 * m + r0, rw[i]);
+			if constexpr (ONLY == 2) { asm volatile("" : "+v"(u.x), "+v"(u.y)); } // (k_sink_direct) the right parts extracted HERE: their four words die before the left parts' work begins
 			const int      s   = ((2 * m + (lane >> 5)) * lbw) & 15;
 			const uint32_t w0 = lw[i].x, w1 = lw[i].y;
 			const uint32_t i0  = (((w0 & 0xFFFFu) >> s) | ((w1 & 0xFFFFu) << (16 - s))) & lmsk;
@@ -353,7 +373,8 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 			uint64_t       l1  = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
 			if (cnt > 0) {
 				int            rank;
-				const uint32_t hits = exception_hits(em, m, lane, rank);
+				uint32_t       hits;
+				if constexpr (LDS::kPrefixInLds) { hits = exception_hits_lds(L, m, lane, rank); } else { hits = exception_hits(em, m, lane, rank); }
 				if (hits & 1u) {
 					l0 = fetch_exception<2>(L, rec, rank, all_staged);
 					++rank;
@@ -364,6 +385,7 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 			const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
 			if constexpr (SINK != kSinkStore) {
 				consume_pair<SINK>(ox, oy, acc_q, range_lo, range_hi);
+				if constexpr (ONLY == 2) { asm volatile("" : "+v"(*acc_q)); } // ... and the pair added HERE: left to itself the compiler keeps all sixteen results for the end (208 bytes of scratch, 3.7 x the time)
 			} else {
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
 			}
@@ -536,8 +558,10 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 #define ALPGPU_SINK_DIRECT_OCC 8 // wavefronts per SIMD the register budget is sized for (8 -> <= 64 VGPRs; measured against 5 and 6: profiles/r03_consumers.txt)
 #endif
 struct SinkWaveLds {
+	static constexpr bool kPrefixInLds = true; // exception_hits_lds
 	uint32_t mask[32];
 	uint8_t  excv[kExcStageBytes];
+	uint32_t pref[32]; // exceptions in front of mask word i
 };
 template <int SINK>
 __global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink_direct(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
@@ -571,6 +595,8 @@ __global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd values (LDS-DMA completion is not tracked through the LDS for the compiler)
 		wave_lds_sync();
 		em = load_exception_mask(L, lane);
+		if (lane < 32) { L.pref[lane] = static_cast<uint32_t>(em.excl); }
+		wave_lds_sync();
 	}
 	uint8_t*          first   = const_cast<uint8_t*>(packed + d.packed_off);
 	constexpr int     kRsrcFlags = 0x00020000; // gfx9 raw buffer, 32-bit data format
@@ -580,8 +606,9 @@ __global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink
 	if (is_alp) { // wave-uniform
 		decode_vector_quarters<false, SINK, kDecWaves, 1>(L, words, d, dict, em, rec, nullptr, 0, lane, part, lo, hi);
 	} else {
-		// ALP_RD a quarter at a time: the right AND left words of eight steps in flight at once do not fit this kernel's 64 registers (built that
-		// way it spilled them and ran 3.7 x slower than the staged kernel on an all-ALP_RD column)
+		// ALP_RD a quarter at a time: the right AND left words of eight steps in flight at once do not fit this kernel's 64 registers; with the two
+		// pins in decode_vector_quarters' ALP_RD arm nothing is spilled (1.41 ms per 1 Mi vectors of an all-ALP_RD column, staged kernel 1.51;
+		// without them 208 bytes of scratch and 5.4 ms)
 #pragma unroll
 		for (int q = 0; q < kDecWaves; ++q) {
 			decode_vector_quarters<false, SINK, 1, 2>(L, words, d, dict, em, rec, nullptr, q, lane, &part[q], lo, hi);

@@ -47,9 +47,8 @@ def host_sums_pipelined(values):
 
 @pytest.fixture(params=["default", "pipelined", "one_wavefront_per_vector", "four_wavefronts_per_vector"])
 def shape(request, ctx):
-    """the kernels behind alpgpu_decode_sum_f64 / _count_range_f64 / alpgpu_column_sum_f64, each with its documented order: the default
-    picks between the one-wavefront and the four-wavefront kernel per column (no ALP_RD rowgroup known / otherwise), and those two give the
-    same bits"""
+    """the kernels behind alpgpu_decode_sum_f64 / _count_range_f64 / alpgpu_column_sum_f64, each with its documented order: the default is
+    the one-wavefront kernel, which gives the same bits as the four-wavefront one"""
     from alp_amd import capi
     ctx.set_option(capi.OPT_CONSUMER_PIPELINED, {"default": 0, "pipelined": 1, "one_wavefront_per_vector": 2, "four_wavefronts_per_vector": 3}[request.param])
     yield host_sums_pipelined if request.param == "pipelined" else host_sums
@@ -106,11 +105,39 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name, shape):
     assert _same_bits(total.cpu().numpy(), host_column_total(want)).all(), name
 
 
+def test_exception_records_that_change_nothing(ctx, oracle, shape):
+    """A clean ALP column whose vectors carry 60-100 exception records each that repeat the value already encoded at their position: every
+    part of the exception machinery runs (records staged, mask, lookup, patch) and none of it may change a sum.  This is the column that
+    exposed the ds_bpermute lookup in the one-wavefront kernel (decode_kernels.hip: exception_hits_lds): ~5 % of the vectors came back
+    wrong in some builds, in others none."""
+    from alp_amd import capi
+    col = np.concatenate([datagen.decimal_column(100, 2, lo=-9e4, hi=9e4, seed=70 + i) for i in range(4)] * 15)
+    enc = oracle.encode_column(col)
+    assert enc["exc_cnt"].max() == 0
+    rng = np.random.default_rng(5)
+    n = enc["scheme"].size
+    values = col.reshape(n, 1024)
+    exc, pos = enc["exc"].reshape(n, 1024), enc["pos"].reshape(n, 1024)
+    for v in range(n):
+        k = int(rng.integers(60, 100))
+        p = np.sort(rng.choice(1024, k, replace=False)).astype(np.uint16)
+        pos[v, :k] = p
+        exc[v, :k] = values[v, p]
+        enc["exc_cnt"][v] = k
+    dcol = capi.DeviceColumn.from_host(*layout.compact(enc))
+    want = shape(values)
+    for _ in range(4):
+        got = ctx.decode_sum(dcol).cpu().numpy()
+        assert _same_bits(got, want).all(), np.nonzero(~_same_bits(got, want))[0][:8]
+    assert torch.equal(ctx.decode(dcol).view(torch.int64).cpu(), torch.from_numpy(col).view(torch.int64))
+
+
 @pytest.mark.parametrize("neighbours", ["alone", "alp_rd", "no_exceptions", "specials"])
 def test_exception_carrying_vectors_across_a_full_chip(ctx, oracle, shape, neighbours):
     """6000 vectors = more wavefronts than the chip holds at once, ~8 % exceptions in every other rowgroup, repeated: a build of the
     one-wavefront kernel whose register allocation differed (no scratch, an experiment of round 3) returned wrong sums for ~4 % of exactly
-    these vectors, only past the first ~2000 and not the same ones from run to run — the small columns of the other tests never saw it."""
+    these vectors, only past the first ~2000 and not the same ones from run to run — the small columns of the other tests never saw it
+    (cause: the exception lookup by ds_bpermute with loads in flight, see test_exception_records_that_change_nothing)."""
     from alp_amd import capi
     d1 = datagen.decimal_column(100, 1, seed=41)
     d3 = datagen.decimal_column(100, 3, seed=43)
