@@ -103,7 +103,7 @@ def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=N
     col.totals[0] = packed_bytes
     col.totals[1] = n_vectors * rec
     col.c.packed_bytes_hint, col.c.exc_bytes_hint = packed_bytes, n_vectors * rec  # what alpgpu_column_totals would report
-    col.c.alp_rd_rowgroups_hint = 1  # ... "no ALP_RD rowgroup": the fused consumers choose their kernel by it
+    col.c.alp_rd_rowgroups_hint = 1  # ... "no ALP_RD rowgroup" (informational)
     # algorithmic bytes per launch: read 128*bw + 10*exc + 13, write 8192, per vector
     alg_bytes = int((128 * bw + 10 * exc_per_vec + 13 + 8192).sum())
     return col, vec, alg_bytes
@@ -735,7 +735,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
         dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
         rt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
         fsums = torch.empty(n, dtype=torch.float64, device=dev)
-        smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)  # kernel chosen per column (alp_rd_rowgroups_hint, set by column_totals above)
+        smed, _ = time_launches(lambda: ctx.decode_sum(fcol, fsums), 7, 10)  # the default kernel (one wavefront per vector)
         by_kernel = {}
         for label, mode in (("one_wavefront_per_vector_ms", 2), ("four_wavefronts_per_vector_ms", 3)):
             ctx.set_option(capi.OPT_CONSUMER_PIPELINED, mode)

@@ -130,8 +130,8 @@ typedef struct alpgpu_column {
 	 * (e.g. states supplied by the caller) is ignored. */
 	uint16_t*              d_rd_order;
 	/* host-side hint (ABI version 3; zero-initialise it): 0 = unknown, else 1 + the number of ALP_RD rowgroups of the column, as counted by
-	 * alpgpu_column_totals (a small kernel over d_rowgroups) or alpgpu_column_from_blob.  The fused consumers (alpgpu_decode_sum_f64, ...)
-	 * take their one-wavefront-per-vector kernel when it says "none" and the staged four-wavefront kernel otherwise. */
+	 * alpgpu_column_totals (a small kernel over d_rowgroups) or alpgpu_column_from_blob.  Informational: the fused consumers chose their
+	 * kernel by it while the one-wavefront kernel's ALP_RD arm spilled; they no longer read it. */
 	uint64_t               alp_rd_rowgroups_hint;
 } alpgpu_column;
 #define ALPGPU_RD_ORDER_STRIDE 296u
@@ -168,17 +168,16 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * identical in every mode. */
 #define ALPGPU_OPT_ENCODE_ASYNC_INIT 6
 /* ALPGPU_OPT_CONSUMER_PIPELINED: which kernel runs alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 / alpgpu_column_sum_f64.
- * 0 (default) = chosen per column: ONE wavefront per vector, packed words read straight from HBM with bounded buffer loads (no LDS stage,
- *     no barrier, one wave-uniform prologue per vector, eight wavefronts per SIMD) when the column is known to hold no ALP_RD rowgroup
- *     (alpgpu_column::alp_rd_rowgroups_hint == 1), else the staged kernel of 3; both give the same bits (the order documented at
- *     alpgpu_decode_sum_f64);
- * 2 / 3 = force the one-wavefront kernel / the staged one (four wavefronts per vector, one short-lived workgroup per two vectors);
+ * 0 (default) and 2 = ONE wavefront per vector, packed words read straight from HBM with bounded buffer loads (no LDS stage, no barrier,
+ *     one wave-uniform prologue per vector, eight wavefronts per SIMD), whatever the column holds;
+ * 3 = the staged kernel (four wavefronts per vector, one short-lived workgroup per two vectors); same bits as 0 / 2 (the order documented
+ *     at alpgpu_decode_sum_f64);
  * 1 = the persistent, software-pipelined kernel of alp_amd/csrc/consume_kernels.hip (one wavefront per vector, packed words, exception
  *     records and descriptors prefetched into per-wavefront LDS rings by LDS-DMA).  Its summation order is its own: lane L adds its 16
  *     values 128m + 2L, 128m + 2L + 1 (m = 0..7) in ascending order from +0.0, then the adjacent-lane tree over the 64 lane sums.
  * Measured in round 3 (profiles/r03_consumers.txt): what the staged kernel runs out of is instruction issue, the scalar unit first; the
- * one-wavefront kernel does a quarter of its scalar work per vector and is 15-30 % faster on ALP columns, but spills on ALP_RD vectors
- * (3.7 x slower on an all-ALP_RD column), hence the per-column choice; the ring kernel is slower than both. */
+ * one-wavefront kernel does a quarter of its scalar work per vector and is 7-30 % faster on ALP and ALP_RD columns alike (while its ALP_RD
+ * arm still spilled, the default chose between the two by alpgpu_column::alp_rd_rowgroups_hint); the ring kernel is slower than both. */
 #define ALPGPU_OPT_CONSUMER_PIPELINED 5
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
