@@ -168,8 +168,9 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * identical in every mode. */
 #define ALPGPU_OPT_ENCODE_ASYNC_INIT 6
 /* ALPGPU_OPT_CONSUMER_PIPELINED: which kernel runs alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 / alpgpu_column_sum_f64.
- * 0 (default) and 2 = ONE wavefront per vector, packed words read straight from HBM with bounded buffer loads (no LDS stage, no barrier,
- *     one wave-uniform prologue per vector, eight wavefronts per SIMD), whatever the column holds;
+ * 0 (default) and 2 = ONE wavefront per vector (no barrier, one wave-uniform prologue per vector, eight wavefronts per SIMD), whatever the
+ *     column holds: narrow ALP vectors (bit width <= 28, <= 48 exceptions) staged whole in the wavefront's LDS by LDS-DMA, every other
+ *     vector's packed words read straight from HBM with bounded buffer loads;
  * 3 = the staged kernel (four wavefronts per vector, one short-lived workgroup per two vectors); same bits as 0 / 2 (the order documented
  *     at alpgpu_decode_sum_f64);
  * 1 = the persistent, software-pipelined kernel of alp_amd/csrc/consume_kernels.hip (one wavefront per vector, packed words, exception
