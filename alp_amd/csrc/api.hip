@@ -476,11 +476,14 @@ static int sum_launch(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums)
 	return alpgpu::launch_decode_sum(ctx->stream, col, d_sums, 2);
 }
 
-// Float columns: the one-wavefront kernel whatever the column holds (its ALP_RD arm fits its registers: 1.06 ms against 1.06 for the staged
-// kernel on an all-ALP_RD column, 0.99 against 1.07 on the decimal one); options 1 and 3 select the staged kernel (there is no ring kernel).
-static bool use_direct_sink_f32(const alpgpu_ctx* ctx) { return ctx->pipelined_consumer == 0 || ctx->pipelined_consumer == 2; }
+// Float columns: the one-wavefront kernel (1.05 against 1.08 ms for the staged kernel on the decimal column) unless the column is known to
+// hold ALP_RD rowgroups (alp_rd_rowgroups_hint > 1: 1.13 against 1.06 ms on an all-ALP_RD column since the kernel runs seven wavefronts per
+// SIMD); 2 forces it, 1 and 3 select the staged kernel (there is no ring kernel).
+static bool use_direct_sink_f32(const alpgpu_ctx* ctx, const alpgpu_column* col) {
+	return ctx->pipelined_consumer == 2 || (ctx->pipelined_consumer == 0 && col->alp_rd_rowgroups_hint <= 1);
+}
 static int  sum_launch_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
-	if (use_direct_sink_f32(ctx)) { return alpgpu::launch_sink_direct_f32(ctx->stream, col, 0.0f, 0.0f, d_sums, false); }
+	if (use_direct_sink_f32(ctx, col)) { return alpgpu::launch_sink_direct_f32(ctx->stream, col, 0.0f, 0.0f, d_sums, false); }
 	return alpgpu::launch_decode_sum_f32(ctx->stream, col, d_sums);
 }
 
@@ -960,7 +963,7 @@ int alpgpu_decode_count_range_f32(alpgpu_ctx* ctx, const alpgpu_column* col, flo
 	if (!col || (!d_counts && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	if ((use_direct_sink_f32(ctx) ? alpgpu::launch_sink_direct_f32(ctx->stream, col, lo, hi, d_counts, true) : alpgpu::launch_decode_count_range_f32(ctx->stream, col, lo, hi, d_counts)) != ALPGPU_OK) {
+	if ((use_direct_sink_f32(ctx, col) ? alpgpu::launch_sink_direct_f32(ctx->stream, col, lo, hi, d_counts, true) : alpgpu::launch_decode_count_range_f32(ctx->stream, col, lo, hi, d_counts)) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "decode-count launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;

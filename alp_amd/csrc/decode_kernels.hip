@@ -113,10 +113,11 @@ __device__ __forceinline__ uint64_t fetch_exception(const LDS& L, const uint8_t*
 // uses.  SOME BUILDS of that kernel (another register budget, another batch size, two compiler pins ...) come back with a wrong extracted
 // field in the step FOLLOWING an exception lookup — right words in the registers, wrong value — for ~5 % of the exception-carrying
 // vectors of a long column, never the same ones; a build either does it in every run or never.  Three such builds became clean with this
-// form instead of ds_bpermute; later one with this form was wrong again, clean with full LDS waits, and another wrong WITH them — the
-// mechanism is not understood (profiles/r03_consumers.txt has everything that was excluded).  What decides is the test: a build of this
+// form instead of ds_bpermute; later one with this form was wrong again, clean with full LDS waits, and another wrong WITH them.  What the
+// wrong builds share turned out to be a live value in the LAST register of their allocation (k_sink_direct below allocates one more for
+// that reason; profiles/r03_consumers.txt has everything that was excluded on the way).  What decides stays the test: a build of this
 // file ships only if tests/test_decode_sum_gpu.py::test_exception_records_that_change_nothing and ...across_a_full_chip pass, repeatedly.
-// k_decode_column (words out of LDS behind a barrier, ds_bpermute lookup) never failed them in any build.
+// k_decode_column (44 of 48 registers, words out of LDS behind a barrier, ds_bpermute lookup) never failed them in any build.
 template <class LDS>
 __device__ __forceinline__ uint32_t exception_hits_lds(const LDS& L, int m, int lane, int& rank) {
 	const int      q    = 4 * m + (lane >> 4);
