@@ -113,11 +113,11 @@ __device__ __forceinline__ uint64_t fetch_exception(const LDS& L, const uint8_t*
 // uses.  SOME BUILDS of that kernel (another register budget, another batch size, two compiler pins ...) come back with a wrong extracted
 // field in the step FOLLOWING an exception lookup — right words in the registers, wrong value — for ~5 % of the exception-carrying
 // vectors of a long column, never the same ones; a build either does it in every run or never.  Three such builds became clean with this
-// form instead of ds_bpermute; later one with this form was wrong again, clean with full LDS waits, and another wrong WITH them.  What the
-// wrong builds share turned out to be a live value in the LAST register of their allocation (k_sink_direct below allocates one more for
-// that reason; profiles/r03_consumers.txt has everything that was excluded on the way).  What decides stays the test: a build of this
-// file ships only if tests/test_decode_sum_gpu.py::test_exception_records_that_change_nothing and ...across_a_full_chip pass, repeatedly.
-// k_decode_column (44 of 48 registers, words out of LDS behind a barrier, ds_bpermute lookup) never failed them in any build.
+// form instead of ds_bpermute; later one with this form was wrong again, clean with full LDS waits, and another wrong WITH them.  None of
+// that was the cause: the wrong builds had a 64-bit shift's amount in the LAST register of their allocation, which gfx950 reads as VGPR0
+// there (see k_sink_direct below; profiles/r03_consumers.txt has the way to it).  The LDS form stayed (same speed).  A build of this file
+// ships only if tools/check_top_vgpr.py is clean and tests/test_decode_sum_gpu.py::test_exception_records_that_change_nothing and
+// ...across_a_full_chip pass.  k_decode_column uses 44 of 48 allocated registers: the pattern cannot arise there.
 template <class LDS>
 __device__ __forceinline__ uint32_t exception_hits_lds(const LDS& L, int m, int lane, int& rank) {
 	const int      q    = 4 * m + (lane >> 4);
@@ -593,11 +593,12 @@ template <int SINK>
 __global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink_direct(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                    const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
                                                                    uint64_t n_vectors, uint64_t wg_offset, double lo, double hi) {
-	// One register MORE than the kernel uses is allocated on purpose.  Builds of this kernel whose registers fill their allocation exactly
-	// (64 of 64, 80 of 80) and keep a live value in the LAST one returned wrong sums for ~5 % of the exception-carrying vectors of a long
-	// column (a field extracted with a clobbered shift amount: the top register was not what the wavefront had written); the same code with
-	// this clobber — nothing but a larger allocation — is clean, as is every build that happened to leave its last register unused.  Who
-	// writes that register was not found (profiles/r03_consumers.txt).  Cost: 72 instead of 64 registers = 7 instead of 8 wavefronts per SIMD, 3-5 %.
+	// One register MORE than the kernel uses is allocated on purpose.  gfx950 range-checks a single-register operand of a 64-bit instruction
+	// (the shift amount of v_lshrrev_b64 / v_lshlrev_b64, which this kernel lives on) as a register PAIR: in the LAST register of the
+	// allocation it counts as out of range and VGPR0 is read instead (tools/last_vgpr_probe.hip).  Builds of this kernel whose registers
+	// filled their allocation exactly (64 of 64, 80 of 80) with a shift amount in the last one returned wrong sums for ~5 % of some vectors;
+	// the register allocator does not know the rule.  tools/check_top_vgpr.py (tests/test_build_rules.py) looks for the pattern in every
+	// kernel; here it cannot arise.  Cost: 72 instead of 64 registers = 7 instead of 8 wavefronts per SIMD, 3-6 %.
 	asm volatile("" ::: "v64");
 	__shared__ SinkWaveLds S[kDecWaves];
 	const int      lane = static_cast<int>(threadIdx.x) & 63;
