@@ -1,7 +1,14 @@
-// last_vgpr_probe.hip — stand-alone probe for what profiles/r03_consumers.txt describes: does a value kept in the LAST register of a
-// wavefront's allocation survive?  Short-lived wavefronts (one small piece of work each, like k_sink_direct) park a marker in v63 of a
-// 64-register allocation (or v(N-1) of N), run loads / LDS traffic / lane-masked regions that never touch it, and read it back.
-//   hipcc --offload-arch=gfx950 -O3 -o last_vgpr_probe tools/last_vgpr_probe.hip && ./last_vgpr_probe [workgroups] [repeats]
+// last_vgpr_probe.hip — stand-alone probe (no library) for a gfx950 behaviour found while chasing wrong sums in k_sink_direct
+// (profiles/r03_consumers.txt): a 64-bit shift (v_lshrrev_b64 / v_lshlrev_b64) whose SHIFT AMOUNT — a single 32-bit register — sits in the
+// LAST register of the wavefront's allocation computes with VGPR0 instead.  The operand seems to be range-checked as a register pair
+// (v63:v64 of a 64-register allocation = out of range -> the documented substitution of VGPR0).
+// Short-lived wavefronts (like k_sink_direct's) park a marker in the top register, run loads / LDS traffic / lane-masked regions that never
+// touch it, read it back (always intact), and use it as the shift amount of 64-bit shifts (wrong for ~40 % of the lanes) and as the 32-bit
+// operand of v_ldexp_f64, v_cvt_f64_u32, v_mad_u64_u32, v_lshl_add_u64 (never wrong).  With one more register allocated (-DMARGIN='"v64"')
+// nothing is ever wrong.  One MI355X, ROCm 7.2:
+//   ./last_vgpr_probe 2500 200    -> of 128000000 lanes 0 read back a different value, 51477462 got a wrong 64-bit shift by it
+//   (MARGIN "v64")                -> 0, 0
+//   hipcc --offload-arch=gfx950 -O3 -o last_vgpr_probe tools/last_vgpr_probe.hip && ./last_vgpr_probe [workgroups] [launches]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -90,6 +97,26 @@ __global__ __launch_bounds__(256, 8) void k_probe(const uint4* __restrict__ in, 
 	uint32_t got;
 	asm volatile("v_mov_b32 %0, " TOP : "=v"(got)::TOP);
 	if (got != marker) { atomicAdd(bad, 1u); }
+	// other 64-bit instructions with a 32-bit operand in the top register (counters 28..31)
+	{
+		const uint32_t k = (lane * 3 + 5) & 31;
+		asm volatile("v_mov_b32 " TOP ", %0" ::"v"(k) : TOP);
+		double   d, e;
+		uint64_t m, a;
+		const double   one = 1.5;
+		const uint64_t big = 0x0000000100000003ull;
+		asm volatile("v_ldexp_f64 %0, %1, " TOP : "=&v"(d) : "v"(one) : TOP);                   // src1 = exponent (32-bit)
+		asm volatile("v_cvt_f64_u32 %0, " TOP : "=&v"(e) : : TOP);                               // 32-bit source, 64-bit result
+		asm volatile("v_mad_u64_u32 %0, vcc, " TOP ", %1, %2" : "=&v"(m) : "v"(7u), "v"(big) : TOP, "vcc"); // 32 x 32 + 64
+		asm volatile("v_lshl_add_u64 %0, %1, " TOP ", %2" : "=&v"(a) : "v"(big), "v"(big) : TOP);  // (64 << 32-bit) + 64  (shift amounts 0..4 only)
+		if (d != __builtin_ldexp(1.5, static_cast<int>(k))) { atomicAdd(bad + 28, 1u); }
+		if (e != static_cast<double>(k)) { atomicAdd(bad + 29, 1u); }
+		if (m != static_cast<uint64_t>(k) * 7u + big) { atomicAdd(bad + 30, 1u); }
+		asm volatile("v_mov_b32 " TOP ", %0" ::"v"(k & 3u) : TOP);
+		asm volatile("v_lshl_add_u64 %0, %1, " TOP ", %2" : "=&v"(a) : "v"(big), "v"(big) : TOP);
+		if (a != (big << (k & 3u)) + big) { atomicAdd(bad + 31, 1u); }
+		asm volatile("v_mov_b32 " TOP ", %0" ::"v"(marker) : TOP);
+	}
 	SHIFT_TEST(8);
 	if (acc == 0x123456789ull || word == 0xdeadbeefu) { sink[0] = acc; }
 }
@@ -117,6 +144,8 @@ int main(int argc, char** argv) {
 	printf("top register " TOP ", margin " MARGIN ", %u workgroups x %u launches: of %llu lanes %u read back a different value, %u got a wrong 64-bit shift by it"
 	       " (%u), %u wavefront-steps (%s)\n",
 	       wgs, reps, static_cast<unsigned long long>(wgs) * 256ull * reps, bad[0], bad[1], bad[2], bad[3], hipGetErrorString(hipGetLastError()));
+	printf("   other 64-bit instructions with their 32-bit operand in " TOP ": v_ldexp_f64 %u wrong, v_cvt_f64_u32 %u, v_mad_u64_u32 %u, v_lshl_add_u64 %u\n", bad[28], bad[29], bad[30],
+	       bad[31]);
 	for (unsigned k = 0; k < bad[3] && k < 8; ++k) {
 		const uint32_t h = bad[4 + 3 * k], e = bad[5 + 3 * k];
 		printf("   step %u lane 1: shift wanted %u, result = shift by %u (99: by none); HW_ID %08x: wave %u simd %u cu %u se %u\n", e & 255u, (e >> 8) & 255u, e >> 16, h, h & 15u,
