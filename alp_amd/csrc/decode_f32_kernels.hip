@@ -382,7 +382,9 @@ template <int SINK>
 __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                       const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
                                                                       uint64_t n_vectors, uint64_t wg_offset, float lo, float hi) {
-	asm volatile("" ::: "v64"); // one register more than the kernel uses is allocated: its last register is never live (decode_kernels.hip: k_sink_direct)
+	#ifdef ALPGPU_SINK_REGISTER_MARGIN
+	asm volatile("" ::: "v64"); // decode_kernels.hip: k_sink_direct
+#endif
 	__shared__ SinkWaveLdsF32 S[kDecThreadsF / 64];
 	const int      lane = static_cast<int>(threadIdx.x) & 63;
 	const int      wv   = wave_in_wg();

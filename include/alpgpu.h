@@ -130,8 +130,8 @@ typedef struct alpgpu_column {
 	 * (e.g. states supplied by the caller) is ignored. */
 	uint16_t*              d_rd_order;
 	/* host-side hint (ABI version 3; zero-initialise it): 0 = unknown, else 1 + the number of ALP_RD rowgroups of the column, as counted by
-	 * alpgpu_column_totals (a small kernel over d_rowgroups) or alpgpu_column_from_blob.  The float consumers (alpgpu_decode_sum_f32, ...)
-	 * take the staged kernel when it says the column holds ALP_RD rowgroups; the double consumers no longer read it. */
+	 * alpgpu_column_totals (a small kernel over d_rowgroups) or alpgpu_column_from_blob.  Informational: the fused consumers chose their
+	 * kernel by it while the one-wavefront kernel's ALP_RD arm spilled; they no longer read it. */
 	uint64_t               alp_rd_rowgroups_hint;
 } alpgpu_column;
 #define ALPGPU_RD_ORDER_STRIDE 296u
@@ -427,9 +427,8 @@ int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
 /* The fused consumers of alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 for float columns.  Sums accumulate in double
  * (every float widens exactly): thread t = 64 w + L of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0, giving
  * p[w][L]; then s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); then the balanced tree over adjacent lanes over the 64 s[L] (as for
- * double; earlier in round 3 each wavefront ran the tree first).  ALPGPU_OPT_CONSUMER_PIPELINED: 0 = one wavefront per vector unless the
- * column is known to hold ALP_RD rowgroups (alp_rd_rowgroups_hint > 1), 2 = one wavefront per vector, 1 / 3 = the staged four-wavefront
- * kernel; same bits. */
+ * double; earlier in round 3 each wavefront ran the tree first).  ALPGPU_OPT_CONSUMER_PIPELINED: 0 / 2 = one wavefront per vector (the
+ * default for float columns whatever they hold), 1 / 3 = the staged four-wavefront kernel; same bits. */
 int alpgpu_decode_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 int alpgpu_decode_count_range_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
 int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values);
