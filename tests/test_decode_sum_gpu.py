@@ -107,9 +107,10 @@ def test_decode_sum_matches_documented_order(ctx, oracle, name, shape):
 
 def test_exception_records_that_change_nothing(ctx, oracle, shape):
     """A clean ALP column whose vectors carry 60-100 exception records each that repeat the value already encoded at their position: every
-    part of the exception machinery runs (records staged, mask, lookup, patch) and none of it may change a sum.  This is the column that
-    exposed the ds_bpermute lookup in the one-wavefront kernel (decode_kernels.hip: exception_hits_lds): ~5 % of the vectors came back
-    wrong in some builds, in others none."""
+    part of the exception machinery runs (records staged, mask, lookup, patch) and none of it may change a sum, so every wrong sum is a wrong
+    NON-exception.  This is the column on which the builds that returned wrong sums (~5 % of the vectors; cause: a 64-bit shift whose amount
+    sat in the kernel's last allocated register reads VGPR0 on gfx950 — tools/last_vgpr_probe.hip, tests/test_build_rules.py) were taken
+    apart."""
     from alp_amd import capi
     col = np.concatenate([datagen.decimal_column(100, 2, lo=-9e4, hi=9e4, seed=70 + i) for i in range(4)] * 15)
     enc = oracle.encode_column(col)
@@ -137,7 +138,8 @@ def test_exception_carrying_vectors_across_a_full_chip(ctx, oracle, shape, neigh
     """6000 vectors = more wavefronts than the chip holds at once, ~8 % exceptions in every other rowgroup, repeated: a build of the
     one-wavefront kernel whose register allocation differed (no scratch, an experiment of round 3) returned wrong sums for ~4 % of exactly
     these vectors, only past the first ~2000 and not the same ones from run to run — the small columns of the other tests never saw it
-    (cause: the exception lookup by ds_bpermute with loads in flight, see test_exception_records_that_change_nothing)."""
+    (cause: see test_exception_records_that_change_nothing; the vectors that fail are the ones whose conversion needs the literal arm, where
+    the failing builds kept a shift amount in their last register)."""
     from alp_amd import capi
     d1 = datagen.decimal_column(100, 1, seed=41)
     d3 = datagen.decimal_column(100, 3, seed=43)
