@@ -39,3 +39,16 @@ _ZN1a1iEv:
 """
     found = check_top_vgpr.kernels_with_pattern(asm)
     assert [(n, k) for n, k, _ in found] == [("_ZN1a1kEv", 64)]
+
+
+def test_committed_profiles_are_those_of_the_built_library():
+    """profiles/hbm_traffic.json (what bench.py quotes as roofline.traffic) and profiles/r03_hbm_traffic.json carry the sha-256 prefix of the
+    library they were measured with; the library in the tree is that one (builds are deterministic: same sources, same compiler, same bytes)"""
+    import hashlib
+    import json
+    lib = os.path.join(ROOT, "alp_amd", "libalpgpu.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    assert json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["lib_sha16"] == sha
+    assert json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))["library_sha256_16"] == sha
