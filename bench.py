@@ -366,6 +366,7 @@ class Clock:
         self.barrier()
         elapsed = time.perf_counter() - t0
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # average step duration (HIP events, launch stream)
+        self.local = (elapsed, kern_ms)  # THIS rank's clock, for its record in `ranks`; what is returned is the max over ranks
         if self.dist is not None:
             t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=self.reduce_on)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -378,6 +379,32 @@ class Clock:
         t = torch.tensor([x], dtype=torch.int64, device=self.reduce_on)
         self.dist.all_reduce(t)
         return int(t[0])
+
+
+def gather_rank_records(dist, record: dict, world: int):
+    """every rank's record on rank 0 (all ranks get the list): `ranks` of the N > 1 line — per-GPU rates and device identities of ONE shot,
+    since the 8-GPU node is the driver's and its run cannot be repeated.  Objects travel through the process group's own collectives
+    (RCCL on the GPU box, gloo in the CPU tests)."""
+    if dist is None or world == 1:
+        return [record]
+    out = [None] * world
+    dist.all_gather_object(out, record)
+    return sorted(out, key=lambda r: r["rank"])
+
+
+def device_identity(local_rank: int) -> dict:
+    """what tells two GPUs of a node apart in a log: marketing name, PCI bus id, compute units, HBM size"""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        ident = {"device": p.name, "cu_count": int(p.multi_processor_count), "hbm_GiB": round(p.total_memory / 2**30, 1), "local_rank": local_rank}
+        for attr in ("pci_bus_id", "pci_device_id", "pci_domain_id"):
+            if hasattr(p, attr):
+                ident[attr] = int(getattr(p, attr))
+        if hasattr(p, "uuid"):
+            ident["uuid"] = str(p.uuid)
+        return ident
+    except Exception as exc:  # (dry run on a box without a GPU)
+        return {"device": f"none ({type(exc).__name__})", "local_rank": local_rank}
 
 
 def encode_alg_bytes(n, pb, eb):
@@ -455,14 +482,19 @@ def dry_run(args):
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0, float(n)], dtype=torch.float64)
     cover = torch.tensor([n], dtype=torch.int64)
+    seen = world
+    ranks = [{"rank": rank, "first_vector": first, "vectors": n, **device_identity(int(os.environ.get("LOCAL_RANK", "0")))}]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cover)
+        seen = dist.get_world_size()
+        ranks = gather_rank_records(dist, ranks[0], world)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "dry run: no GPU work", "value": 0.0, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "data": "none (ALPGPU_BENCH_DRY_RUN)", "config": {"column_vectors": total, "vectors_covered_by_the_shards": int(cover[0])}}), flush=True)
+        print(json.dumps({"metric": "dry run: no GPU work", "value": 0.0, "unit": "GB/s", "n_gpus": world, "world_size_seen": seen, "steps": args.steps, "warmup": args.warmup,
+                          "data": "none (ALPGPU_BENCH_DRY_RUN)", "config": {"column_vectors": total, "vectors_covered_by_the_shards": int(cover[0])},
+                          "ranks": ranks}), flush=True)
 
 
 def main():
@@ -562,11 +594,13 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
                        "decode_launch_shape": f"{shape} vector(s) per 4-wave workgroup (chosen from the column's size hints)",
                        "parallelism": f"{world} whole-rowgroup shards, no collective on the data path"})
     del col
+    d_local_elapsed, d_local_ms = clock.local
     # ---- encode leg: the rank's shard of the mixed column, generated on the device; round trip checked at full size
     x = mixed_column_shard(first, n, dev, seed=42)
     ecol = capi.DeviceColumn(n, local_rank, packed_capacity=int(n * 8192 * 0.60) + 4096, exc_capacity=int(n * 8192 * 0.15) + 4096)
     e_steps = max(3, min(args.steps, 10))
     e_elapsed, e_ms = clock.run(lambda: ctx.encode(x, ecol), e_steps, 2)
+    e_local_elapsed, e_local_ms = clock.local
     pb, eb, ov = ctx.column_totals(ecol)
     d_elapsed, d_ms = clock.run(lambda: ctx.decode(ecol, out), e_steps, 3)
     rt = bool(torch.equal(out.view(torch.int64), x.view(torch.int64)))
@@ -585,6 +619,17 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
                                         "roofline_frac_algorithmic": round((n * 8192 + pb + eb + 13 * n) / d_ms / 1e6 / HBM_PEAK_GBPS, 4)},
         "roundtrip_bit_exact_all_ranks": bool(rt_all),
     }
+    # every rank's own figures and device identity (configs[4]: "per-GPU and aggregate"): one 8-GPU shot returns all of them
+    mine = {"rank": rank, **device_identity(local_rank), "first_vector": first, "vectors": n,
+            "decode_ms": round(d_local_ms, 4), "decode_GBps": round(n * 8192 * args.steps / d_local_elapsed / 1e9, 2),
+            "decode_roofline_frac": round(alg_bytes / d_local_ms / 1e6 / HBM_PEAK_GBPS, 4),
+            "encode_ms": round(e_local_ms, 4), "encode_GBps": round(n * 8192 * e_steps / e_local_elapsed / 1e9, 2),
+            "encode_roofline_frac": round(e_alg / e_local_ms / 1e6 / HBM_PEAK_GBPS, 4), "roundtrip_bit_exact": rt, "lib_sha16": lib_sha16()}
+    result["ranks"] = gather_rank_records(clock.dist, mine, world)
+    result["world_size_seen"] = clock.dist.get_world_size() if clock.dist is not None else 1
+    result["per_gpu_value"] = round(float(np.mean([r["decode_GBps"] for r in result["ranks"]])), 2)
+    result["per_gpu_value_min"] = round(float(np.min([r["decode_GBps"] for r in result["ranks"]])), 2)
+    result["per_gpu_note"] = "per_gpu_value = mean of the ranks' own decode rates (their own clocks), _min the slowest; `value` = all shards / the max-over-ranks time"
     return result
 
 
@@ -601,7 +646,11 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
                       "falp fused decode, synthetic decimal doubles, 1024-value vectors, bit-width sweep 1-53 across rowgroups, no exceptions (BASELINE.json configs[1])",
                       "weak", {"vectors_per_gpu": n, "decoded_bytes_per_gpu": n * 8192,
                                "decode_launch_shape": f"{shape} vector(s) per 4-wave workgroup (chosen from the column's size hints)",
-                               "parallelism": "1 shard (python bench.py --gpus N shards ONE column over N ranks: configs[4])"})
+                               "parallelism": "1 shard (python bench.py --gpus N shards ONE column over N ranks: configs[4])",
+                               "scale_curve_note": "the N > 1 lines time the decode of each rank's shard of THIS column (same generator, global rowgroup indices) cut from a 100 GB "
+                                                   "column; a GPU's decode rate does not depend on the shard's length (4510 GB/s at 1 Mi vectors, 4543 GB/s at 11.3 M: "
+                                                   "profiles/r03_bench.json, r03_bench_configs4_n1.json), so this value is the curve's N = 1 point; "
+                                                   "`python bench.py --gpus 1 --column-gb 100` measures the capped 100 GB form itself"})
     traffic_from_profile(result, n)
     if args.no_extras:
         return result
@@ -612,13 +661,21 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     extras = {}
     # per-bit-width sweep at the FULL column size (1 Mi vectors): smaller columns leave the packed stream resident in
     # the 256 MiB Infinity Cache across launches and overstate narrow widths by up to 1.8x (profiles/r01_time_one.txt)
-    sweep = {}
-    for bw in (1, 2, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 53):
-        c, _, ab = build_decode_column(n, local_rank, seed=7, bw_of_rowgroup=bw)
-        med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
-        sweep[str(bw)] = {"decoded_GBps": round(n * 8192 / med / 1e6, 1), "roofline_frac": frac(ab, med), "vectors_per_wg": ctx.decode_vectors_per_wg(c)}
-        del c
-    extras["decode_sweep_by_bit_width"] = sweep
+    # EVERY width 1..53 (BASELINE.json configs[1] "bit-width sweep 1-53"), without exceptions and with 20 per vector (2 %); the summary prints
+    # the minimum, the 10th percentile and the mean, so that the headline (the mean of a column that mixes the widths) cannot hide a floor
+    def sweep_of(exc_per_vec):
+        rows = {}
+        for bw in range(1, 54):
+            c, _, ab = build_decode_column(n, local_rank, seed=7, bw_of_rowgroup=bw, exc_per_vec=exc_per_vec)
+            med, _ = time_launches(lambda: ctx.decode(c, out), 7, 6)
+            rows[str(bw)] = {"decoded_GBps": round(n * 8192 / med / 1e6, 1), "roofline_frac": frac(ab, med), "vectors_per_wg": ctx.decode_vectors_per_wg(c)}
+            del c
+        fr = np.array([rows[str(b)]["roofline_frac"] for b in range(1, 54)])
+        rows["summary"] = {"min": round(float(fr.min()), 4), "argmin_bit_width": int(fr.argmin()) + 1, "p10": round(float(np.percentile(fr, 10)), 4),
+                           "mean": round(float(fr.mean()), 4), "max": round(float(fr.max()), 4), "widths": 53, "exceptions_per_vector": exc_per_vec}
+        return rows
+    extras["decode_sweep_by_bit_width"] = sweep_of(0)
+    extras["decode_sweep_by_bit_width_2pct_exceptions"] = sweep_of(20)
     # 2 % exceptions (second run) and the 2-vectors-per-workgroup tuning option, which keeps twice the
     # bytes in flight: better for narrow widths and for vectors with exceptions, worse for wide ones
     exc_cases = {}

@@ -85,3 +85,17 @@ def test_world_size_that_disagrees_with_gpus_exits_non_zero():
     assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
     p = _run_bench(["--gpus", "8"], {}, timeout=120)  # no launcher, and (here) no 8 GPUs either
     assert p.returncode != 0 and "GPU(s) are visible" in p.stderr
+
+
+def test_gpus_4_dry_run_returns_four_rank_records():
+    """the one 8-GPU shot must come back with EVERY rank's figures: rank 0's line carries `ranks` (one record per rank, gathered through the
+    process group) and the world size the group itself reports"""
+    p = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--column-gb", "2"], {"ALPGPU_BENCH_DRY_RUN": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 4 and r["world_size_seen"] == 4
+    assert [x["rank"] for x in r["ranks"]] == [0, 1, 2, 3]
+    assert sum(x["vectors"] for x in r["ranks"]) == r["config"]["column_vectors"]
+    firsts = [x["first_vector"] for x in r["ranks"]]
+    assert firsts == sorted(firsts) and firsts[0] == 0 and all(f % 100 == 0 for f in firsts), "contiguous whole-rowgroup shards in rank order"
+    assert all("device" in x for x in r["ranks"])

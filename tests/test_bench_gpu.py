@@ -31,6 +31,13 @@ def test_two_ranks_shard_one_column_and_rank0_prints_one_line():
     assert r["value"] > 0 and r["roofline"]["frac"] > 0
     enc = r["encode"]
     assert enc["roundtrip_bit_exact_all_ranks"] is True and enc["overflow"] == 0 and enc["value"] > 0
+    # every rank's own record: device identity, shard, decode and encode figures (BASELINE.json configs[4]: "per-GPU and aggregate")
+    assert r["world_size_seen"] == 2 and [x["rank"] for x in r["ranks"]] == [0, 1]
+    for x in r["ranks"]:
+        assert x["vectors"] > 0 and x["first_vector"] % 100 == 0 and x["device"]
+        assert x["decode_GBps"] > 0 and x["encode_GBps"] > 0 and x["decode_ms"] > 0 and x["encode_ms"] > 0 and x["roundtrip_bit_exact"] is True
+    assert r["ranks"][1]["first_vector"] >= r["ranks"][0]["first_vector"] + r["ranks"][0]["vectors"], "rank 1's shard starts where rank 0's (possibly capped) shard ends or later"
+    assert r["per_gpu_value_min"] <= r["per_gpu_value"]
 
 
 def test_gpus_2_without_a_launcher_starts_its_own_ranks():
