@@ -215,6 +215,16 @@ __device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state_async(const
 		}
 		__builtin_amdgcn_s_sleep(32);
 	}
+#ifndef ALPGPU_STATE_SINGLE_READ
+	// The tag was seen: the publisher's other words reached memory BEFORE it stored the tag, so a load issued AFTER this observation returns
+	// them whole.  The load that saw the tag is not that load — nothing in the memory model says one 32-byte request cannot be served while
+	// the publisher is between its stores — so the state is read once more, behind the first load's completion (the
+	// readlane above consumed it: s_waitcnt vmcnt(0)).  One more L2-side hit per wavefront, under the vector's own loads.
+	if (ok) {
+		asm volatile("" ::: "memory");
+		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+#endif
 	uint32_t w[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) { w[i] = __builtin_amdgcn_readlane(mine, i); }

@@ -1244,7 +1244,7 @@ void shard_of(uint64_t n, int i, int k, uint64_t* first, uint64_t* count) {
 	const uint64_t first_rg = i * base + (static_cast<uint64_t>(i) < extra ? i : extra);
 	const uint64_t my_rg    = base + (static_cast<uint64_t>(i) < extra ? 1 : 0);
 	const uint64_t last     = (first_rg + my_rg) * 100 < n ? (first_rg + my_rg) * 100 : n;
-	*first                  = first_rg * 100;
+	*first                  = first_rg * 100 < n ? first_rg * 100 : n; // an empty trailing shard (more pieces than rowgroups) starts at the column's end, not past it
 	*count                  = last > *first ? last - *first : 0;
 }
 
@@ -1281,9 +1281,10 @@ int compress_host_multi(alpgpu_ctx* const* ctxs, int k, const void* h_in, uint64
 	std::vector<std::string> errs(k);
 	for (int i = 0; i < k; ++i) { shard_of(n, i, k, &first[i], &count[i]); }
 	for (int i = 0; i <= k; ++i) { // region i = [reg_off[i], reg_off[i+1]) of the stream area, 8-byte aligned, in proportion to the vectors
-		const uint64_t upto = i < k ? first[i] : n;
+		const uint64_t upto = (i < k && first[i] < n) ? first[i] : n; // never past the column: a region must end inside the caller's buffer
 		reg_off[i]          = n ? (static_cast<uint64_t>(static_cast<unsigned __int128>(room) * upto / n) & ~7ull) : 0;
 	}
+	if (reg_off[k] > room) { return fail(ALPGPU_ERR_INVALID, "internal: shard regions exceed the blob buffer"); } // (cannot happen: upto <= n)
 	std::vector<std::thread> th;
 	for (int i = 0; i < k; ++i) {
 		th.emplace_back([&, i]() {
@@ -1303,7 +1304,23 @@ int compress_host_multi(alpgpu_ctx* const* ctxs, int k, const void* h_in, uint64
 		if (rcs[i] != ALPGPU_OK && (bad < 0 || rcs[bad] == ALPGPU_ERR_CAPACITY)) { bad = i; } // a failure other than "too small" is reported first
 	}
 	if (bad >= 0) {
-		if (written) { *written = rcs[bad] == ALPGPU_ERR_CAPACITY ? worst_case_blob<VALUE_BYTES>(n) : alpgpu_blob_size(n, total_p, total_e); }
+		if (written) {
+			*written = alpgpu_blob_size(n, total_p, total_e);
+			if (rcs[bad] == ALPGPU_ERR_CAPACITY) {
+				// "Too small" here means: some shard did not fit ITS region (regions are proportional to the shards' vector counts).  Every piece
+				// has counted its true sizes, so the capacity that makes every region large enough is known: the largest
+				// (bytes of shard i) * n / (vectors of shard i), plus the fixed part — at most the worst-case size, which always suffices.
+				unsigned __int128 need_room = 0;
+				for (int i = 0; i < k; ++i) {
+					if (count[i] == 0) { continue; }
+					const unsigned __int128 r = (static_cast<unsigned __int128>(align8(pb[i]) + align8(eb[i]) + 16) * n + count[i] - 1) / count[i];
+					need_room                 = r > need_room ? r : need_room;
+				}
+				const uint64_t worst = worst_case_blob<VALUE_BYTES>(n);
+				const unsigned __int128 want = static_cast<unsigned __int128>(fixed) + need_room + 64ull * k;
+				*written = want < worst ? static_cast<uint64_t>(want) : worst;
+			}
+		}
 		return fail(rcs[bad], errs[bad].c_str());
 	}
 	if (written) { *written = alpgpu_blob_size(n, total_p, total_e); }

@@ -255,37 +255,70 @@ struct rowgroup {
 // This is what replaces the reference's caller loop (publication/source_code/bench_compression_ratio/alp.cpp:198-229) as a whole.
 // A pool of contexts for a list of devices (one each; the same device may be listed more than once — e.g. in tests on a one-GPU box):
 // what alp::gpu::column<PT>::compress / decompress over a device list run on.  Contexts live until the process ends.
-inline std::vector<alpgpu_ctx*> contexts_for(const std::vector<int>& devices) {
-	static std::mutex                                   mu;
-	static std::vector<std::pair<int, alpgpu_ctx*>>     pool; // (device, context), in creation order
-	std::lock_guard<std::mutex>                         lock(mu);
-	std::vector<alpgpu_ctx*>                            out;
-	std::vector<bool>                                   taken(pool.size(), false);
-	for (int dev : devices) {
-		alpgpu_ctx* c = nullptr;
-		for (size_t i = 0; i < pool.size(); ++i) {
-			if (!taken[i] && pool[i].first == dev) {
-				taken[i] = true;
-				c        = pool[i].second;
-				break;
-			}
-		}
-		if (!c) {
-			check(alpgpu_ctx_create(dev, &c), "alpgpu_ctx_create");
-			pool.emplace_back(dev, c);
-			taken.push_back(true);
-		}
-		out.push_back(c);
+// A context serves ONE pipeline at a time (include/alpgpu.h: "a context must not be used by anything else during the call"), so the pool
+// hands contexts out as a LEASE: entries are marked in use until the lease is destroyed, and a second thread that asks for the same devices
+// meanwhile gets other (new) contexts.  column<PT>::compress / decompress over a device list are thereby safe to call from several threads.
+struct context_pool {
+	struct entry {
+		int         device;
+		alpgpu_ctx* ctx;
+		bool        in_use;
+	};
+	std::mutex         mu;
+	std::vector<entry> entries; // in creation order; contexts live until the process ends
+	static context_pool& instance() {
+		static context_pool p;
+		return p;
 	}
-	return out;
-}
+};
+class context_lease {
+	std::vector<alpgpu_ctx*> ctxs_;
+	std::vector<size_t>      held_;
+
+public:
+	explicit context_lease(const std::vector<int>& devices) {
+		context_pool&               P = context_pool::instance();
+		std::lock_guard<std::mutex> lock(P.mu);
+		try {
+			for (int dev : devices) {
+				size_t at = P.entries.size();
+				for (size_t i = 0; i < P.entries.size(); ++i) {
+					if (!P.entries[i].in_use && P.entries[i].device == dev) {
+						at = i;
+						break;
+					}
+				}
+				if (at == P.entries.size()) {
+					alpgpu_ctx* c = nullptr;
+					check(alpgpu_ctx_create(dev, &c), "alpgpu_ctx_create");
+					P.entries.push_back({dev, c, false});
+				}
+				P.entries[at].in_use = true;
+				held_.push_back(at);
+				ctxs_.push_back(P.entries[at].ctx);
+			}
+		} catch (...) {
+			for (size_t i : held_) { P.entries[i].in_use = false; }
+			throw;
+		}
+	}
+	~context_lease() {
+		context_pool&               P = context_pool::instance();
+		std::lock_guard<std::mutex> lock(P.mu);
+		for (size_t i : held_) { P.entries[i].in_use = false; }
+	}
+	context_lease(const context_lease&)            = delete;
+	context_lease& operator=(const context_lease&) = delete;
+	const std::vector<alpgpu_ctx*>& contexts() const { return ctxs_; }
+};
 
 template <class PT>
 struct column {
 	// The column cut into whole-rowgroup shards over `devices` (alpgpu_compress_host_multi_*): every GPU of the node works on its shard
 	// over its own PCIe link, the result is the one-device blob byte for byte.
 	static std::vector<uint8_t> compress(const PT* values, size_t n_values, const std::vector<int>& devices) {
-		const std::vector<alpgpu_ctx*> ctxs = contexts_for(devices);
+		const context_lease             lease(devices); // the contexts are this call's until it returns
+		const std::vector<alpgpu_ctx*>& ctxs = lease.contexts();
 		const uint64_t                 n    = (n_values + config::VECTOR_SIZE - 1) / config::VECTOR_SIZE;
 		uint64_t                       cap  = alpgpu_blob_size(n, n * config::VECTOR_SIZE * sizeof(PT) + 1024 * ctxs.size(), 0);
 		std::vector<uint8_t>           blob;
@@ -305,7 +338,8 @@ struct column {
 		return blob;
 	}
 	static std::vector<PT> decompress(const uint8_t* blob, size_t size, const std::vector<int>& devices) {
-		const std::vector<alpgpu_ctx*> ctxs = contexts_for(devices);
+		const context_lease             lease(devices);
+		const std::vector<alpgpu_ctx*>& ctxs = lease.contexts();
 		uint64_t  n_values = 0;
 		const int probe    = sizeof(PT) == 8 ? alpgpu_decompress_host_multi_f64(ctxs.data(), 1, blob, size, nullptr, 0, &n_values)
 		                                     : alpgpu_decompress_host_multi_f32(ctxs.data(), 1, blob, size, nullptr, 0, &n_values);

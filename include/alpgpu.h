@@ -208,7 +208,10 @@ int alpgpu_decompress_host_f32(alpgpu_ctx* ctx, const void* h_blob, uint64_t siz
  * shards before ended: no collective, a host-side concatenation is the only exchange).  This is how a C / C++ caller that holds a
  * host column (publication/source_code/bench_compression_ratio/alp.cpp:198-229; the worker loop of
  * publication/source_code/bench_end_to_end/src/benchmarks/alp/run_query.cpp:233-305) uses all GPUs of a node from one process.
- * Capacity and *written as above (regions of the caller's buffer serve as the shards' staging: the worst-case size always suffices).
+ * Capacity: regions of the caller's buffer, proportional to the shards' vector counts, serve as the shards' staging, so a shard that
+ * compresses worse than the column's average can fail with ALPGPU_ERR_CAPACITY although the sum would fit; *written is then the capacity with
+ * which every shard fits its region (never more than the worst-case size alpgpu_blob_size(n, packed_capacity(n), exc_capacity(n)), which
+ * always suffices — the capacities' constant terms cover the regions' 8-byte rounding for n_ctx <= 64); on success *written is the blob's size.
  * A context must not be used by anything else during the call; ctxs[i] must be distinct. */
 int alpgpu_compress_host_multi_f64(alpgpu_ctx* const* ctxs, int n_ctx, const double* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);
 int alpgpu_compress_host_multi_f32(alpgpu_ctx* const* ctxs, int n_ctx, const float* h_in, uint64_t n_values, void* h_blob, uint64_t capacity, uint64_t* written);

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "alp.hpp"
@@ -91,7 +92,8 @@ int main(int argc, char** argv) {
 	// a buffer that is too small: refused, with the size that works
 	{
 		const std::vector<double>      col  = make_column<double>(4000 * 1024, 5);
-		const std::vector<alpgpu_ctx*> ctxs = alp::gpu::contexts_for(devices);
+		const alp::gpu::context_lease   lease(devices);
+		const std::vector<alpgpu_ctx*>& ctxs = lease.contexts();
 		std::vector<uint8_t>           small(alpgpu_blob_size(4000, 0, 0) + 4096 * devices.size());
 		uint64_t                       written = 0;
 		const int rc = alpgpu_compress_host_multi_f64(ctxs.data(), static_cast<int>(ctxs.size()), col.data(), col.size(), small.data(), small.size(), &written);
@@ -102,6 +104,31 @@ int main(int argc, char** argv) {
 		       "the size returned must work");
 		alpgpu_ctx* twice[2] = {ctxs[0], ctxs[0]};
 		EXPECT(alpgpu_compress_host_multi_f64(twice, 2, col.data(), col.size(), right.data(), right.size(), &w2) == ALPGPU_ERR_INVALID, "the same context twice is refused");
+	}
+	// two host threads over the SAME device list at the same time: the pool leases each of them its own contexts (a context serves one
+	// pipeline at a time), both blobs are the one-context blob
+	{
+		const std::vector<double> col  = make_column<double>(30000ull * 1024 + 77, 9);
+		const auto                want = alp::gpu::column<double>::compress(col.data(), col.size(), std::vector<int> {devices[0]});
+		std::vector<uint8_t>      got[2];
+		std::vector<double>       back[2];
+		std::thread               th[2];
+		for (int t = 0; t < 2; ++t) {
+			th[t] = std::thread([&, t]() {
+				got[t]  = alp::gpu::column<double>::compress(col.data(), col.size(), devices);
+				back[t] = alp::gpu::column<double>::decompress(got[t].data(), got[t].size(), devices);
+			});
+		}
+		for (auto& x : th) { x.join(); }
+		for (int t = 0; t < 2; ++t) {
+			EXPECT(got[t] == want, "concurrent compress, thread %d: blob differs from the one-context blob", t);
+			EXPECT(back[t].size() == col.size() && std::memcmp(back[t].data(), col.data(), col.size() * 8) == 0, "concurrent round trip, thread %d", t);
+		}
+		// a lease held here keeps its contexts out of another lease's hands
+		const alp::gpu::context_lease a(devices), b(devices);
+		for (alpgpu_ctx* x : a.contexts()) {
+			for (alpgpu_ctx* y : b.contexts()) { EXPECT(x != y, "two live leases share a context"); }
+		}
 	}
 	std::printf("multi_test: %d failures\n", failures);
 	return failures ? 1 : 0;

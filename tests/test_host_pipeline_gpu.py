@@ -134,3 +134,33 @@ def test_several_contexts_write_the_one_context_blob(dtype):
     bad.numpy()[64 + 32 * nrg: 64 + 32 * nrg + 32 * n].view(capi.VECTOR_DTYPE)[n - 5]["bw"] = 77
     with pytest.raises(capi.AlpGpuError):
         capi.Context.decompress_host_multi(ctxs[:3], bad, torch.empty(n_values, dtype=dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_more_contexts_than_rowgroups_and_a_short_buffer(dtype):
+    """with more contexts than rowgroups the trailing shards are empty; their regions must not reach past the caller's buffer.
+    An incompressible column of 150 vectors (2 rowgroups, n % 100 != 0) over 5 contexts, into a buffer that is too small: the call fails with
+    ALPGPU_ERR_CAPACITY, writes nothing behind the buffer (a guard band stays intact), and the size it reports is one that works."""
+    import ctypes as C
+    ctxs = [capi.Context(0) for _ in range(5)]
+    n_values = 150 * 1024 - 7
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.random(n_values).astype(np.float64 if dtype == torch.float64 else np.float32))  # ALP_RD: ~7/8 of the input stays
+    t = "f64" if dtype == torch.float64 else "f32"
+    want = ctxs[0].compress_host(x)
+    small = int(want.numel() * 0.6) // 8 * 8
+    guard = 1 << 16
+    buf = torch.full((small + guard,), 0xAB, dtype=torch.uint8)
+    arr = (C.c_void_p * 5)(*[c.h for c in ctxs])
+    w = C.c_uint64()
+    rc = getattr(capi.lib, "alpgpu_compress_host_multi_" + t)(arr, 5, C.c_void_p(x.data_ptr()), n_values, C.c_void_p(buf.data_ptr()), small, C.byref(w))
+    assert rc != 0 and b"small" in capi.lib.alpgpu_last_error()
+    assert bool((buf[small:] == 0xAB).all()), "bytes behind the caller's capacity were written"
+    assert w.value > small
+    big = torch.empty(w.value, dtype=torch.uint8)
+    blob = capi.Context.compress_host_multi(ctxs, x, big)  # the reported size suffices
+    assert torch.equal(blob, want)
+    out = torch.empty(n_values, dtype=dtype)
+    assert capi.Context.decompress_host_multi(ctxs, blob, out) == n_values
+    it = torch.int64 if dtype == torch.float64 else torch.int32
+    assert torch.equal(out.view(it), x.view(it))

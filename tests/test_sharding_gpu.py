@@ -149,3 +149,42 @@ def test_full_size_encode_columns(ctx, oracle, kind):
             assert np.array_equal(got["pos"][v, :c], want["pos"][v, :c]), (kind, g, v, "positions")
             w = np.uint64 if want["scheme"][v] == 2 else np.uint16
             assert np.array_equal(got["exc"][v].view(w)[:c], want["exc"][v].view(w)[:c]), (kind, g, v, "exception values")
+
+
+def test_one_context_per_visible_device_in_one_process():
+    """The in-process multi-GPU path (alpgpu_compress_host_multi_* / alpgpu_decompress_host_multi_*) on EVERY GPU the box has: one context per
+    device, one host column cut into whole-rowgroup shards, ONE blob — byte for byte the blob of device 0 alone — and a per-device encode /
+    decode round trip issued from this one thread in turn (every entry point makes its context's device current itself:
+    tools/audit_set_device.py).  Needs two GPUs: skipped on the one-GPU test boxes, armed for the first node that has more."""
+    import datagen
+    from alp_amd import capi
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} GPU visible: the multi-device form needs two")
+    ctxs = [capi.Context(d) for d in range(n_dev)]  # each follows torch's current stream of ITS device
+    for d, c in enumerate(ctxs):
+        assert "gfx950" in c.device_info()["name"], (d, c.device_info())
+    n = 100 * 3 * n_dev + 57
+    a = datagen.mixed_column(n, seed=77, exc_rate=0.01)
+    a[: 200 * 1024] = np.random.default_rng(1).random(200 * 1024)  # two ALP_RD rowgroups
+    x = torch.from_numpy(a)
+    want = ctxs[0].compress_host(x)
+    blob = capi.Context.compress_host_multi(ctxs, x)
+    assert torch.equal(blob, want), "the shards of all devices join into the one-device blob"
+    out = torch.empty(n * 1024, dtype=torch.float64)
+    assert capi.Context.decompress_host_multi(ctxs, blob, out) == n * 1024
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+    # device-resident columns on every device, driven from this thread in turn (the current device changes under each call)
+    cols = []
+    for d, c in enumerate(ctxs):
+        with torch.cuda.device(d):
+            xd = x.to(f"cuda:{d}")
+        cols.append((xd, c.encode(xd)))
+    for d, c in reversed(list(enumerate(ctxs))):
+        xd, col = cols[d]
+        back = c.decode(col)
+        c.synchronize()
+        assert back.device.index == d and torch.equal(back.view(torch.int64), xd.view(torch.int64)), f"device {d}"
+        host = col.to_host()
+        for got, ref, what in zip(host, cols[0][1].to_host(), ("rowgroup states", "descriptors", "packed stream", "exception stream")):
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (d, what)
