@@ -130,6 +130,8 @@ _sig("alpgpu_state_from_samples_f32", _int, _vp, _vp, C.c_uint32, _vp)
 _sig("alpgpu_rd_state_from_samples_f32", _int, _vp, _vp, C.c_uint32, _vp)
 _sig("alpgpu_state_from_samples_f64", _int, _vp, _vp, C.c_uint32, _vp)
 _sig("alpgpu_rd_state_from_samples_f64", _int, _vp, _vp, C.c_uint32, _vp)
+_sig("alpgpu_rd_dictionary_for_cut_f64", _int, _vp, _vp, C.c_uint32, C.c_uint8, _vp, _vp)
+_sig("alpgpu_rd_dictionary_for_cut_f32", _int, _vp, _vp, C.c_uint32, C.c_uint8, _vp, _vp)
 _sig("alpgpu_pad_tail_f32", _int, _vp, _vp, _u64)
 _sig("alpgpu_column_to_blob_f32", _int, _vp, C.POINTER(CColumn), _u64, _vp, _u64, C.POINTER(_u64))
 _sig("alpgpu_column_from_blob_f32", _int, _vp, _vp, _u64, C.POINTER(CColumn), C.POINTER(_u64))
@@ -301,6 +303,10 @@ class Context:
         """samples: device tensor of 1..288 first-level samples; state: 32-byte uint8 device tensor"""
         self._call("rd_state_from_samples" if rd_only else "state_from_samples", self._sfx(samples), _vp(samples.data_ptr()), samples.numel(),
                    _vp(state.data_ptr()))
+
+    def rd_dictionary_for_cut(self, samples, right_bit_width: int, state, estimate):
+        """rd_encoder::build_left_parts_dictionary for one cut: state (32-byte uint8 device tensor) and estimate (1 float64, device) are written"""
+        self._call("rd_dictionary_for_cut", self._sfx(samples), _vp(samples.data_ptr()), samples.numel(), right_bit_width, _vp(state.data_ptr()), _vp(estimate.data_ptr()))
 
     # ---- tail padding + serialized container ------------------------------------------------------
     def pad_tail(self, x, n_values: int):

@@ -316,11 +316,11 @@ int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vec
 	return ALPGPU_OK;
 }
 
-static int state_from_samples(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+static int state_from_samples(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_estimate = nullptr) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_samples || !d_state) { return fail(ALPGPU_ERR_INVALID, "null samples or state"); }
 	if (n_samples == 0 || n_samples > 288) { return fail(ALPGPU_ERR_INVALID, "n_samples must be 1..288 (9 sampled vectors x 32)"); }
-	if (alpgpu::launch_state_from_samples(ctx->stream, d_samples, n_samples, d_state, force_rd) != ALPGPU_OK) {
+	if (alpgpu::launch_state_from_samples(ctx->stream, d_samples, n_samples, d_state, force_rd, d_estimate) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "state-from-samples launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;
@@ -332,6 +332,11 @@ int alpgpu_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint
 
 int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state) {
 	return state_from_samples(ctx, d_samples, n_samples, d_state, 1);
+}
+// rd_encoder::build_left_parts_dictionary for ONE cut (rd.hpp:33-87): the kernel of alpgpu_rd_state_from_samples with every other cut ruled out
+int alpgpu_rd_dictionary_for_cut_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, uint8_t right_bit_width, alpgpu_rowgroup_state* d_state, double* d_estimate) {
+	if (right_bit_width < 48 || right_bit_width > 63) { return fail(ALPGPU_ERR_INVALID, "right_bit_width must be 48..63 (a cut of 1..16 bits, rd.hpp:92)"); }
+	return state_from_samples(ctx, d_samples, n_samples, d_state, 0x100 | (64 - right_bit_width), d_estimate);
 }
 
 // Single pass, with the recovery route enqueued behind it: the two-pass kernels, gated on the stall flag the single pass
@@ -883,11 +888,11 @@ int alpgpu_rowgroup_init_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vect
 	return ALPGPU_OK;
 }
 
-static int state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+static int state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_estimate = nullptr) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!d_samples || !d_state) { return fail(ALPGPU_ERR_INVALID, "null samples or state"); }
 	if (n_samples == 0 || n_samples > 288) { return fail(ALPGPU_ERR_INVALID, "n_samples must be 1..288 (9 sampled vectors x 32)"); }
-	if (alpgpu::launch_state_from_samples_f32(ctx->stream, d_samples, n_samples, d_state, force_rd) != ALPGPU_OK) {
+	if (alpgpu::launch_state_from_samples_f32(ctx->stream, d_samples, n_samples, d_state, force_rd, d_estimate) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "state-from-samples launch failed", hipGetLastError());
 	}
 	return ALPGPU_OK;
@@ -897,6 +902,10 @@ int alpgpu_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint3
 }
 int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state) {
 	return state_from_samples_f32(ctx, d_samples, n_samples, d_state, 1);
+}
+int alpgpu_rd_dictionary_for_cut_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, uint8_t right_bit_width, alpgpu_rowgroup_state* d_state, double* d_estimate) {
+	if (right_bit_width < 16 || right_bit_width > 31) { return fail(ALPGPU_ERR_INVALID, "right_bit_width must be 16..31 (a cut of 1..16 bits, rd.hpp:92)"); }
+	return state_from_samples_f32(ctx, d_samples, n_samples, d_state, 0x100 | (32 - right_bit_width), d_estimate);
 }
 
 static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col, bool async_states) { // see encode_vectors_f64

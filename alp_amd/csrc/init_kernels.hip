@@ -284,7 +284,7 @@ __device__ __forceinline__ void store_rowgroup_state(alpgpu_rowgroup_state* __re
 template <class P, bool FROM_SAMPLES, int W, bool ASYNC>
 __global__ __launch_bounds__(64 * W, (ASYNC && W == kInitAsyncWaves) ? kInitAsyncWavesPerSimd : 1) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
                                                           alpgpu_rowgroup_state* __restrict__ rgs, int force_rd,
-                                                          uint16_t* __restrict__ rd_order, uint64_t rg_first, uint64_t rg_end) {
+                                                          uint16_t* __restrict__ rd_order, uint64_t rg_first, uint64_t rg_end, double* __restrict__ cut_est_out) {
 	static_assert(!ASYNC || !FROM_SAMPLES, "the persistent form gathers its own samples");
 	static_assert(W >= 2 && W <= kMaxSampledVectors, "the scratch arrays are sized for 9 wavefronts; wavefront 0 and the order replay use two of them");
 	__shared__ typename P::value_t smp[kMaxSampledVectors * 32];
@@ -529,8 +529,18 @@ __global__ __launch_bounds__(64 * W, (ASYNC && W == kInitAsyncWaves) ? kInitAsyn
 	__syncthreads();
 
 	RdWaveScratch& WS = s_rd[wave];
+	// force_rd = 0x100 | cut: rd_encoder::build_left_parts_dictionary for ONE cut position (rd.hpp:33-87, called on its own): the other cuts
+	// get an estimate nothing beats, so the dictionary below is that cut's
+	const int forced_cut = (force_rd & 0x100) ? (force_rd & 0xFF) : 0;
 	for (int cut = wave + 1; cut <= 16; cut += W) { // wave-uniform
 		const int rbw = P::kBits - cut;
+		if (forced_cut != 0 && cut != forced_cut) {
+			if (lane == 0) {
+				s_cut_est[cut] = 1.7976931348623157e308;
+				s_cut_ds[cut]  = 0;
+			}
+			continue;
+		}
 		rd_build_runs(WS, nullptr, s_key, n_smp, cut, lane);
 		// histogram of run lengths; number of distinct left parts
 		int distinct = 0;
@@ -575,6 +585,7 @@ __global__ __launch_bounds__(64 * W, (ASYNC && W == kInitAsyncWaves) ? kInitAsyn
 			}
 		}
 		s_best_cut = bc;
+		if (cut_est_out != nullptr) { cut_est_out[blockIdx.x] = best; } // estimate_compression_size of the chosen (or forced) cut (rd.hpp:80-82)
 	}
 	__syncthreads();
 	if (wave == 0) { // the dictionary of the chosen cut: the (<= 8) best-ranked runs
@@ -648,7 +659,7 @@ int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vect
 	// (4-wavefront workgroups, six of them per CU instead of three of nine wavefronts, take exactly as long — 0.578 ms per 1 Mi vectors, 1.00 ms all-ALP_RD:
 	//  the search is bound by its arithmetic, not by its fixed latencies; profiles/r03_async_init.txt)
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false, kMaxSampledVectors, false>), dim3(static_cast<unsigned>(rg_count)), dim3(kInitThreads), 0, stream, d_in,
-	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count);
+	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
@@ -660,10 +671,10 @@ static int launch_rowgroup_init_async_t(hipStream_t stream, const typename P::va
 	const uint64_t g = rg_count < static_cast<uint64_t>(grid) ? rg_count : static_cast<uint64_t>(grid);
 	if (g == rg_count) { // one workgroup per rowgroup (the head in front of the encode): the 9-wavefront shape, publishing
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kMaxSampledVectors, true>), dim3(static_cast<unsigned>(g)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
-		                   d_rd_order, rg_first, rg_first + rg_count);
+		                   d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
 	} else {
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kInitAsyncWaves, true>), dim3(static_cast<unsigned>(g)), dim3(64 * kInitAsyncWaves), 0, stream, d_in, n_vectors, d_rgs,
-		                   0, d_rd_order, rg_first, rg_first + rg_count);
+		                   0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
@@ -676,9 +687,9 @@ int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64
 	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid);
 }
 
-int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, true, kMaxSampledVectors, false>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples),
-	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull);
+	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull, d_cut_estimate);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
@@ -689,13 +700,13 @@ int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_v
 	if (rg_first >= n_rg) { return ALPGPU_OK; }
 	if (rg_count == 0 || rg_first + rg_count > n_rg) { rg_count = n_rg - rg_first; }
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false, kMaxSampledVectors, false>), dim3(static_cast<unsigned>(rg_count)), dim3(kInitThreads), 0, stream, d_in,
-	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count);
+	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd) {
+int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, true, kMaxSampledVectors, false>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples),
-	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull);
+	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull, d_cut_estimate);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

@@ -30,7 +30,7 @@ int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first = 0,
                          uint64_t rg_count = 0);
 
-int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
+int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate = nullptr);
 // the persistent, publishing form (runs beside the single-pass encode on a second stream) and the tag clean-up behind it
 int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                uint64_t rg_count, int grid);
@@ -91,7 +91,7 @@ int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t*
 int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores);
 int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
                              uint64_t rg_first = 0, uint64_t rg_count = 0);
-int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd);
+int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate = nullptr);
 int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,
                             bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
 int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,

@@ -8,6 +8,7 @@
 #include "alp/decoder.hpp"
 #include "alp/gpu_bridge.hpp"
 #include <cmath>
+#include <stdexcept>
 #include "alp/sampler.hpp"
 #include <unordered_map>
 #include <utility>
@@ -125,6 +126,43 @@ struct encoder {
 		gpu::d2h(fe, s.fac(), 2);
 		stt.fac = fe[0];
 		stt.exp = fe[1];
+	}
+
+	//! second-level sampling on its own (encoder.hpp:241-305): the best of the rowgroup's top_k candidates for this vector.  It is the first half
+	//! of the device's vector encode (alpgpu_encode_values_*: candidate choice, then encode_simdized with the winner), whose choice is returned;
+	//! the 32 samples are the values at stride 32 of a whole vector, which is what the reference's encode() passes (stt.vector_size = 1024) —
+	//! another input_vector_size has no device form and throws std::invalid_argument.
+	static inline void find_best_exponent_factor_from_combinations(const std::vector<std::pair<int, int>>& top_combinations,
+	                                                               const uint8_t                           top_k,
+	                                                               const PT*                               input_vector,
+	                                                               const uint16_t                          input_vector_size,
+	                                                               uint8_t&                                factor,
+	                                                               uint8_t&                                exponent) {
+		if (input_vector_size != config::VECTOR_SIZE) { throw std::invalid_argument("alp::encoder::find_best_exponent_factor_from_combinations: whole vectors (1024 values) only"); }
+		if (top_k == 0 || top_k > config::MAX_K_COMBINATIONS || top_combinations.size() < top_k) {
+			if (top_k == 0) { // the reference's loop does not run: both stay 0
+				factor = exponent = 0;
+				return;
+			}
+			throw std::invalid_argument("alp::encoder::find_best_exponent_factor_from_combinations: top_k must be 1..5 and covered by top_combinations");
+		}
+		auto&                 s = gpu::tls();
+		alpgpu_rowgroup_state d {};
+		d.scheme = ALPGPU_SCHEME_ALP;
+		d.k      = top_k;
+		for (size_t i = 0; i < top_k; ++i) {
+			d.combos[2 * i]     = static_cast<uint8_t>(top_combinations[i].first);
+			d.combos[2 * i + 1] = static_cast<uint8_t>(top_combinations[i].second);
+		}
+		gpu::h2d(s.at<PT>(s.IN), input_vector, gpu::abi<PT>::VEC_BYTES);
+		gpu::h2d(s.at<alpgpu_rowgroup_state>(s.STATE), &d, sizeof(d));
+		gpu::check(gpu::abi<PT>::encode_values(s.at<PT>(s.IN), s.at<alpgpu_rowgroup_state>(s.STATE), s.at<PT>(s.EXC), s.at<uint16_t>(s.POS), s.cnt(),
+		                                       s.at<ST>(s.ENC), s.fac(), s.exp()),
+		           "alpgpu_encode_values");
+		uint8_t fe[2];
+		gpu::d2h(fe, s.fac(), 2);
+		factor   = fe[0];
+		exponent = fe[1];
 	}
 
 	//! encoder.hpp:307-400 with an explicit (factor, exponent)

@@ -68,6 +68,7 @@ struct abi<double> {
 	static constexpr size_t VEC_BYTES = 8192;
 	static int state_from_samples(const double* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_state_from_samples_f64(context(), smp, n, st); }
 	static int rd_state_from_samples(const double* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_rd_state_from_samples_f64(context(), smp, n, st); }
+	static int rd_dictionary_for_cut(const double* smp, uint32_t n, uint8_t rbw, alpgpu_rowgroup_state* st, double* est) { return alpgpu_rd_dictionary_for_cut_f64(context(), smp, n, rbw, st, est); }
 	static int encode_values(const double* in, const alpgpu_rowgroup_state* st, double* exc, uint16_t* pos, uint16_t* cnt, ST* enc, uint8_t* fac, uint8_t* exp) {
 		return alpgpu_encode_values_f64(context(), in, st, nullptr, exc, pos, 1024, cnt, enc, fac, exp, 1);
 	}
@@ -92,6 +93,7 @@ struct abi<float> {
 	static constexpr size_t VEC_BYTES = 4096;
 	static int state_from_samples(const float* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_state_from_samples_f32(context(), smp, n, st); }
 	static int rd_state_from_samples(const float* smp, uint32_t n, alpgpu_rowgroup_state* st) { return alpgpu_rd_state_from_samples_f32(context(), smp, n, st); }
+	static int rd_dictionary_for_cut(const float* smp, uint32_t n, uint8_t rbw, alpgpu_rowgroup_state* st, double* est) { return alpgpu_rd_dictionary_for_cut_f32(context(), smp, n, rbw, st, est); }
 	static int encode_values(const float* in, const alpgpu_rowgroup_state* st, float* exc, uint16_t* pos, uint16_t* cnt, ST* enc, uint8_t* fac, uint8_t* exp) {
 		return alpgpu_encode_values_f32(context(), in, st, nullptr, exc, pos, 1024, cnt, enc, fac, exp, 1);
 	}

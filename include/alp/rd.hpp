@@ -12,6 +12,7 @@
 #include "alp/encoder.hpp"
 #include "alp/gpu_bridge.hpp"
 #include "alp/sampler.hpp"
+#include <stdexcept>
 
 namespace alp {
 
@@ -19,6 +20,39 @@ template <class PT>
 struct rd_encoder {
 	using UT                                     = typename inner_t<PT>::ut;
 	static constexpr uint8_t EXACT_TYPE_BIT_SIZE = sizeof(UT) * 8;
+
+	//! rd.hpp:23-31: the bits per value a cut is estimated to cost within a sample (plain arithmetic on four numbers: no codec work in it)
+	static inline double estimate_compression_size(const bw_t right_bit_width, const bw_t left_bit_width, const exp_c_t exceptions_count, const uint64_t sample_count) {
+		const double exceptions_size = exceptions_count * (RD_EXCEPTION_POSITION_SIZE + RD_EXCEPTION_SIZE);
+		return right_bit_width + left_bit_width + (exceptions_size / static_cast<double>(sample_count));
+	}
+
+	//! rd.hpp:33-87: the dictionary of ONE cut position and its estimated size; PERSIST_DICT also writes it into the state.  The device runs the
+	//! kernel of find_best_dictionary with every other cut ruled out (alpgpu_rd_dictionary_for_cut_*): same left-part histogram, same
+	//! libstdc++ order of equally frequent parts.  The cut must be one find_best_dictionary can choose (1..16 bits: rd.hpp:92); anything else
+	//! throws std::invalid_argument (the reference would shift by whatever it is given).
+	template <bool PERSIST_DICT>
+	static double build_left_parts_dictionary(const PT* in_p, bw_t right_bit_width, state<PT>& stt) {
+		if (right_bit_width >= EXACT_TYPE_BIT_SIZE || EXACT_TYPE_BIT_SIZE - right_bit_width > config::CUTTING_LIMIT) {
+			throw std::invalid_argument("alp::rd_encoder::build_left_parts_dictionary: right_bit_width must leave a left part of 1..16 bits");
+		}
+		auto&        s       = gpu::tls();
+		const size_t n       = stt.sampled_values_n;
+		const size_t n_block = (n + config::SAMPLES_PER_VECTOR - 1) / config::SAMPLES_PER_VECTOR;
+		const size_t n_up    = n < config::SAMPLES_PER_VECTOR ? n : n_block * config::SAMPLES_PER_VECTOR;
+		gpu::h2d(s.at<PT>(s.SAMPLES), in_p, n_up * sizeof(PT));
+		gpu::check(gpu::abi<PT>::rd_dictionary_for_cut(s.at<PT>(s.SAMPLES), static_cast<uint32_t>(n), right_bit_width, s.at<alpgpu_rowgroup_state>(s.STATE),
+		                                               s.at<double>(s.META + 32)),
+		           "alpgpu_rd_dictionary_for_cut");
+		double estimate = 0.0;
+		gpu::d2h(&estimate, s.at<double>(s.META + 32), sizeof(double));
+		if (PERSIST_DICT) {
+			alpgpu_rowgroup_state d {};
+			gpu::d2h(&d, s.at<alpgpu_rowgroup_state>(s.STATE), sizeof(d));
+			persist(d, stt);
+		}
+		return estimate;
+	}
 
 	//! rd.hpp:180-185: sample the rowgroup, choose the cut and the dictionary
 	static inline void init(const PT* data_column, size_t column_offset, size_t tuples_count, PT* sample_arr, state<PT>& stt) {
@@ -39,6 +73,12 @@ struct rd_encoder {
 		           "alpgpu_rd_state_from_samples");
 		alpgpu_rowgroup_state d {};
 		gpu::d2h(&d, s.at<alpgpu_rowgroup_state>(s.STATE), sizeof(d));
+		persist(d, stt);
+	}
+
+private:
+	//! the fields build_left_parts_dictionary<true> leaves in the state (rd.hpp:69-84)
+	static inline void persist(const alpgpu_rowgroup_state& d, state<PT>& stt) {
 		stt.right_bit_width              = d.rd_rbw;
 		stt.left_bit_width               = d.rd_lbw;
 		stt.actual_dictionary_size       = d.rd_dict_size;
@@ -49,6 +89,8 @@ struct rd_encoder {
 			if (i < d.rd_dict_size) { stt.left_parts_dict_map.insert({d.rd_dict[i], static_cast<uint16_t>(i)}); }
 		}
 	}
+
+public:
 
 	//! rd.hpp:109-147
 	static inline void encode(const PT*  dbl_arr,

@@ -261,6 +261,14 @@ int alpgpu_rowgroup_init_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vec
 int alpgpu_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
 /* rd_encoder::init's half alone (include/alp/rd.hpp:180-185): cut + dictionary for these samples, no ALP/ALP_RD re-decision */
 int alpgpu_rd_state_from_samples_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
+/* rd_encoder::build_left_parts_dictionary for ONE cut position (include/alp/rd.hpp:33-87, called by find_best_dictionary :89-104 for every cut
+ * and once more for the chosen one): right_bit_width = 64 - cut for doubles (48..63), 32 - cut for floats (16..31).  *d_state receives the ALP_RD
+ * state of that cut (bit widths, dictionary size, dictionary in the reference's order), *d_estimate the value the reference returns —
+ * estimate_compression_size (rd.hpp:23-31): right + left bit width + 32 bits per sampled exception / sample.  Both in device memory. */
+int alpgpu_rd_dictionary_for_cut_f64(alpgpu_ctx* ctx, const double* d_samples, uint32_t n_samples, uint8_t right_bit_width, alpgpu_rowgroup_state* d_state,
+                                     double* d_estimate);
+int alpgpu_rd_dictionary_for_cut_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, uint8_t right_bit_width, alpgpu_rowgroup_state* d_state,
+                                     double* d_estimate);
 
 /* Vector encode of the whole column given col->d_rowgroups (from alpgpu_rowgroup_init_f64 or supplied by
  * the caller): second-level sampling, encode + exception compaction, analyze_ffor, FFOR pack (ALP);

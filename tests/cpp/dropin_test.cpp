@@ -55,7 +55,30 @@ static int test_column(const std::string& dir, const std::string& name, size_t n
 		if (v % alp::config::N_VECTORS_PER_ROWGROUP == 0) {
 			stt = alp::state<PT>();
 			alp::encoder<PT>::init(column.data(), offset, n_values, B.sample.data(), stt);
-			if (stt.scheme == alp::Scheme::ALP_RD) { alp::rd_encoder<PT>::init(column.data(), offset, n_values, B.sample.data(), stt); }
+			if (stt.scheme == alp::Scheme::ALP_RD) {
+				alp::rd_encoder<PT>::init(column.data(), offset, n_values, B.sample.data(), stt);
+				// the public statics find_best_dictionary is made of (rd.hpp:23-104): the 16 cuts one by one give the cut it chose (first strictly
+				// smaller estimate), persisting that cut gives its dictionary, and an estimate is estimate_compression_size of what it counted
+				alp::state<PT> probe = stt;
+				double         best  = 1e300;
+				alp::bw_t      chosen = 0;
+				for (size_t i = 1; i <= alp::config::CUTTING_LIMIT; ++i) {
+					const alp::bw_t rbw = static_cast<alp::bw_t>(sizeof(PT) * 8 - i);
+					const double    est = alp::rd_encoder<PT>::template build_left_parts_dictionary<false>(B.sample.data(), rbw, probe);
+					if (est < rbw + 1) { std::printf("FAIL %s: estimate %.3f below its own bit widths\n", name.c_str(), est), ++failures; }
+					if (est < best) { best = est, chosen = rbw; }
+				}
+				if (chosen != stt.right_bit_width) { std::printf("FAIL %s: cut-by-cut search picks rbw %d, init picked %d\n", name.c_str(), chosen, stt.right_bit_width), ++failures; }
+				const double again = alp::rd_encoder<PT>::template build_left_parts_dictionary<true>(B.sample.data(), chosen, probe);
+				if (again != best || probe.left_bit_width != stt.left_bit_width || probe.actual_dictionary_size != stt.actual_dictionary_size ||
+				    std::memcmp(probe.left_parts_dict, stt.left_parts_dict, sizeof(stt.left_parts_dict)) != 0) {
+					std::printf("FAIL %s: build_left_parts_dictionary<true> of the chosen cut differs from find_best_dictionary\n", name.c_str()), ++failures;
+				}
+				const double lo = alp::rd_encoder<PT>::estimate_compression_size(chosen, stt.left_bit_width, 0, stt.sampled_values_n);
+				if (again < lo || alp::rd_encoder<PT>::estimate_compression_size(10, 3, 4, 64) != 13.0 + 4 * 32 / 64.0) {
+					std::printf("FAIL %s: estimate_compression_size\n", name.c_str()), ++failures;
+				}
+			}
 			if (v == 0 && want_rd >= 0 && (stt.scheme == alp::Scheme::ALP_RD) != (want_rd == 1)) {
 				std::printf("FAIL %s: scheme %d, expected rd=%d\n", name.c_str(), static_cast<int>(stt.scheme), want_rd);
 				++failures;
@@ -74,6 +97,12 @@ static int test_column(const std::string& dir, const std::string& name, size_t n
 		} else {
 			alp::bw_t bit_width = 0;
 			alp::encoder<PT>::encode(B.input.data(), B.exceptions.data(), B.pos.data(), B.exc_c.data(), B.encoded.data(), stt);
+			if (v % 7 == 0) { // second-level sampling called on its own (encoder.hpp:241-305) chooses what encode() chose
+				uint8_t fac = 255, exp = 255;
+				alp::encoder<PT>::find_best_exponent_factor_from_combinations(stt.best_k_combinations, static_cast<uint8_t>(stt.k_combinations), B.input.data(),
+				                                                              alp::config::VECTOR_SIZE, fac, exp);
+				if (fac != stt.fac || exp != stt.exp) { std::printf("FAIL %s v%zu: second-level sampling alone gives (%d,%d), encode() (%d,%d)\n", name.c_str(), v, exp, fac, stt.exp, stt.fac), ++failures; }
+			}
 			alp::encoder<PT>::analyze_ffor(B.encoded.data(), bit_width, B.base.data());
 			ffor::ffor(B.encoded.data(), B.ffor_buf.data(), bit_width, B.base.data());
 			generated::falp::fallback::scalar::falp(B.ffor_buf.data(), B.decoded.data(), bit_width, B.base.data(), stt.fac, stt.exp);

@@ -398,3 +398,41 @@ def test_alp_vectors_of_every_packed_width(ctx, oracle, route, exceptions):
         ctx.synchronize()
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
         assert torch.equal(out.view(torch.int64), x.view(torch.int64)), f"decode, {vpw} vectors per workgroup"
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rd_dictionary_of_one_cut_matches_the_reference_formula(ctx, dtype):
+    """alpgpu_rd_dictionary_for_cut_* = rd_encoder::build_left_parts_dictionary (rd.hpp:33-87) for ONE cut: its estimate against the reference's
+    arithmetic restated in numpy (histogram of the left parts, the 8 most frequent stay, 32 bits per other sample; ties do not move the
+    estimate), for every cut of 1..16 bits; and the first strictly smallest estimate is the cut alpgpu_rd_state_from_samples_* chooses."""
+    from alp_amd import capi
+    bits = 64 if dtype == "f64" else 32
+    rng = np.random.default_rng(12)
+    tdt, ndt, udt = (torch.float64, np.float64, np.uint64) if dtype == "f64" else (torch.float32, np.float32, np.uint32)
+    for n_smp, gen in ((288, lambda: rng.random(288)), (288, lambda: rng.normal(0, 1e-3, 288) + 7.25), (96, lambda: rng.random(96) * 1e6), (17, lambda: rng.random(17))):
+        smp = gen().astype(ndt)
+        d_smp = torch.from_numpy(smp).cuda()
+        st = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        est = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ests = []
+        for cut in range(1, 17):
+            rbw = bits - cut
+            ctx.rd_dictionary_for_cut(d_smp, rbw, st, est)
+            ctx.synchronize()
+            left = smp.view(udt) >> udt(rbw)
+            _, counts = np.unique(left, return_counts=True)
+            counts = np.sort(counts)[::-1]
+            ds = min(8, counts.size)
+            lbw = max(1, int(np.ceil(np.log2(ds))))
+            want = rbw + lbw + float(counts[8:].sum()) * 32 / n_smp
+            got_state = st.cpu().numpy().view(capi.ROWGROUP_DTYPE)[0]
+            assert float(est[0]) == want, (dtype, n_smp, cut, float(est[0]), want)
+            assert (got_state["rd_rbw"], got_state["rd_lbw"], got_state["rd_dict_size"], got_state["scheme"]) == (rbw, lbw, ds, capi.SCHEME_ALP_RD)
+            assert set(int(x) for x in got_state["rd_dict"][:ds]) <= set(int(x) for x in left)
+            ests.append(float(est[0]))
+        ctx.state_from_samples(d_smp, st, rd_only=True)
+        ctx.synchronize()
+        chosen = int(st.cpu().numpy().view(capi.ROWGROUP_DTYPE)[0]["rd_rbw"])
+        assert chosen == bits - (1 + int(np.argmin(ests))), "find_best_dictionary takes the first strictly smaller estimate in cut order"
+    with pytest.raises(capi.AlpGpuError, match="right_bit_width"):
+        ctx.rd_dictionary_for_cut(d_smp, bits - 17, st, est)
