@@ -202,29 +202,7 @@ __device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state(const alpgp
 // the other words had reached memory) says whether they are there.  Polls with s_sleep in between; gives up after spin_limit polls
 // (ok = false: the caller raises the encode's stall flag and the recovery route re-encodes).  The returned state has pad = 0.
 constexpr uint32_t kStateReady = 0xA5u;
-__device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state_async(const alpgpu_rowgroup_state* __restrict__ p, int lane, uint32_t spin_limit, bool& ok) {
-	const uint32_t* src  = reinterpret_cast<const uint32_t*>(p) + (lane & 7);
-	uint32_t        mine = 0, spins = 0;
-	ok                   = true;
-	for (;;) {
-		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if ((static_cast<uint32_t>(__builtin_amdgcn_readlane(mine, 3)) >> 24) == kStateReady) { break; }
-		if (++spins > spin_limit) {
-			ok = false;
-			break;
-		}
-		__builtin_amdgcn_s_sleep(32);
-	}
-#ifndef ALPGPU_STATE_SINGLE_READ
-	// The tag was seen: the publisher's other words reached memory BEFORE it stored the tag, so a load issued AFTER this observation returns
-	// them whole.  The load that saw the tag is not that load — nothing in the memory model says one 32-byte request cannot be served while
-	// the publisher is between its stores — so the state is read once more, behind the first load's completion (the
-	// readlane above consumed it: s_waitcnt vmcnt(0)).  One more L2-side hit per wavefront, under the vector's own loads.
-	if (ok) {
-		asm volatile("" ::: "memory");
-		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-#endif
+__device__ __forceinline__ alpgpu_rowgroup_state unpack_rowgroup_state(uint32_t mine) {
 	uint32_t w[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) { w[i] = __builtin_amdgcn_readlane(mine, i); }
@@ -240,6 +218,38 @@ __device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state_async(const
 #pragma unroll
 	for (int i = 0; i < 8; ++i) { s.rd_dict[i] = static_cast<uint16_t>(w[4 + (i >> 1)] >> (16 * (i & 1))); }
 	return s;
+}
+// Split in two so that the FIRST poll can be issued in front of the vector's own loads (vector-memory loads return in order: a poll issued
+// behind them could not be looked at before all 8 KiB had arrived, and the re-read below would then be a whole extra round trip in the open —
+// measured: +3 % on the encode).  begin: one agent-scope load per lane (word lane & 7).  finish: looks at it, polls on while the tag is
+// missing, and — ADVICE round 3 — reads the state ONCE MORE after the tag has been seen: the publisher's other words reached memory BEFORE it
+// stored the tag, so a load issued AFTER that observation returns them whole, while nothing in the memory model says that the very request
+// that saw the tag could not have been served between the publisher's stores.  The second read travels under the vector's loads.
+__device__ __forceinline__ uint32_t rowgroup_state_poll_begin(const alpgpu_rowgroup_state* __restrict__ p, int lane) {
+	return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ alpgpu_rowgroup_state rowgroup_state_poll_finish(const alpgpu_rowgroup_state* __restrict__ p, uint32_t mine, int lane, uint32_t spin_limit, bool& ok) {
+	const uint32_t* src   = reinterpret_cast<const uint32_t*>(p) + (lane & 7);
+	uint32_t        spins = 0;
+	ok                    = true;
+	while ((static_cast<uint32_t>(__builtin_amdgcn_readlane(mine, 3)) >> 24) != kStateReady) {
+		if (++spins > spin_limit) {
+			ok = false;
+			break;
+		}
+		__builtin_amdgcn_s_sleep(32);
+		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+#ifndef ALPGPU_STATE_SINGLE_READ
+	if (ok) {
+		asm volatile("" ::: "memory");
+		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+#endif
+	return unpack_rowgroup_state(mine);
+}
+__device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state_async(const alpgpu_rowgroup_state* __restrict__ p, int lane, uint32_t spin_limit, bool& ok) {
+	return rowgroup_state_poll_finish(p, rowgroup_state_poll_begin(p, lane), lane, spin_limit, ok);
 }
 
 // The ALP_RD dictionary of a vector's rowgroup (eight u16 entries = bytes 16..31 of the state) as two words.  The column decode

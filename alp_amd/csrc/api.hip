@@ -31,6 +31,7 @@ struct alpgpu_ctx {
 	int         async_init;      // 1 (default): alpgpu_encode_* of a long column runs the rowgroup search BESIDE the vector encode (second stream)
 	hipStream_t init_stream;     // ... on this stream (highest priority: its few workgroups are placed first)
 	hipEvent_t  ev_fork, ev_head, ev_join;
+	int         encode_kernel;   // ALPGPU_ENCODE_KERNEL_LEAN (default) / _CLASSIC
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -119,6 +120,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
 	ctx->pipelined_consumer = 0;
+	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	ctx->ws_stream       = nullptr;
@@ -189,6 +191,10 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_ENCODE_ASYNC_INIT:
 		if (value < 0 || value > 2) { return fail(ALPGPU_ERR_INVALID, "async init: 0 (off), 1 (double columns: default) or 2 (float columns too)"); }
 		ctx->async_init = static_cast<int>(value);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_ENCODE_KERNEL:
+		if (value != ALPGPU_ENCODE_KERNEL_LEAN && value != ALPGPU_ENCODE_KERNEL_CLASSIC) { return fail(ALPGPU_ERR_INVALID, "encode kernel: 0 (lean) or 1 (classic)"); }
+		ctx->encode_kernel = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_CONSUMER_PIPELINED:
 		if (value < 0 || value > 3) { return fail(ALPGPU_ERR_INVALID, "consumer kernel: 0 (chosen per column), 1 (persistent LDS-ring kernel), 2 (one wavefront per vector, no stage) or 3 (four wavefronts per vector)"); }
@@ -360,7 +366,7 @@ static int encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	if (ctx->encode_two_pass) {
 		rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus);
 	} else {
-		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head); // (waits for / joins the search's stream)
+		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head, ctx->encode_kernel); // (waits for / joins the search's stream)
 		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus, col->d_totals + 6); }
 	}
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
@@ -399,7 +405,8 @@ static int encode_with_side_search(alpgpu_ctx* ctx, const T* d_in, uint64_t n_ve
 		if constexpr (f32) {
 			return alpgpu::launch_rowgroup_init_async_f32(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid);
 		} else {
-			return alpgpu::launch_rowgroup_init_async(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid);
+			return alpgpu::launch_rowgroup_init_async(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid,
+			                                          ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN && count > static_cast<uint64_t>(grid));
 		}
 	};
 	if (search(0, kAsyncHeadRowgroups, static_cast<int>(kAsyncHeadRowgroups)) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError()); }

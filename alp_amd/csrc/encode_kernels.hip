@@ -333,6 +333,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	// started two memory round trips late — 20 % of a tile's life.  A wavefront past the end of the column reads the launch's
 	// first vector instead (nothing of it is stored).
 	const uint64_t v_read = live ? v : v_first;
+	const alpgpu_rowgroup_state* rg_ptr  = rgs + v_read / kRowgroup;
+	const uint32_t               st_word = async_states ? rowgroup_state_poll_begin(rg_ptr, lane) : reinterpret_cast<const uint32_t*>(rg_ptr)[lane & 7]; // in FRONT of the vector's loads (alp_device.hpp)
 #ifdef ALPGPU_EXPERIMENT_ENC_WRAP_TRAFFIC // timing experiment (profiles/r03_encode_levers.txt): every vector's 8 KiB come from the first 8192 vectors and go
 	// to the first 64 MiB / 8 MiB of the streams — the same arithmetic on a column that repeats its first 8192 vectors, without the HBM traffic
 	x = load_vector(in, v_read & 8191ull, lane);
@@ -345,8 +347,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_encode_fused(const double*
 	// rowgroups ahead).  A state that does not arrive within the spin limit is a stall like a look-back that gives up: flag, no output
 	// of this tile, the recovery route (behind both streams) re-encodes.
 	bool                         state_ok = true;
-	const alpgpu_rowgroup_state  st  = async_states ? load_rowgroup_state_async(rgs + v_read / kRowgroup, lane, spin_limit >> 4, state_ok)
-	                                                : load_rowgroup_state(rgs + v_read / kRowgroup, lane);
+	const alpgpu_rowgroup_state  st  = async_states ? rowgroup_state_poll_finish(rg_ptr, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
 	const alpgpu_rowgroup_state* rgp = &st;
 	if (!state_ok) { // wave-uniform
 		if (lane == 0) { status_store(totals + 3, 1ull); }
@@ -609,8 +610,10 @@ int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col) {
 // vectors [v_first, v_first + n_range): continues the streams where d_totals[0..1] say the previous range ended
 // async_head / async_join (with async_states): the events behind the head of the search and behind the persistent rest; the stream
 // waits for the first in front of the first encode launch, for the second in front of the LAST finish kernel, which then clears the tags
+void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
+                          uint32_t spin_limit, uint32_t async_states); // encode_lean_kernels.hip
 int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                              bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
+                              bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head, int kernel) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
@@ -619,9 +622,13 @@ int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpg
 		if (async_states && first == v_first && async_head != nullptr) { // the head of the search (side stream) is what the first tiles need
 			if (hipStreamWaitEvent(stream, async_head, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		}
-		hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
-		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u);
+		if (kernel == ALPGPU_ENCODE_KERNEL_LEAN) {
+			launch_k_encode_lean(stream, static_cast<unsigned>(n_tiles), d_in, col, d_workspace, first, n_launch, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u);
+		} else {
+			hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
+			                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
+			                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u);
+		}
 		const bool last = first + n_launch >= v_first + n_range;
 		if (async_states && last) {
 			if (hipStreamWaitEvent(stream, async_join, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
@@ -634,9 +641,9 @@ int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpg
 }
 
 int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall,
-                        bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
+                        bool async_states, hipEvent_t async_join, hipEvent_t async_head, int kernel) {
 	if (launch_encode_reset_totals(stream, col) != ALPGPU_OK) { return ALPGPU_ERR_HIP; }
-	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors, force_stall, async_states, async_join, async_head);
+	return launch_encode_fused_range(stream, d_in, col, d_workspace, 0, n_vectors, force_stall, async_states, async_join, async_head, kernel);
 }
 
 // the scan of the two-pass form (shared with the float column kernels): descriptor sizes -> offsets, totals, overflow flag

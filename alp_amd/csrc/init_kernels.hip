@@ -281,8 +281,17 @@ __device__ __forceinline__ void store_rowgroup_state(alpgpu_rowgroup_state* __re
 // byte = kStateReady) last, behind an s_waitcnt vmcnt(0); for an ALP_RD rowgroup its rd_order table is released first.  Eight
 // wavefronts of 64 VGPRs are what fits a CU next to two encode tiles (2 x 8 wavefronts x 96 VGPRs, 2 x 66 KiB LDS): the search then
 // runs in the issue slots the memory-bound encode leaves idle instead of 0.55 ms in front of it.
+// Register budgets of the persistent forms: W = kInitAsyncWaves (4) beside two classic encode tiles: <= 96 VGPRs; W = kInitAsyncTileWaves (8) — a
+// workgroup in the SHAPE of a lean encode tile (eight wavefronts, <= 80 VGPRs, 25 KiB of LDS): it takes one of a CU's three tile slots while the
+// search lasts and gives it back afterwards, instead of keeping the third tile out for the whole encode the way a 96-register wavefront per
+// SIMD would (6 x 80 + 96 > 512) — round 4: 3.13 -> 3.05 ms per 1 Mi vectors on the mixed column beside k_encode_lean.
+constexpr int kInitAsyncTileWaves = 8;
+template <bool ASYNC, int W>
+constexpr int init_waves_per_simd() {
+	return !ASYNC ? 1 : (W == kInitAsyncWaves ? kInitAsyncWavesPerSimd : (W == kInitAsyncTileWaves ? 6 : 1));
+}
 template <class P, bool FROM_SAMPLES, int W, bool ASYNC>
-__global__ __launch_bounds__(64 * W, (ASYNC && W == kInitAsyncWaves) ? kInitAsyncWavesPerSimd : 1) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
+__global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W>())) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
                                                           alpgpu_rowgroup_state* __restrict__ rgs, int force_rd,
                                                           uint16_t* __restrict__ rd_order, uint64_t rg_first, uint64_t rg_end, double* __restrict__ cut_est_out) {
 	static_assert(!ASYNC || !FROM_SAMPLES, "the persistent form gathers its own samples");
@@ -666,12 +675,15 @@ int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vect
 // The persistent, publishing form for rowgroups [rg_first, rg_first + rg_count): `grid` workgroups of kInitAsyncWaves wavefronts.
 template <class P>
 static int launch_rowgroup_init_async_t(hipStream_t stream, const typename P::value_t* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
-                                        uint64_t rg_first, uint64_t rg_count, int grid) {
+                                        uint64_t rg_first, uint64_t rg_count, int grid, bool tile_shaped) {
 	if (rg_count == 0) { return ALPGPU_OK; }
 	const uint64_t g = rg_count < static_cast<uint64_t>(grid) ? rg_count : static_cast<uint64_t>(grid);
 	if (g == rg_count) { // one workgroup per rowgroup (the head in front of the encode): the 9-wavefront shape, publishing
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kMaxSampledVectors, true>), dim3(static_cast<unsigned>(g)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
 		                   d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
+	} else if (tile_shaped) {
+		hipLaunchKernelGGL((k_rowgroup_init<P, false, kInitAsyncTileWaves, true>), dim3(static_cast<unsigned>(g)), dim3(64 * kInitAsyncTileWaves), 0, stream, d_in, n_vectors,
+		                   d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
 	} else {
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kInitAsyncWaves, true>), dim3(static_cast<unsigned>(g)), dim3(64 * kInitAsyncWaves), 0, stream, d_in, n_vectors, d_rgs,
 		                   0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
@@ -679,12 +691,12 @@ static int launch_rowgroup_init_async_t(hipStream_t stream, const typename P::va
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
-                               uint64_t rg_count, int grid) {
-	return launch_rowgroup_init_async_t<PrecF64>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid);
+                               uint64_t rg_count, int grid, bool tile_shaped) {
+	return launch_rowgroup_init_async_t<PrecF64>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, tile_shaped);
 }
 int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                    uint64_t rg_count, int grid) {
-	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid);
+	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, false);
 }
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {

@@ -32,20 +32,23 @@ int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vect
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate = nullptr);
 // the persistent, publishing form (runs beside the single-pass encode on a second stream) and the tag clean-up behind it
+// tile_shaped: eight-wavefront workgroups that fit a lean encode tile's slot (init_kernels.hip), else four wavefronts beside two classic tiles
 int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
-                               uint64_t rg_count, int grid);
+                               uint64_t rg_count, int grid, bool tile_shaped = false);
 int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                    uint64_t rg_count, int grid);
 
 // encode_kernels.hip
 uint64_t encode_workspace_bytes(uint64_t n_vectors);
 // single pass (force_stall: debug, every look-back that has to wait gives up — exercises the recovery route)
+// kernel: ALPGPU_ENCODE_KERNEL_LEAN (encode_lean_kernels.hip: 6 KiB of LDS and <= 72 VGPRs per wavefront, three tiles per CU) or _CLASSIC (k_encode_fused)
 int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,
-                        bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
+                        bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr, int kernel = ALPGPU_ENCODE_KERNEL_LEAN);
 // pieces of the above for a caller that interleaves other work: zero d_totals, then vector ranges in ascending order
 int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col);
 int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                              bool force_stall = false, bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
+                              bool force_stall = false, bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr,
+                              int kernel = ALPGPU_ENCODE_KERNEL_LEAN);
 // two pass; gate = nullptr: unconditionally, else a device word that must be non-zero for the kernels to do anything (d_totals + 6)
 int launch_encode_vectors(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace,
                           int n_cus, const uint64_t* gate = nullptr);

@@ -180,6 +180,14 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * one-wavefront kernel does a quarter of its scalar work per vector and is 7-30 % faster on ALP and ALP_RD columns alike (while its ALP_RD
  * arm still spilled, the default chose between the two by alpgpu_column::alp_rd_rowgroups_hint); the ring kernel is slower than both. */
 #define ALPGPU_OPT_CONSUMER_PIPELINED 5
+/* ALPGPU_OPT_ENCODE_KERNEL: which single-pass kernel alpgpu_encode_f64 / alpgpu_encode_vectors_f64 launch (same bytes either way).
+ * ALPGPU_ENCODE_KERNEL_LEAN (default): the input is the only vector-sized thing a wavefront holds — the analysis keeps lane masks, the pack
+ * recomputes each integer as it shifts it into a 4 KiB LDS image that also waits for the ordered offset — 6 KiB of LDS and <= 72 VGPRs per
+ * wavefront, three 8-vector tiles per CU.  ALPGPU_ENCODE_KERNEL_CLASSIC: round 3's kernel (input + integers + packed units in registers,
+ * 8 KiB image, two tiles per CU).  DESIGN.md §3.2. */
+#define ALPGPU_OPT_ENCODE_KERNEL 7
+#define ALPGPU_ENCODE_KERNEL_LEAN 0
+#define ALPGPU_ENCODE_KERNEL_CLASSIC 1
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */

@@ -1,20 +1,66 @@
 #!/usr/bin/env python3
-"""check_top_vgpr.py [hipcc flags...]: compiles every kernel source to assembly and lists the kernels in which a 64-bit instruction (v_*_b64 /
-_f64 / _i64 / _u64) reads the LAST register of the kernel's allocation as a single-register operand — e.g. the shift amount of v_lshrrev_b64.
-On gfx950 such an operand is range-checked as if it were a register pair: v(N-1):vN falls out of the allocation and the instruction reads
-VGPR0 instead (tools/last_vgpr_probe.hip shows it in isolation; profiles/r03_consumers.txt tells how it was found).  Exit status 1 if any
-kernel has the pattern.  The register allocator does not know this rule; a kernel that uses exactly 8k registers can get it from any rebuild."""
+"""check_top_vgpr.py — the "last allocated register" rule of gfx950, checked statically.
+
+On gfx950 a single-register (32-bit) VGPR operand of certain instructions that also carry 64-bit register operands is range-checked as if it were
+a register PAIR: when it is the LAST register of the wavefront's allocation, v(N-1):vN falls out of the allocation and the instruction computes
+with VGPR0 instead (tools/last_vgpr_probe.hip, tools/last_vgpr_probe2.hip; profiles/r03_last_register.txt, r04_last_register.txt).  Builds of
+k_sink_direct with that pattern returned wrong sums (profiles/r03_consumers.txt).  The register allocator does not know the rule; a kernel that
+uses exactly 8k registers can get the pattern from any rebuild.
+
+Two modes, same rule:
+  check_top_vgpr.py [hipcc flags...]      compiles every kernel source to assembly (what __graft_entry__.build() and the CPU suite run)
+  check_top_vgpr.py --library lib.so      disassembles the code objects INSIDE a built library (llvm-objdump) and reads each kernel's descriptor
+                                          (allocation granule, accum offset) from the ELF: the artefact that is loaded is the artefact that is
+                                          checked (tests/test_last_register_gpu.py runs it on the library the process has loaded)
+  check_top_vgpr.py --opcodes lib.so      the instruction mnemonics the library uses, with counts (the set the probes have to cover)
+Exit status 1 if any kernel has the pattern, 2 if the check could not see the build."""
 import glob
 import os
 import re
+import struct
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include")]
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# Instructions CONVICTED by the probes (operand position of the 32-bit register does not matter: any bare vN operand after the destination).
+# Everything else that mixes a 32-bit register with wider operands was probed and is clean — see CLEARED — and is therefore not flagged;
+# an instruction in neither list that reads the top register beside a 64-bit operand is reported as "unprobed" and fails the check too.
+CONVICTED = re.compile(r"^v_(lshlrev_b64|lshrrev_b64|ashrrev_i64)")
+CLEARED = re.compile(r"^(v_lshl_add_u64|v_ldexp_f64|v_cvt_f64_(u32|i32|f32)|v_cvt_(u32|i32|f32)_f64|v_frexp_exp_i32_f64|v_mad_u64_u32|v_mad_i64_i32|v_cmp_class_f64|"
+                     r"v_trig_preop_f64|ds_read_b64|ds_read_b128|ds_read2_b64|ds_read2st64_b64|ds_write_b64|ds_write_b128|ds_write2_b64|ds_write2st64_b64|ds_write_b96|ds_or_b64|"
+                     r"global_load_dwordx[234]|global_store_dwordx[234]|global_load_lds_dwordx4|buffer_load_dwordx[234]|scratch_(load|store)_dwordx[234]|"
+                     r"flat_load_dwordx[234]|flat_store_dwordx[234]|global_atomic_\w+_x2)")
+WIDE = re.compile(r"(_b64|_f64|_i64|_u64|_b96|_b128|dwordx[234]|_x2)")
+
+
+def top_register_hits(body_lines, top):
+    """instructions of one kernel that read / write `top` as a bare operand beside wider register operands -> (convicted, unprobed)"""
+    convicted, unprobed = [], []
+    for line in body_lines:
+        t = line.split(";")[0].split("//")[0].strip()
+        if not t or not re.match(r"^(v_|ds_|global_|buffer_|flat_|scratch_)", t):
+            continue
+        op = t.split()[0]
+        if not WIDE.search(op):
+            continue
+        operands = [o.strip() for o in t[len(op):].split(",")]
+        if top not in operands:
+            continue
+        if not any(re.match(r"^[va]\[\d+:\d+\]$", o) for o in operands):
+            continue  # no wider VGPR operand next to it (e.g. a 64-bit scalar base only)
+        mnem = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+        if CONVICTED.match(mnem) and top in operands[1:]:
+            convicted.append(t)
+        elif not CLEARED.match(mnem) and not CONVICTED.match(mnem):
+            unprobed.append(t)
+    return convicted, unprobed
 
 
 def kernels_with_pattern(asm_text):
+    """assembly mode: [(kernel, allocated registers, instructions)] for kernels whose last ALLOCATED register is used the convicted way"""
     out = []
     for part in re.split(r"\n(?=_Z[\w]+:\s)", asm_text):
         m = re.match(r"(_Z\w+):", part)
@@ -22,23 +68,119 @@ def kernels_with_pattern(asm_text):
         if not m or not nv:
             continue
         n = int(nv.group(1))
-        if n % 8 != 0:  # the allocation is rounded up to 8: the last allocated register is not one the kernel uses
-            continue
-        top = "v%d" % (n - 1)
+        acc = re.search(r"\.amdhsa_accum_offset\s+(\d+)", part)
+        tops = set()
+        if n % 8 == 0:  # the allocation is rounded up to 8: otherwise its last register is not one the kernel uses
+            tops.add(n - 1)
+        if acc and int(acc.group(1)) < n:  # AGPRs in use: the last ARCHITECTURAL register is accum_offset - 1, whatever the total is
+            tops.add(int(acc.group(1)) - 1)
         hits = []
-        for line in part.split("\n"):
-            t = line.split(";")[0].strip()
-            if not t.startswith("v_"):
-                continue
-            op = t.split()[0]
-            if not re.search(r"(_b64|_f64|_i64|_u64)", op):
-                continue
-            operands = [o.strip() for o in t[len(op):].split(",")]
-            if top in operands[1:]:
-                hits.append(t)
+        for top in sorted(tops):
+            c, u = top_register_hits(part.split("\n"), "v%d" % top)
+            hits += c + ["(unprobed) " + x for x in u]
         if hits:
             out.append((m.group(1), n, hits))
     return out
+
+
+# ---- library mode: the code objects inside a built .so ---------------------------------------------------------------------------------
+def code_objects(so_path):
+    """the gfx950 ELF images bundled in a library's .hip_fatbin sections"""
+    data = open(so_path, "rb").read()
+    objs = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        b = m.start()
+        n = struct.unpack_from("<Q", data, b + 24)[0]
+        off = b + 32
+        for _ in range(n):
+            o, s, ts = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + ts].decode(errors="replace")
+            off += ts
+            if "gfx950" in triple and s > 0:
+                objs.append(data[b + o:b + o + s])
+    return objs
+
+
+def kernel_descriptors(elf):
+    """kernel name -> (allocated VGPRs, accum offset) from the .kd symbols of one code object (AMDHSA kernel descriptor: compute_pgm_rsrc3 at
+    byte 44, compute_pgm_rsrc1 at byte 48; gfx90a+: allocation = (GRANULATED_WORKITEM_VGPR_COUNT + 1) * 8, accum offset = (ACCUM_OFFSET + 1) * 4)"""
+    assert elf[:4] == b"\x7fELF" and elf[4] == 2
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+    out = {}
+    for sh in secs:
+        if sh[1] != 2:  # SHT_SYMTAB
+            continue
+        strtab = secs[sh[6]]
+        for i in range(sh[5] // sh[9]):
+            name_off, info, other, shndx, value, size = struct.unpack_from("<IBBHQQ", elf, sh[4] + i * sh[9])
+            end = elf.index(b"\0", strtab[4] + name_off)
+            name = elf[strtab[4] + name_off:end].decode()
+            if not name.endswith(".kd") or shndx == 0 or shndx >= len(secs):
+                continue
+            sec = secs[shndx]
+            fo = sec[4] + (value - sec[3])
+            rsrc3, rsrc1 = struct.unpack_from("<II", elf, fo + 44)
+            out[name[:-3]] = (((rsrc1 & 0x3F) + 1) * 8, ((rsrc3 & 0x3F) + 1) * 4)
+    return out
+
+
+def library_kernels(so_path):
+    """[(kernel, allocated, accum offset, body lines)] for every kernel of every code object in the library"""
+    import tempfile
+    out = []
+    for elf in code_objects(so_path):
+        kds = kernel_descriptors(elf)
+        with tempfile.NamedTemporaryFile(suffix=".o") as f:
+            f.write(elf)
+            f.flush()
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True).stdout
+        cur, body = None, []
+        for line in dis.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <([\w.$]+)>:", line)
+            if m:
+                if cur in kds:
+                    out.append((cur, kds[cur][0], kds[cur][1], body))
+                cur, body = m.group(1), []
+            else:
+                body.append(re.sub(r"^\s*", "", line))
+        if cur in kds:
+            out.append((cur, kds[cur][0], kds[cur][1], body))
+    return out
+
+
+def check_library(so_path):
+    kernels = library_kernels(so_path)
+    bad = 0
+    for name, alloc, accum, body in kernels:
+        used = [int(x) for l in body for x in re.findall(r"\bv(\d+)\b", l.split("//")[0])] + [int(b) for l in body for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", l.split("//")[0])]
+        top_used = max(used) if used else -1
+        tops = {t for t in (alloc - 1, accum - 1) if t == top_used or (t == accum - 1 and accum < alloc)}
+        for top in sorted(tops):
+            c, u = top_register_hits(body, "v%d" % top)
+            if c or u:
+                bad += 1
+                print(f"{name} ({alloc} registers allocated, accum offset {accum}): " + "; ".join(c + ["(unprobed) " + x for x in u][:3]))
+    print(f"{bad} of {len(kernels)} kernels of {os.path.basename(so_path)} use the last register of their allocation in an instruction gfx950 executes wrongly (or that no probe has cleared)")
+    if len(kernels) < 40:
+        print("fewer kernels than the library has: the check did not see the real build")
+        return 2
+    return 1 if bad else 0
+
+
+def opcodes(so_path):
+    import collections
+    cnt = collections.Counter()
+    for _, _, _, body in library_kernels(so_path):
+        for l in body:
+            m = re.match(r"^((?:v_|ds_|global_|buffer_|flat_|scratch_)\w+)", l)
+            if m:
+                cnt[re.sub(r"_(e32|e64|sdwa|dpp)$", "", m.group(1))] += 1
+    for k, v in sorted(cnt.items()):
+        print(f"{k} {v}")
+    return 0
 
 
 def main(extra_flags=()):
@@ -61,4 +203,8 @@ def main(extra_flags=()):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--library":
+        sys.exit(check_library(sys.argv[2]))
+    if len(sys.argv) > 2 and sys.argv[1] == "--opcodes":
+        sys.exit(opcodes(sys.argv[2]))
     sys.exit(main(sys.argv[1:]))

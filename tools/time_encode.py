@@ -15,7 +15,7 @@ from alp_amd import capi  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 kinds = sys.argv[2:] or ["mixed", "rd"]
 ctx = capi.Context(0)
-tag = os.path.basename(os.environ.get("ALPGPU_LIB", "libalpgpu.so")) + (" wg/cu=" + os.environ["ALPGPU_ASYNC_INIT_WG_PER_CU"] if os.environ.get("ALPGPU_ASYNC_INIT_WG_PER_CU") else "")
+tag = os.path.basename(os.environ.get("ALPGPU_LIB", "libalpgpu.so")) + " kernel=" + os.environ.get("ALPGPU_ENCODE_KERNEL", "0(lean)") + (" wg/cu=" + os.environ["ALPGPU_ASYNC_INIT_WG_PER_CU"] if os.environ.get("ALPGPU_ASYNC_INIT_WG_PER_CU") else "")
 for kind in kinds:
     x = bench.synthetic_input(kind, n, torch.device("cuda:0"), seed=42)
     cols, ms = {}, {}
