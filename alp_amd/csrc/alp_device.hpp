@@ -219,20 +219,30 @@ __device__ __forceinline__ alpgpu_rowgroup_state unpack_rowgroup_state(uint32_t 
 	for (int i = 0; i < 8; ++i) { s.rd_dict[i] = static_cast<uint16_t>(w[4 + (i >> 1)] >> (16 * (i & 1))); }
 	return s;
 }
-// Split in two so that the FIRST poll can be issued in front of the vector's own loads (vector-memory loads return in order: a poll issued
-// behind them could not be looked at before all 8 KiB had arrived, and the re-read below would then be a whole extra round trip in the open —
-// measured: +3 % on the encode).  begin: one agent-scope load per lane (word lane & 7).  finish: looks at it, polls on while the tag is
-// missing, and — ADVICE round 3 — reads the state ONCE MORE after the tag has been seen: the publisher's other words reached memory BEFORE it
-// stored the tag, so a load issued AFTER that observation returns them whole, while nothing in the memory model says that the very request
-// that saw the tag could not have been served between the publisher's stores.  The second read travels under the vector's loads.
+// Split in two so that the poll can be issued in front of the vector's own loads (vector-memory loads return in order: a poll issued behind
+// them cannot be looked at before all 8 KiB have arrived).  begin: one agent-scope load per lane (word lane & 7).  finish: looks at it and polls
+// on while the state is not there.
+// "There" (nothing in the memory model says that the 32-byte request that saw the tag was not served BETWEEN the publisher's
+// stores): the caller's memset leaves every unpublished state as all-ones bytes (kStateUnpublished); the publisher stores each of the four
+// 8-byte words exactly once, the tagged one last; and no word of a real state is all-ones — word 0 starts with the scheme (1 or 2), words 2 and
+// 3 hold four dictionary entries each, which are distinct where used and zero where not.  A read is therefore whole iff its tag is kStateReady
+// AND none of its other words is still all-ones: a torn read is seen as such and simply polled again.  (A second, dependent read of the state
+// after the tag — the first answer to the advice — cost 3 % of the encode: two far round trips in a row at the head of every wavefront.)
+// (kStateUnpublished = 0xFF, the memset value of the states' buffer in front of a publishing search: launch.hpp)
 __device__ __forceinline__ uint32_t rowgroup_state_poll_begin(const alpgpu_rowgroup_state* __restrict__ p, int lane) {
 	return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool rowgroup_state_is_whole(uint32_t mine) {
+	const uint32_t w0 = __builtin_amdgcn_readlane(mine, 0), w1 = __builtin_amdgcn_readlane(mine, 1), w3 = __builtin_amdgcn_readlane(mine, 3);
+	const uint32_t w4 = __builtin_amdgcn_readlane(mine, 4), w5 = __builtin_amdgcn_readlane(mine, 5), w6 = __builtin_amdgcn_readlane(mine, 6), w7 = __builtin_amdgcn_readlane(mine, 7);
+	const bool     unpublished = ((w0 & w1) == 0xFFFFFFFFu) | ((w4 & w5) == 0xFFFFFFFFu) | ((w6 & w7) == 0xFFFFFFFFu);
+	return ((w3 >> 24) == kStateReady) & !unpublished;
 }
 __device__ __forceinline__ alpgpu_rowgroup_state rowgroup_state_poll_finish(const alpgpu_rowgroup_state* __restrict__ p, uint32_t mine, int lane, uint32_t spin_limit, bool& ok) {
 	const uint32_t* src   = reinterpret_cast<const uint32_t*>(p) + (lane & 7);
 	uint32_t        spins = 0;
 	ok                    = true;
-	while ((static_cast<uint32_t>(__builtin_amdgcn_readlane(mine, 3)) >> 24) != kStateReady) {
+	while (!rowgroup_state_is_whole(mine)) {
 		if (++spins > spin_limit) {
 			ok = false;
 			break;
@@ -240,12 +250,6 @@ __device__ __forceinline__ alpgpu_rowgroup_state rowgroup_state_poll_finish(cons
 		__builtin_amdgcn_s_sleep(32);
 		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-#ifndef ALPGPU_STATE_SINGLE_READ
-	if (ok) {
-		asm volatile("" ::: "memory");
-		mine = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-#endif
 	return unpack_rowgroup_state(mine);
 }
 __device__ __forceinline__ alpgpu_rowgroup_state load_rowgroup_state_async(const alpgpu_rowgroup_state* __restrict__ p, int lane, uint32_t spin_limit, bool& ok) {

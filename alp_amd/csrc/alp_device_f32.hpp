@@ -70,8 +70,11 @@ __device__ __forceinline__ u32x4 unpack_quad_u32(const u32x4* __restrict__ units
 	const int   s  = p & 31;
 	const u32x4 w0 = units[8 * k + a];
 	const u32x4 w1 = units[8 * k + 8 + a];
-	// (w1 << (32 - s)) without the undefined shift by 32 when s == 0
-	return ((w0 >> static_cast<uint32_t>(s)) | ((w1 << 1u) << static_cast<uint32_t>(31 - s))) & mask;
+	// the 64-bit funnel {w1, w0} >> s as one v_alignbit_b32 per value (amount modulo 32: s = 0 yields w0)
+	u32x4 r;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) { r[c] = __builtin_amdgcn_alignbit(w1[c], w0[c], static_cast<uint32_t>(s)) & mask; }
+	return r;
 }
 
 } // namespace alpgpu

@@ -22,6 +22,7 @@ struct alpgpu_ctx {
 	int         n_cus;
 	int         decode_variant;
 	int         decode_auto;     // 1: vectors per decode workgroup chosen from the column's size hints
+	double      decode_four_bits, decode_four_bits_exc; // auto rule: four vectors per workgroup up to this many packed bits per value (without / with exceptions)
 	int         decode_vpw;      // the value last given to ALPGPU_OPT_DECODE_VECTORS_PER_WG (0 auto, 1, 2, 4); float decode reads this
 	char        name[128];
 	uint64_t    hbm_bytes;
@@ -117,6 +118,8 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup, bit 1: plain stores
 	ctx->decode_auto     = 1;
 	ctx->decode_vpw      = 0;
+	ctx->decode_four_bits     = std::getenv("ALPGPU_DECODE_FOUR_BITS") ? std::atof(std::getenv("ALPGPU_DECODE_FOUR_BITS")) : 0.0;     // (tuning runs; defaults set from the sweep)
+	ctx->decode_four_bits_exc = std::getenv("ALPGPU_DECODE_FOUR_BITS_EXC") ? std::atof(std::getenv("ALPGPU_DECODE_FOUR_BITS_EXC")) : 0.0;
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
 	ctx->pipelined_consumer = 0;
@@ -177,7 +180,7 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		}
 		ctx->decode_auto    = value == 0;
 		ctx->decode_vpw     = static_cast<int>(value);
-		ctx->decode_variant = (ctx->decode_variant & ~1) | (value >= 2 ? 0 : 1); // double columns: 4 behaves as 2
+		ctx->decode_variant = (ctx->decode_variant & ~5) | (value >= 2 ? 0 : 1) | (value == 4 ? 4 : 0); // (4: four vectors over the narrow stage)
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_TWO_PASS:
 		ctx->encode_two_pass = value ? 1 : 0;
@@ -396,7 +399,7 @@ static int encode_with_side_search(alpgpu_ctx* ctx, const T* d_in, uint64_t n_ve
 	if (int rc = check_column(col, n_vectors)) { return rc; }
 	static const bool serial = std::getenv("ALPGPU_ASYNC_SERIAL") != nullptr; // experiment: the publishing search IN FRONT of the polling encode, one stream
 	hipStream_t       side   = serial ? ctx->stream : ctx->init_stream;
-	ALPGPU_HIP(hipMemsetAsync(col->d_rowgroups, 0, 32ull * n_rg, ctx->stream)); // no tag is set
+	ALPGPU_HIP(hipMemsetAsync(col->d_rowgroups, alpgpu::kStateUnpublished, 32ull * n_rg, ctx->stream)); // "unpublished": no tag, every word all-ones (alp_device.hpp)
 	ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
 	if (!serial) { ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0)); }
 	// the head of the search and, behind it, the persistent rest: both on the side stream; the context's stream meanwhile clears its
@@ -437,13 +440,16 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
 		const double n        = static_cast<double>(col->n_vectors);
 		const bool   hinted   = col->packed_bytes_hint != 0 || col->exc_bytes_hint != 0;
-		// Two vectors per workgroup pay off while the vectors are narrow: up to 17 packed bits per value without exceptions (crossover
-		// measured between 16 and 18, tools/sweep_vpw.py), up to 26 with ~2 or more exceptions per vector (between 24 and 28,
-		// tools/sweep_vpw_exc.py, profiles/r03_decode_floor_experiment.txt); wider vectors — every ALP_RD column — do better one per
-		// workgroup whatever their exceptions (ALP_RD column of bench.py: 0.82 against 0.73 of peak).
+		// More vectors per workgroup = more bytes in flight per CU, which is what narrow vectors lack (two dependent round trips for 8 KiB of
+		// output) and what wide ones pay for.  Crossovers measured at 1-bit resolution on 1 Mi-vector columns (tools/sweep_vpw_fine.py,
+		// profiles/r04_decode_floor.txt): without exceptions one vector per workgroup wins from 17 bits on (16 itself — whole KiB per vector —
+		// still prefers more), with ~2 or more exceptions per vector from 21 bits on; every ALP_RD column is far beyond either.  Up to
+		// kNarrowAutoBits bits FOUR vectors share a workgroup over the narrow stage (round 4).
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
-		const bool   narrow   = static_cast<double>(col->packed_bytes_hint) <= (with_exc ? 26.0 : 17.0) * 128.0 * n;
-		variant               = (variant & ~1) | ((hinted && narrow) ? 0 : 1);
+		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * (n > 0 ? n : 1.0));
+		const bool   narrow   = bits <= (with_exc ? 20.0 : 16.0);
+		const bool   four     = bits <= (with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits);
+		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
 	}
 	return variant;
 }
@@ -452,7 +458,8 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32) {
 	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
 	if (is_f32) { return ctx->decode_vpw ? ctx->decode_vpw : 2; }
-	return (decode_variant_for(ctx, col) & 1) ? 1 : 2;
+	const int variant = decode_variant_for(ctx, col);
+	return (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
 }
 
 // measurement aid: what alpgpu_decode_sum_f64 costs with its unpack arithmetic left out (decode_kernels.hip: kSinkProbe)

@@ -185,15 +185,34 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 		rank                = pref + __builtin_popcount(word & ((1u << b0) - 1u));
 	}
 	// FastLanes u32 unpack (alp_device_f32.hpp: unpack_quad_u32): (w1 << (32 - s)) without the undefined shift by 32 when s == 0
-	const uint32_t s = static_cast<uint32_t>(row * bw) & 31u;
-	const u32x4    q = ((w.w0 >> s) | ((w.w1 << 1u) << (31u - s))) & bw_mask32(bw);
+	// ... which is the 64-bit funnel {w1, w0} >> s: ONE v_alignbit_b32 per value (it takes the amount modulo 32, so s = 0 yields w0), where the
+	// spelled-out form cost four (round 4: the one-wavefront sink is bound by its vector instructions — 489 per vector before this)
+	const uint32_t s    = static_cast<uint32_t>(row * bw) & 31u;
+	const uint32_t msk  = bw_mask32(bw);
+	u32x4          q;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) { q[c] = __builtin_amdgcn_alignbit(w.w1[c], w.w0[c], s) & msk; }
 	u32x4          out;
 	if (d.scheme == ALPGPU_SCHEME_ALP) {
 		const uint32_t base = static_cast<uint32_t>(d.base);
 		const uint32_t fact = static_cast<uint32_t>(dict.lo);
 		const float    frac = __uint_as_float(static_cast<uint32_t>(dict.hi));
+		// Conversion shortcut, decided once per vector from its descriptor (wave-uniform, scalar arithmetic; the double kernels' kDecodeTab idea):
+		// if every integer base + digit of the vector lies in [-2^24, 2^24] and times 10^f stays inside int32, then (float)(int32)(value * 10^f)
+		// — a quarter-rate 32-bit integer multiply and a conversion — is the correctly rounded product of two exactly representable floats, i.e.
+		// the IEEE product (float)value * 10^f (10^f = 2^f 5^f with 5^10 < 2^24: exact for every f <= 10): same bits, one full-rate multiply.
+		const int64_t lo64 = static_cast<int64_t>(static_cast<int32_t>(base)), hi64 = lo64 + static_cast<int64_t>(bw_mask32(bw));
+		const int64_t lim  = d.f <= 9 ? ((1ll << 31) - 1) / static_cast<int64_t>(fact) : 0; // (fact = 10^f for f <= 9; 10^10 does not fit: literal path)
+		const int64_t bnd  = lim < (1ll << 24) ? lim : (1ll << 24);
+		const bool    shortcut = bw <= 24 && lo64 >= -bnd && hi64 <= bnd;
+		if (shortcut) {
+			const float fact_f = static_cast<float>(fact);
 #pragma unroll
-		for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint(decode_value_f32(static_cast<int32_t>(q[c] + base), fact, frac)); }
+			for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint((static_cast<float>(static_cast<int32_t>(q[c] + base)) * fact_f) * frac); }
+		} else {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint(decode_value_f32(static_cast<int32_t>(q[c] + base), fact, frac)); }
+		}
 		if (hits) {
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
@@ -372,8 +391,17 @@ static int launch_sink_f32(hipStream_t stream, const alpgpu_column* col, void* d
 // ---- the float sinks with ONE wavefront per vector, packed words straight from HBM (decode_kernels.hip: k_sink_direct) ----------------
 // Lane L does what threads L, 64 + L, 128 + L, 192 + L of the staged kernel do: four quads, their partials kept apart (p[w][L]), all four
 // quads' words requested before the first is used; then (p0 + p1) + (p2 + p3) and the adjacent-lane tree: the same bits.
-struct SinkWaveLdsF32 {
+#ifndef ALPGPU_SINK_STAGE_F32
+#define ALPGPU_SINK_STAGE_F32 3584 // bytes of packed words (bit widths <= 28) a wavefront of k_sink_direct_f32 stages in its LDS by LDS-DMA (0: none), as k_sink_direct does
+#endif
+#ifndef ALPGPU_SINK_STAGE_F32_MAX_EXC
+#define ALPGPU_SINK_STAGE_F32_MAX_EXC 48 // ... only for vectors with at most this many exceptions
+#endif
+struct __attribute__((aligned(16))) SinkWaveLdsF32 {
 	static constexpr bool kPrefixInLds = true;
+#if ALPGPU_SINK_STAGE_F32 > 0
+	uint8_t  stage[ALPGPU_SINK_STAGE_F32 + 128]; // + the unit row past the end that the unpack reads and masks off
+#endif
 	uint32_t mask[32];
 	uint8_t  excv[4 * kExcStageF];
 	uint32_t pref[32]; // exceptions in front of mask word i
@@ -397,6 +425,20 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	const bool               is_alp = d.scheme == ALPGPU_SCHEME_ALP;
 	const int                cnt    = d.exc_cnt;
 	ExcMaskF                 em {0u, 0};
+#if ALPGPU_SINK_STAGE_F32 > 0
+	// Round 4: a narrow ALP vector's words whole into the wavefront's LDS by LDS-DMA (1 KiB per instruction, no registers): ONE round trip for all
+	// of them instead of eight 16-byte buffer loads per lane — what took the double sink from 0.85 to 0.73 ms (profiles/r03_consumers.txt) and what
+	// the float one never had ("is the stage arm even taken for float?" — there was none).
+	const bool staged = is_alp && 128u * d.bw <= static_cast<uint32_t>(ALPGPU_SINK_STAGE_F32) && cnt <= ALPGPU_SINK_STAGE_F32_MAX_EXC; // wave-uniform
+	if (staged) {
+		typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+		const ull2* g       = reinterpret_cast<const ull2*>(packed + d.packed_off);
+		const int   n_units = 8 * d.bw;
+		for (int j = 0; 64 * j < n_units; ++j) {
+			if (64 * j + lane < n_units) { __builtin_amdgcn_global_load_lds(g + 64 * j + lane, reinterpret_cast<ull2*>(L.stage) + 64 * j, 16, 0, 0); }
+		}
+	}
+#endif
 	if (cnt > 0) { // wave-uniform: values of the first kExcStageF exceptions by LDS-DMA, the mask from the positions
 		const uint32_t val_bytes = (is_alp ? 4u : 2u) * static_cast<uint32_t>(cnt);
 		const int      dwords    = static_cast<int>(((val_bytes < 4u * kExcStageF ? val_bytes : 4u * kExcStageF) + 3u) >> 2);
@@ -421,8 +463,19 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	const BufferWordsF words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d.bw, kRsrcFlags),
 	                          __builtin_amdgcn_make_buffer_rsrc(first + 128u * d.bw, 0, is_alp ? 0 : 128 * d.lbw, kRsrcFlags)};
 	QuadWords w[4];
+#if ALPGPU_SINK_STAGE_F32 > 0
+	if (staged) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
+		wave_lds_sync();
+		const StagedWordsF sw {L.stage};
 #pragma unroll
-	for (int q = 0; q < 4; ++q) { w[q] = request_quad_f32(words, d, 64 * q + lane); }
+		for (int q = 0; q < 4; ++q) { w[q] = request_quad_f32(sw, d, 64 * q + lane); }
+	} else
+#endif
+	{
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { w[q] = request_quad_f32(words, d, 64 * q + lane); }
+	}
 	double part[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int q = 0; q < 4; ++q) { finish_quad_f32<false, SINK>(L, w[q], d, dict, em, rec, nullptr, 64 * q + lane, q, lane, &part[q], lo, hi); }

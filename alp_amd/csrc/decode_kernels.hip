@@ -44,12 +44,22 @@ constexpr int kStageBytes   = 8704; // >= 63*128 (RD right) + 3*128 (RD left) + 
 constexpr int kExcStage     = 128;  // 8-byte exception values staged in LDS per vector (512 2-byte ALP_RD ones); the rest are read from HBM on use
 constexpr uint32_t kExcStageBytes = 8u * kExcStage;
 
-struct __attribute__((aligned(16))) DecodeLds {
+template <int STAGE>
+struct __attribute__((aligned(16))) DecodeLdsT {
 	static constexpr bool kPrefixInLds = false; // exception lookup by ds_bpermute (exception_hits)
-	uint8_t  stage[kStageBytes];
+	static constexpr int  kStage       = STAGE;
+	uint8_t  stage[STAGE];
 	uint32_t mask[32];
 	uint8_t  excv[kExcStageBytes]; // the head of the exception record as it lies in the stream (its values come first), brought in by LDS-DMA
 };
+using DecodeLds = DecodeLdsT<kStageBytes>;
+// Round 4: FOUR narrow vectors per workgroup.  With two, a column of <= 16-bit vectors sits on a plateau of 0.69-0.73 of the HBM peak whatever its
+// width (profiles/r04_decode_floor.txt): what bounds it is the bytes in flight per CU — 16 vectors, each two dependent round trips — and the full
+// 8.5 KiB stage per vector is what caps a CU at two vectors x eight workgroups.  A stage of 2.25 KiB (17 bits + the unit row the unpack reads
+// past the end) lets a workgroup take four.  A vector that does not fit it (the launch shape follows the column's AVERAGE width) is not staged:
+// its lanes read their words straight from HBM through buffer loads, as the one-wavefront sinks do.
+constexpr int kNarrowStageBytes = 17 * 128 + 128;
+using DecodeLdsNarrow = DecodeLdsT<kNarrowStageBytes>;
 
 // The exception mask (32 words) as seen by one wavefront: lane l < 32 holds word l and the number of exceptions in the
 // words before it.  The prefix is a DPP row scan (register-to-register; a __shfl_up chain would be five dependent trips
@@ -413,8 +423,8 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 }
 
 // one wavefront's share of a staged vector (the column kernels: four wavefronts per vector)
-template <bool NT_STORE, int SINK = kSinkStore>
-__device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const alpgpu_vector_desc& d, const VectorConsts& dict,
+template <bool NT_STORE, int SINK = kSinkStore, class LDS = DecodeLds>
+__device__ __forceinline__ void decode_staged_vector(const LDS& L, const alpgpu_vector_desc& d, const VectorConsts& dict,
                                                      const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
                                                      double range_lo = 0.0, double range_hi = 0.0) {
 	ExcMask em {0u, 0};
@@ -426,15 +436,22 @@ __device__ __forceinline__ void decode_staged_vector(const DecodeLds& L, const a
 // lane, no VGPR round trip), exception positions into registers.  (Until round 3 the values went through registers too, behind a branch on the
 // scheme for their width — and the compiler's wait-count pass put an s_waitcnt vmcnt(0) between the two arms, i.e. a whole HBM round trip in
 // front of the packed loads of every vector with exceptions of one of the two schemes.)
-__device__ __forceinline__ uint32_t issue_vector_loads(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
+// (a vector whose words do not fit the workgroup's stage — narrow stage only — is not staged: see vector_fits_stage)
+template <class LDS>
+__device__ __forceinline__ bool vector_fits_stage(const alpgpu_vector_desc& d) {
+	return 128 * (static_cast<int>(d.bw) + (d.scheme == ALPGPU_SCHEME_ALP ? 0 : static_cast<int>(d.lbw))) + 128 <= LDS::kStage;
+}
+template <class LDS>
+__device__ __forceinline__ uint32_t issue_vector_loads(LDS& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
                                                        const uint8_t* __restrict__ rec, int tid, int wave) {
 	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 	constexpr int T       = 64 * kDecWaves;
 	const bool    is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
-	const int     n_units = 8 * (d.bw + (is_alp ? 0 : d.lbw));
+	const int     n_units = vector_fits_stage<LDS>(d) ? 8 * (d.bw + (is_alp ? 0 : d.lbw)) : 0;
 	const ull2*   g       = reinterpret_cast<const ull2*>(packed + d.packed_off);
+	constexpr int kMaxUnits = (LDS::kStage - 128) / 16 < 528 ? (LDS::kStage - 128) / 16 : 528;
 #pragma unroll
-	for (int j = 0; j < (528 + T - 1) / T; ++j) {
+	for (int j = 0; j < (kMaxUnits + T - 1) / T; ++j) {
 		const int c = tid + T * j;
 		if (c < n_units) { // LDS destination = wave-uniform base + 16 * lane
 			__builtin_amdgcn_global_load_lds(g + c, reinterpret_cast<ull2*>(L.stage) + (T * j + 64 * wave), 16, 0, 0);
@@ -452,7 +469,8 @@ __device__ __forceinline__ uint32_t issue_vector_loads(DecodeLds& L, const alpgp
 	return pos;
 }
 
-__device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, uint32_t pos, int tid) {
+template <class LDS>
+__device__ __forceinline__ void land_exceptions(LDS& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, uint32_t pos, int tid) {
 	constexpr int T   = 64 * kDecWaves;
 	const int     cnt = d.exc_cnt;
 	if (tid < cnt) { atomicOr(&L.mask[pos >> 5], 1u << (pos & 31)); }
@@ -467,13 +485,14 @@ __device__ __forceinline__ void land_exceptions(DecodeLds& L, const alpgpu_vecto
 
 // V consecutive vectors per workgroup: all of their loads are in flight together, then they are unpacked one after the
 // other by the same 4 wavefronts.  V = 2 doubles the bytes in flight per CU for the same residency (8 workgroups per CU).
-template <int V, bool NT_STORE, int SINK = kSinkStore>
+template <int V, bool NT_STORE, int SINK = kSinkStore, class LDS = DecodeLds>
 __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_vector_desc* __restrict__ descs,
                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                   const uint8_t* __restrict__ packed,
                                                                   const uint8_t* __restrict__ excs, double* __restrict__ out,
                                                                   uint64_t n_vectors, uint64_t wg_offset, double lo, double hi) {
-	__shared__ DecodeLds L[V];
+	static_assert(LDS::kStage == kStageBytes || SINK == kSinkStore, "the sinks pass their lane partials through a full stage");
+	__shared__ LDS L[V];
 		const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
 	const int      wave = wave_in_wg();
@@ -557,8 +576,19 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {
-			decode_staged_vector<NT_STORE>(L[i], d[i], dict[i], excs + d[i].exc_off,
-			                               reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
+			if (LDS::kStage == kStageBytes || vector_fits_stage<LDS>(d[i])) { // (always, with the full stage)
+				decode_staged_vector<NT_STORE, kSinkStore, LDS>(L[i], d[i], dict[i], excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
+			} else { // a wide vector in a narrow-stage launch: its words straight from HBM (bounded buffer loads, as in k_sink_direct)
+				ExcMask em {0u, 0};
+				if (d[i].exc_cnt > 0) { em = load_exception_mask(L[i], lane); }
+				uint8_t*          first      = const_cast<uint8_t*>(packed + d[i].packed_off);
+				constexpr int     kRsrcFlags = 0x00020000;
+				const bool        is_alp     = d[i].scheme == ALPGPU_SCHEME_ALP;
+				const BufferWords words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d[i].bw, kRsrcFlags),
+				                         __builtin_amdgcn_make_buffer_rsrc(first + 128u * d[i].bw, 0, is_alp ? 0 : 128 * d[i].lbw, kRsrcFlags)};
+				decode_vector_quarters<NT_STORE, kSinkStore, 1>(L[i], words, d[i], dict[i], em, excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane,
+				                                                nullptr, 0.0, 0.0);
+			}
 		}
 	}
 }
@@ -700,14 +730,19 @@ int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, 
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus) {
 	(void)n_cus;
 	const uint64_t n = col->n_vectors;
-	// variant bit 0: one vector per workgroup (default) instead of two; bit 1: plain instead of non-temporal stores
-	const int      V        = (variant & 1) ? 1 : 2;
+	// variant bit 0: one vector per workgroup (default) instead of two; bit 1: plain instead of non-temporal stores; bit 2: FOUR vectors per
+	// workgroup over the narrow stage (columns of <= 16-bit vectors)
+	const int      V        = (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
 	const bool     nt       = !(variant & 2);
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
-		if (V == 2 && nt) {
+		if (V == 4 && nt) {
+			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+		} else if (V == 4) {
+			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+		} else if (V == 2 && nt) {
 			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (V == 2) {
 			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);

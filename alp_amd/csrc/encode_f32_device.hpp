@@ -302,6 +302,42 @@ __device__ __forceinline__ void pack_u32_scatter(uint32_t* image, const uint32_t
 		P.acc[t] = acc;
 	}
 }
+// The same scatter that LEAVES the image in LDS (round 4: nothing of the packed vector sits in registers while the wavefront waits for its
+// ordered offset; the image's units are copied out afterwards, store_image_f32) — bytes [0, 128 * bw) of `image`.
+__device__ __forceinline__ void pack_u32_scatter_image(uint32_t* image, const uint32_t (&vals)[4][4], int bw, int lane) {
+	u32x4*    img4    = reinterpret_cast<u32x4*>(image);
+	const int n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		if (64 * t < n_units) { img4[lane + 64 * t] = u32x4 {0u, 0u, 0u, 0u}; }
+	}
+	if (bw > 0) {
+		const uint32_t p0 = static_cast<uint32_t>(lane >> 3) * static_cast<uint32_t>(bw);
+		uint32_t*      wa = image + 4 * (lane & 7);
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			const uint32_t p = p0 + static_cast<uint32_t>(8 * m) * static_cast<uint32_t>(bw);
+			const uint32_t k = p >> 5, s = p & 31u;
+			uint32_t*      w = wa + 32 * k;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { __hip_atomic_fetch_or(w + j, vals[m][j] << s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+			if (s + static_cast<uint32_t>(bw) > 32u) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { __hip_atomic_fetch_or(w + 32 + j, vals[m][j] >> (32u - s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+			}
+		}
+	}
+	wave_lds_sync();
+}
+__device__ __forceinline__ void store_image_f32(const uint32_t* image, int bw, u32x4* __restrict__ out, int lane) {
+	const u32x4* img4    = reinterpret_cast<const u32x4*>(image);
+	const int    n_units = 8 * bw;
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const int u = lane + 64 * t;
+		if (64 * t < n_units && u < n_units) { out[u] = img4[u]; }
+	}
+}
 __device__ __forceinline__ void store_packed_units_f32(const PackedUnitsF32& P, int bw, u32x4* __restrict__ out, int lane) {
 	const int n_units = 8 * bw;
 #pragma unroll

@@ -23,7 +23,7 @@ namespace alpgpu {
 
 enum FusedMode { kSinglePass = 0, kAnalyze = 1, kPack = 2 };
 #ifndef ALPGPU_F32_ENC_OCC
-#define ALPGPU_F32_ENC_OCC 5 // __launch_bounds__' second argument for the single pass: wavefronts per SIMD the register budget is sized for
+#define ALPGPU_F32_ENC_OCC 8 // __launch_bounds__' second argument for the single pass: wavefronts per SIMD the register budget is sized for (round 4: 62 VGPRs, four tiles per CU)
 #endif
 constexpr int kScanTileF32 = 1024; // = kScanTile of encode_kernels.hip: vectors per tile of the two-pass scan
 
@@ -78,11 +78,17 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	d.base                   = 0;
 	d.bw = d.e = d.f = d.lbw = 0;
 	d.exc_cnt = d.scheme = 0;
-	// once, into registers; async_states: published by the persistent search beside this kernel (see k_encode_fused)
+	// The rowgroup's state once, into registers; async_states: published by the persistent search beside this kernel (see k_encode_fused).  Its
+	// (first) read is issued in FRONT of the vector's loads and looked at behind them: one round trip at the head of the wavefront, not two
+	// (until round 4 the vector was requested only after the state had arrived).
+	const uint64_t               v_read   = live ? v : v_first;
+	const alpgpu_rowgroup_state* rg_ptr   = rgs + v_read / kRowgroup;
+	const bool                   polling  = MODE == kSinglePass && async_states;
+	const uint32_t               st_word  = polling ? rowgroup_state_poll_begin(rg_ptr, lane) : reinterpret_cast<const uint32_t*>(rg_ptr)[lane & 7];
+	x                                     = load_vector_f32(in, v_read, lane);
 	bool                         state_ok = true;
-	const alpgpu_rowgroup_state  st  = (MODE == kSinglePass && async_states) ? load_rowgroup_state_async(rgs + (live ? v : v_first) / kRowgroup, lane, spin_limit >> 4, state_ok)
-	                                                                         : load_rowgroup_state(rgs + (live ? v : v_first) / kRowgroup, lane);
-	const alpgpu_rowgroup_state* rgp = &st;
+	const alpgpu_rowgroup_state  st       = polling ? rowgroup_state_poll_finish(rg_ptr, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
+	const alpgpu_rowgroup_state* rgp      = &st;
 	if (!state_ok) { // wave-uniform: a stall, like a look-back that gives up
 		if (lane == 0) { status_store(totals + 3, 1ull); }
 		return;
@@ -91,7 +97,6 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	// that nothing but the ordered offset stands between the wait and the stores
 	const uint64_t base_p = totals[0], base_e = totals[1];
 	if (live) {
-		x        = load_vector_f32(in, v, lane);
 		d.scheme = rgp->scheme;
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
 			int e, f;
@@ -180,55 +185,40 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
 		}
 	}
-	// pack into registers while the ordered offset is on its way (see k_encode_fused)
-	PackedUnitsF32 packed_units;
-#ifdef ALPGPU_PACK_GATHER // the round-2 form (A/B): values staged in natural order, every output word gathers its rows
-	{
-		u32x4* lv = reinterpret_cast<u32x4*>(L.vals);
-#pragma unroll
-		for (int m = 0; m < 4; ++m) { lv[64 * m + lane] = u32x4 {pvals[m][0], pvals[m][1], pvals[m][2], pvals[m][3]}; }
-		wave_lds_sync();
-		pack_u32_units(L, d.bw, lane, packed_units);
-	}
-#else
-	pack_u32_scatter(reinterpret_cast<uint32_t*>(L.vals), pvals, d.bw, lane, packed_units);
-#endif
-	// the exception record's image goes to the (now free) staging area and leaves as contiguous stores after the wait, see
-	// k_encode_fused: values always fit (4 B x 1024), the positions follow them when the whole record does (<= 682 exceptions;
-	// always for ALP_RD), else they are written from the ballots after the wait.  Pad bytes are zero.
-	const bool     alp_rec      = d.scheme == ALPGPU_SCHEME_ALP;
-	const uint32_t val_bytes    = alp_rec ? 4u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
-	const bool     pos_staged   = my_e <= sizeof(L.vals);
-	const uint32_t staged_bytes = pos_staged ? static_cast<uint32_t>(my_e) : val_bytes;
-	if (cnt > 0) {
-		uint8_t* img = reinterpret_cast<uint8_t*>(L.vals);
-		wave_lds_sync(); // the pack's reads are issued; one wavefront's LDS operations execute in order
-		if (pos_staged && lane == 0) { reinterpret_cast<uint64_t*>(img)[(staged_bytes >> 3) - 1] = 0ull; } // the pad lives in the last word
+	// Pack while the ordered offset is on its way (see k_encode_fused) — into the wavefront's 4 KiB image, which STAYS in LDS until the offset is
+	// there (round 4; until then the image was read back into sixteen registers and the record took its place): nothing vector-sized but the
+	// input itself is live across the wait.  The exception record is laid out behind the image's 128 * bw bytes when it fits what is left of the
+	// 4 KiB, and leaves as contiguous stores after the wait; else (a wide vector with many exceptions) it is written from the registers then.
+	// Pad bytes are zero.
+	pack_u32_scatter_image(reinterpret_cast<uint32_t*>(L.vals), pvals, d.bw, lane);
+	const bool     alp_rec    = d.scheme == ALPGPU_SCHEME_ALP;
+	const uint32_t val_bytes  = alp_rec ? 4u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
+	const uint32_t rec_off    = 128u * d.bw;
+	const bool     rec_staged = rec_off + my_e <= sizeof(L.vals);
+	uint8_t*       img        = reinterpret_cast<uint8_t*>(L.vals) + rec_off;
+	if (cnt > 0 && rec_staged) {
+		if (lane == 0) { reinterpret_cast<uint64_t*>(img)[(my_e >> 3) - 1] = 0ull; } // the pad lives in the last word
 		wave_lds_sync();
 		const int rbw = d.bw;
 		for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
 			const uint32_t bits = __float_as_uint(x.x[m][j]);
-			const uint16_t pos  = static_cast<uint16_t>(256 * m + 4 * lane + j);
 			if (alp_rec) {
 				reinterpret_cast<uint32_t*>(img)[r] = bits;
 			} else {
 				reinterpret_cast<uint16_t*>(img)[r] = static_cast<uint16_t>(bits >> rbw);
 			}
-			if (pos_staged) { reinterpret_cast<uint16_t*>(img + val_bytes)[r] = pos; }
+			reinterpret_cast<uint16_t*>(img + val_bytes)[r] = static_cast<uint16_t>(256 * m + 4 * lane + j);
 		});
 		wave_lds_sync();
 	}
 	if (MODE == kSinglePass) {
+		// wavefront 0 finds the tile's offset; the others park at a workgroup barrier meanwhile (see k_encode_lean: a worker that spins on an LDS
+		// word takes issue slots from the wavefronts that still compute)
 		if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
-		uint32_t spins = 0;
-		while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
-			if (++spins > 64u * kSpinLimit) { return; }
-			__builtin_amdgcn_s_sleep(2);
-		}
-		uint64_t local = 0;
-#pragma unroll
-		for (int w = 0; w < kFusedWaves; ++w) { local += w < wave ? s_size[w] : 0; }
-		const uint64_t excl = s_excl;
+		__syncthreads();
+		const uint64_t mine_sz = lane < wave ? s_size[lane & (kFusedWaves - 1)] : 0ull;
+		const uint64_t local   = wave_sum_u64(mine_sz);
+		const uint64_t excl    = s_excl;
 		if (excl == ~0ull) { return; }
 		const uint64_t pre = excl + local;
 		d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
@@ -249,18 +239,28 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	uint8_t* dst = packed + d.packed_off;
 	uint8_t* rec = excs + d.exc_off;
 	if (cnt > 0) {
-		const uint32_t* img32 = reinterpret_cast<const uint32_t*>(L.vals);
-		uint32_t*       rec32 = reinterpret_cast<uint32_t*>(rec);
-		const int       n_w   = static_cast<int>(staged_bytes >> 2);
-		for (int w = lane; w < n_w; w += 64) { rec32[w] = img32[w]; }
-		if (!pos_staged) { // > 682 exceptions in an ALP vector: positions (and their pad) straight from the ballots
+		if (rec_staged) {
+			const uint64_t* img64 = reinterpret_cast<const uint64_t*>(img);
+			uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
+			const int       n_w   = static_cast<int>(my_e >> 3);
+			for (int w = lane; w < n_w; w += 64) { rec64[w] = img64[w]; }
+		} else { // no room behind the image: values, positions and pad straight from the registers
 			uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
-			for_each_exception_f32(ballots, lane, [&](int r, int m, int j) { rpos[r] = static_cast<uint16_t>(256 * m + 4 * lane + j); });
+			const int rbw  = d.bw;
+			for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
+				const uint32_t bits = __float_as_uint(x.x[m][j]);
+				if (alp_rec) {
+					reinterpret_cast<uint32_t*>(rec)[r] = bits;
+				} else {
+					reinterpret_cast<uint16_t*>(rec)[r] = static_cast<uint16_t>(bits >> rbw);
+				}
+				rpos[r] = static_cast<uint16_t>(256 * m + 4 * lane + j);
+			});
 			const int n_pos = static_cast<int>((my_e - val_bytes) >> 1);
 			if (cnt + lane < n_pos) { rpos[cnt + lane] = 0; }
 		}
 	}
-	store_packed_units_f32(packed_units, d.bw, reinterpret_cast<u32x4*>(dst), lane);
+	store_image_f32(reinterpret_cast<const uint32_t*>(L.vals), d.bw, reinterpret_cast<u32x4*>(dst), lane);
 	if (d.scheme != ALPGPU_SCHEME_ALP && lane < 16) {
 		uint64_t* out64 = reinterpret_cast<uint64_t*>(dst + 128ull * d.bw);
 		for (int k = 0; k < d.lbw; ++k) { // word k of lane64 columns 4*lane .. 4*lane+3

@@ -24,7 +24,7 @@
 namespace alpgpu {
 
 #ifndef ALPGPU_ENC_PRIO
-#define ALPGPU_ENC_PRIO 2
+#define ALPGPU_ENC_PRIO 1 // issue priority over the search workgroup that shares the CU: 1 and 2 alike on ALP columns (3.01 / 3.02 ms), 1 better on ALP_RD columns, whose search paces the encode (4.43 against 4.58 ms); 0: 3.16 / 4.46
 #endif
 #ifndef ALPGPU_LEAN_OCC
 #define ALPGPU_LEAN_OCC 6 // __launch_bounds__ second argument (wavefronts per SIMD the register budget must admit): 6 -> <= 80 VGPRs (what three 48 KiB tiles per CU need), 7 -> <= 72, 8 -> <= 64

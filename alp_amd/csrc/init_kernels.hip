@@ -286,12 +286,12 @@ __device__ __forceinline__ void store_rowgroup_state(alpgpu_rowgroup_state* __re
 // search lasts and gives it back afterwards, instead of keeping the third tile out for the whole encode the way a 96-register wavefront per
 // SIMD would (6 x 80 + 96 > 512) — round 4: 3.13 -> 3.05 ms per 1 Mi vectors on the mixed column beside k_encode_lean.
 constexpr int kInitAsyncTileWaves = 8;
-template <bool ASYNC, int W>
-constexpr int init_waves_per_simd() {
-	return !ASYNC ? 1 : (W == kInitAsyncWaves ? kInitAsyncWavesPerSimd : (W == kInitAsyncTileWaves ? 6 : 1));
+template <bool ASYNC, int W, int BITS>
+constexpr int init_waves_per_simd() { // (a float encode tile has 64 registers per lane: its tile-shaped search must fit 64 as well)
+	return !ASYNC ? 1 : (W == kInitAsyncWaves ? kInitAsyncWavesPerSimd : (W == kInitAsyncTileWaves ? (BITS == 32 ? 8 : 6) : 1));
 }
 template <class P, bool FROM_SAMPLES, int W, bool ASYNC>
-__global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W>())) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
+__global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W, P::kBits>())) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
                                                           alpgpu_rowgroup_state* __restrict__ rgs, int force_rd,
                                                           uint16_t* __restrict__ rd_order, uint64_t rg_first, uint64_t rg_end, double* __restrict__ cut_est_out) {
 	static_assert(!ASYNC || !FROM_SAMPLES, "the persistent form gathers its own samples");
@@ -696,7 +696,7 @@ int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t 
 }
 int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                    uint64_t rg_count, int grid) {
-	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, false);
+	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, true); // the float tiles are lean-shaped (encode_f32_kernels.hip)
 }
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {

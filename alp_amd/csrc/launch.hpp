@@ -7,6 +7,10 @@
 
 namespace alpgpu {
 
+// what alpgpu_encode_* memsets the rowgroup states to in front of a search that PUBLISHES them beside the encode: every byte 0xFF = "not there"
+// (alp_device.hpp: rowgroup_state_is_whole — no word of a real state is all-ones, so a torn read of a state being published is recognised)
+constexpr int kStateUnpublished = 0xFF;
+
 // decode_kernels.hip
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus);
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg);

@@ -81,9 +81,16 @@ def test_falp_every_bit_width_class(ctx, oracle, bw):
     want = oracle.decode_column(enc)
     got = gpu_decode(ctx, enc)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    from alp_amd import capi
+    try:  # four vectors per workgroup over the narrow stage (widths <= 17 staged, wider ones read straight from HBM): the same bits
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 4)
+        got4 = gpu_decode(ctx, enc)
+    finally:
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+    assert np.array_equal(got4.view(np.uint64), want.view(np.uint64))
 
 
-@pytest.mark.parametrize("vectors_per_wg,plain", [(2, 0), (2, 1), (1, 1)])
+@pytest.mark.parametrize("vectors_per_wg,plain", [(2, 0), (2, 1), (1, 1), (4, 0), (4, 1)])  # 4: the narrow stage; wide and ALP_RD vectors take its straight-from-HBM arm
 def test_tuning_options_do_not_change_results(ctx, oracle, vectors_per_wg, plain):
     from alp_amd import capi
     try:

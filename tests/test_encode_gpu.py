@@ -392,7 +392,7 @@ def test_alp_vectors_of_every_packed_width(ctx, oracle, route, exceptions):
         ctx.set_option(capi.OPT_ENCODE_TWO_PASS, 0)
     for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{route}: {what}"
-    for vpw in (1, 2):
+    for vpw in (1, 2, 4):
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
         out = ctx.decode(dcol)
         ctx.synchronize()
