@@ -127,6 +127,7 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 	const uint32_t fact   = kFactArrF[f];
 	const float    frac_e = kFracArrF[e];
 	R.cnt   = 0;
+#ifndef ALPGPU_F32_SHORTCUT_ANALYSIS // the default: every value through the literal conversions
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -144,6 +145,72 @@ __device__ __forceinline__ void encode_alp_registers_f32(const VecInF& in, int e
 			R.cnt += __builtin_popcountll(R.ballot[m][j]);
 		}
 	}
+#else
+	// -DALPGPU_F32_SHORTCUT_ANALYSIS (round 4, measured, NOT the default: bit-identical — 130 float / fuzz / reference tests — but 1093 instead of 1037 vector
+	// instructions per vector and 2.45 instead of 2.43 ms per 1 Mi vectors: its twelve extra lane masks per value step push the kernel's
+	// scalar registers over the edge, and every spilled mask comes back as v_readlane pairs — profiles/r04_float_encode.txt):
+	// the double kernel's shortcut arithmetic (encode_device.hpp: encode_alp_registers), restated for float, on value PAIRS so that the
+	// six roundings per value issue as packed instructions (v_pk_mul_f32 / v_pk_add_f32: two values per issue slot; -ffp-contract=off keeps every
+	// one of them its own IEEE rounding).  The kernel runs eight wavefronts per SIMD with its VALU 85 % busy (profiles/r04_float_encode.txt): what
+	// it executes per value is what it costs.  With t = (v * 10^e) * 10^-f, u = t + M, r = u - M (M = 2^23 + 2^22):
+	//   * |t| < 2^22: u lies in [2^23, 2^24), where consecutive floats are consecutive integers: the encoded integer (int32)r is bits(u) - bits(M);
+	//   * |r * 10^f| < 2^31: the int32 product does not wrap, and (float)(int32)(enc * 10^f) is the correctly rounded value of that integer — the
+	//     IEEE product r * 10^f of two exactly representable floats (10^f = 2^f 5^f, 5^10 < 2^24);
+	//   * |r * 10^f| > 2^31 (as a float: the exact product is then > 2^31 + 128): the product wraps.  Up to 2^32 it comes back with the opposite
+	//     sign of v and not zero, beyond that with a magnitude below 2^31 <= half of |P| while v = P 10^-e (1 +- 2^-22): never equal — an exception
+	//     without computing it;
+	//   * NaN, +-Inf, -0.0 (pass 1 replaces them by 2^63, encoder.hpp:326-338): the cast of the huge t gives INT32_MIN, whose product with 10^f
+	//     is 0 modulo 2^32 for f >= 1 and -2^31 for f = 0: decoded 0 or -2^31 10^-e, never 2^63 — always exceptions;
+	//   * everything else (|t| >= 2^22, or |r * 10^f| == 2^31 exactly) redoes the value step literally, for the whole wavefront.
+	// Bit-identical by construction; tests/test_float_gpu.py, test_fuzz_gpu.py and test_reference_gpu.py compare every stream byte.
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	const float fact_f = static_cast<float>(fact); // exact (f <= 9; f = 10: fact is 10^10 mod 2^32, and then every non-zero integer is an exception on either route: see below)
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		f32x2    vv[2], rr[2], dec[2], uu[2];
+		uint64_t over_m[4], wide_m[4], sp_m[4];
+		uint64_t any_wide = 0;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const f32x2 v2 = {in.x[m][2 * h], in.x[m][2 * h + 1]};
+			const f32x2 t2 = (v2 * exp10) * frac_f;
+			const f32x2 u2 = t2 + kMagicF;
+			const f32x2 r2 = u2 - kMagicF;
+			const f32x2 p2 = r2 * fact_f;
+			vv[h] = v2, rr[h] = r2, uu[h] = u2;
+			dec[h] = p2 * frac_e;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				const int   j  = 2 * h + c;
+				const float ap = __builtin_fabsf(p2[c]);
+				sp_m[j]        = ballot64(__builtin_amdgcn_classf(v2[c], 0x227)); // sNaN, qNaN, -Inf, -0.0, +Inf
+				over_m[j]      = ballot64(ap > 0x1p31f);
+				wide_m[j]      = (ballot64(!(__builtin_fabsf(t2[c]) < 0x1p22f)) | (ballot64(!(ap < 0x1p31f)) & ~over_m[j])) & ~sp_m[j];
+				any_wide |= wide_m[j];
+			}
+		}
+		int32_t enc[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { enc[j] = static_cast<int32_t>(__float_as_uint(uu[j >> 1][j & 1]) - 0x4B400000u); }
+		float decs[4] = {dec[0][0], dec[0][1], dec[1][0], dec[1][1]};
+		if (__builtin_expect(any_wide != 0, 0)) { // wave-uniform, rare: the literal conversions for the value steps that need them
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (wide_m[j] != 0) {
+					enc[j]  = cast32_x86(rr[j >> 1][j & 1]);
+					decs[j] = decode_value_f32(enc[j], fact, frac_e);
+				}
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint64_t exc_m = ballot64(decs[j] != vv[j >> 1][j & 1]) | (over_m[j] & ~wide_m[j]) | sp_m[j];
+			R.enc[m][j]          = enc[j];
+			R.ballot[m][j]       = exc_m;
+			R.cnt += __builtin_popcountll(exc_m);
+		}
+	}
+#endif
 	// filler = encoded value at the first non-exception position p (encoder.hpp:382-388); 0 when there is none or p == 1023
 	int32_t filler = 0;
 	bool    found  = false;

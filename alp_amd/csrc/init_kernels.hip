@@ -696,7 +696,8 @@ int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t 
 }
 int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                    uint64_t rg_count, int grid) {
-	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, true); // the float tiles are lean-shaped (encode_f32_kernels.hip)
+	static const bool tile = std::getenv("ALPGPU_F32_SEARCH_TILE") != nullptr; // A/B: the eight-wavefront (64-register, spilling) form instead of four wavefronts of 96
+	return launch_rowgroup_init_async_t<PrecF32>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, tile);
 }
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {

@@ -149,8 +149,11 @@ int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 or 2 consecutive vectors per decode
  * workgroup, or 0 (default) = choose from the column's size hints: 2 keeps twice the bytes in flight and is faster for
- * narrow columns (average packed width <= 17 bits; <= 26 bits when there are about two or more exceptions per vector),
- * 1 for wider ones — every ALP_RD column — and when no hint is present.  ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
+ * narrow columns (average packed width <= 16 bits; <= 20 bits when there are about two or more exceptions per vector: crossovers
+ * re-measured at one-bit resolution in round 4), 1 for wider ones — every ALP_RD column — and when no hint is present.
+ * 4 (double columns; round 4) = four vectors per workgroup over a 2.25 KiB stage, vectors wider than 17 bits read straight from HBM:
+ * built to lift the narrow widths' floor, measured SLOWER than 2 at every width (profiles/r04_decode_floor.txt), never chosen by 0.
+ * ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
 #define ALPGPU_OPT_DECODE_VECTORS_PER_WG 1
 #define ALPGPU_OPT_DECODE_PLAIN_STORES 2
 /* ALPGPU_OPT_ENCODE_TWO_PASS: 1 = analysis pass + scan + pack pass (reads the input twice) instead of the default
@@ -441,7 +444,7 @@ int alpgpu_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint3
 int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
 int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
 int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
-/* ALPGPU_OPT_DECODE_VECTORS_PER_WG applies with values 0 (auto), 1, 2 and, for float only, 4 */
+/* ALPGPU_OPT_DECODE_VECTORS_PER_WG applies with values 0 (auto), 1, 2 and 4 (float: four vectors over the full stage) */
 int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
 /* The fused consumers of alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 for float columns.  Sums accumulate in double
  * (every float widens exactly): thread t = 64 w + L of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0, giving

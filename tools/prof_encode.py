@@ -20,3 +20,7 @@ col = capi.DeviceColumn(n, 0)
 med, mean = time_launches(lambda: ctx.encode(x, col), 5, 2)
 pb, eb, ov = ctx.column_totals(col)
 print(f"{kind}: n={n} encode median {med:.3f} ms -> {n*8192/med/1e6:.1f} GB/s in; packed {pb/n:.0f} B/vec exc {eb/n:.0f} B/vec overflow {ov}")
+# ... and the decode of what was just encoded (the ALP_RD column's decode has no other row in the round's profile)
+out = torch.empty(n * 1024, dtype=torch.float64, device=dev)
+dmed, _ = time_launches(lambda: ctx.decode(col, out), 5, 3)
+print(f"{kind}: decode of the encoded column median {dmed:.3f} ms = {(n * 8192 + pb + eb + 13 * n) / dmed / 1e6 / 8000:.3f} of peak; round trip {bool(torch.equal(out.view(torch.int64), x.view(torch.int64)))}")
