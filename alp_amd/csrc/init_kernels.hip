@@ -537,10 +537,17 @@ __global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W, P::kBits>())
 	}
 	__syncthreads();
 
+#ifdef ALPGPU_EXPERIMENT_RD_STOP_AFTER_SORT // timing experiments (profiles/r04_rd_search.txt): where the ALP_RD half of the search spends its time
+	continue;
+#endif
 	RdWaveScratch& WS = s_rd[wave];
 	// force_rd = 0x100 | cut: rd_encoder::build_left_parts_dictionary for ONE cut position (rd.hpp:33-87, called on its own): the other cuts
 	// get an estimate nothing beats, so the dictionary below is that cut's
+#ifdef ALPGPU_EXPERIMENT_RD_ONE_CUT
+	const int forced_cut = 12;
+#else
 	const int forced_cut = (force_rd & 0x100) ? (force_rd & 0xFF) : 0;
+#endif
 	for (int cut = wave + 1; cut <= 16; cut += W) { // wave-uniform
 		const int rbw = P::kBits - cut;
 		if (forced_cut != 0 && cut != forced_cut) {
