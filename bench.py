@@ -646,7 +646,7 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
         "value": round(total_in * e_steps / e_elapsed / 1e9, 2), "unit": "GB/s input doubles (whole job)", "per_gpu_value": round(n * 8192 * e_steps / e_elapsed / 1e9, 2),
         "ms_per_step": round(e_elapsed / e_steps * 1e3, 4), "steps": e_steps,
         "roofline": {"bound": "hbm", "achieved": round(e_alg / e_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(e_alg / e_ms / 1e6 / HBM_PEAK_GBPS, 4),
-                     "kernels": "k_rowgroup_init (persistent, beside) || k_encode_fused (+ gated recovery launches)", "ms": round(e_ms, 4), "algorithmic_bytes_per_step": e_alg},
+                     "kernels": "k_rowgroup_init (persistent, beside) || k_encode_lean (+ gated recovery launches)", "ms": round(e_ms, 4), "algorithmic_bytes_per_step": e_alg},
         "compressed_bits_per_value": round((pb + eb + 32 * n) * 8 / (n * VEC), 2), "overflow": int(ov),
         "decode_of_the_encoded_shard": {"value": round(total_in * e_steps / d_elapsed / 1e9, 2), "unit": "GB/s decoded doubles (whole job)",
                                         "roofline_frac_algorithmic": round((n * 8192 + pb + eb + 13 * n) / d_ms / 1e6 / HBM_PEAK_GBPS, 4)},
@@ -799,7 +799,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
         vec_ms = extras[label]["vector_encode_ms"]
         extras[label]["traffic_only_probe"] = {"ms": round(pmed, 3), "GBps_read_plus_write": round(n * (8192 + wb) / pmed / 1e6, 1), "written_bytes_per_vector": wb,
                                                "vector_encode_ms": round(vec_ms, 3), "vector_encode_vs_probe": round(pmed / vec_ms, 4),
-                                               "note": "same launch shape as k_encode_fused, loads + dependent stores only; the encode cannot be faster than this plus the rowgroup search"}
+                                               "note": "same launch shape as the encode kernel, loads + dependent stores only; the encode cannot be faster than this plus the rowgroup search"}
     del probe_in
     # single precision: alpgpu_encode_f32 / alpgpu_decode_f32 on 1 Mi float vectors (4 GiB decoded)
     fl = {}
