@@ -29,10 +29,12 @@ struct alpgpu_ctx {
 	int         encode_two_pass; // 0 (default): single-pass encode with look-back offsets; 1: analysis + scan + pack
 	int         force_stall;     // debug: the single pass gives up in its look-back, the recovery route re-encodes
 	int         async_init_wg_per_cu; // persistent search workgroups per CU (1; ALPGPU_ASYNC_INIT_WG_PER_CU for experiments)
+	int         async_init_adaptive;  // three per CU when the column's head is mostly ALP_RD (default; ALPGPU_ASYNC_INIT_ADAPTIVE=0 for A/B runs)
 	int         async_init;      // 1 (default): alpgpu_encode_* of a long column runs the rowgroup search BESIDE the vector encode (second stream)
 	hipStream_t init_stream;     // ... on this stream (highest priority: its few workgroups are placed first)
 	hipEvent_t  ev_fork, ev_head, ev_join;
 	int         encode_kernel;   // ALPGPU_ENCODE_KERNEL_LEAN (default) / _CLASSIC
+	int         decode_pairing;  // ALPGPU_OPT_DECODE_PAIRING (experiment): 0 off, 1..3 -> k_decode_pairs
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -113,6 +115,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->async_init     = std::getenv("ALPGPU_ENCODE_SYNC_INIT") ? 0 : 1;
 	ctx->async_init_wg_per_cu = std::getenv("ALPGPU_ASYNC_INIT_WG_PER_CU") ? std::atoi(std::getenv("ALPGPU_ASYNC_INIT_WG_PER_CU")) : 1;
 	if (ctx->async_init_wg_per_cu < 1) { ctx->async_init_wg_per_cu = 1; }
+	ctx->async_init_adaptive = std::getenv("ALPGPU_ASYNC_INIT_ADAPTIVE") ? std::atoi(std::getenv("ALPGPU_ASYNC_INIT_ADAPTIVE")) : 1;
 	ctx->n_cus          = prop.multiProcessorCount;
 	ctx->hbm_bytes      = prop.totalGlobalMem;
 	ctx->decode_variant  = 1; // bit 0: one vector per decode workgroup, bit 1: plain stores
@@ -123,6 +126,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
 	ctx->pipelined_consumer = 0;
+	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
 	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
@@ -194,6 +198,10 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_ENCODE_ASYNC_INIT:
 		if (value < 0 || value > 2) { return fail(ALPGPU_ERR_INVALID, "async init: 0 (off), 1 (double columns: default) or 2 (float columns too)"); }
 		ctx->async_init = static_cast<int>(value);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_PAIRING:
+		if (value < 0 || value > 3) { return fail(ALPGPU_ERR_INVALID, "decode pairing: 0 (off) .. 3"); }
+		ctx->decode_pairing = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_KERNEL:
 		if (value != ALPGPU_ENCODE_KERNEL_LEAN && value != ALPGPU_ENCODE_KERNEL_CLASSIC) { return fail(ALPGPU_ERR_INVALID, "encode kernel: 0 (lean) or 1 (classic)"); }
@@ -404,17 +412,21 @@ static int encode_with_side_search(alpgpu_ctx* ctx, const T* d_in, uint64_t n_ve
 	if (!serial) { ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0)); }
 	// the head of the search and, behind it, the persistent rest: both on the side stream; the context's stream meanwhile clears its
 	// totals and status words and then waits for the head only
-	auto search = [&](uint64_t first, uint64_t count, int grid) {
+	auto search = [&](uint64_t first, uint64_t count, int grid, uint32_t adaptive_base = 0) {
 		if constexpr (f32) {
 			return alpgpu::launch_rowgroup_init_async_f32(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid);
 		} else {
 			return alpgpu::launch_rowgroup_init_async(side, d_in, n_vectors, col->d_rowgroups, col->d_rd_order, first, count, grid,
-			                                          ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN && count > static_cast<uint64_t>(grid));
+			                                          ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN && count > static_cast<uint64_t>(grid), adaptive_base);
 		}
 	};
 	if (search(0, kAsyncHeadRowgroups, static_cast<int>(kAsyncHeadRowgroups)) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError()); }
 	ALPGPU_HIP(hipEventRecord(ctx->ev_head, side));
-	if (search(kAsyncHeadRowgroups, n_rg - kAsyncHeadRowgroups, ctx->n_cus * ctx->async_init_wg_per_cu) != ALPGPU_OK) {
+	// double columns beside the lean kernel: three search workgroups per CU are launched, two of them leave at once unless the column's head is
+	// mostly ALP_RD (whose latency-bound search the encode would wait for anyway; k_rowgroup_init: `walkers`)
+	const bool adaptive = !f32 && ctx->async_init_adaptive && ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN && ctx->async_init_wg_per_cu < 3;
+	const int  wg_per_cu = adaptive ? 3 : ctx->async_init_wg_per_cu;
+	if (search(kAsyncHeadRowgroups, n_rg - kAsyncHeadRowgroups, ctx->n_cus * wg_per_cu, adaptive ? static_cast<uint32_t>(ctx->n_cus * ctx->async_init_wg_per_cu) : 0u) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
 	}
 	ALPGPU_HIP(hipEventRecord(ctx->ev_join, side));
@@ -451,7 +463,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const bool   four     = bits <= (with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits);
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
 	}
-	return variant;
+	return (variant & 7) | (ctx->decode_pairing << 3);
 }
 
 // what alpgpu_decode_f64 / _f32 would launch for this column right now (option + size hints): vectors per decode workgroup

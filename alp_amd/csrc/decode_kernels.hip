@@ -593,6 +593,84 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	}
 }
 
+// ---- experiment (round 4): a workgroup that decides how to run its vectors from their descriptors ---------------------------------------------
+// The launch shape of k_decode_column is one decision per COLUMN (from its size hints), but a column's rowgroups differ: on the benchmark column
+// (widths 1..53 by rowgroup) the average says "one vector per workgroup" and the narrow third of the rowgroups runs in the shape that is 20-30 %
+// slower for it when a whole column looks like that.  Here every workgroup owns TWO consecutive vectors, reads both descriptors at once and decides:
+//   PAIRING 1: both narrow -> loads of both in flight together (k_decode_column<2>); else one after the other (the second one's descriptor
+//              round trip is already behind it)
+//   PAIRING 2: as 1, but the second vector's loads are issued as soon as the first one's have landed, in front of its unpack
+//   PAIRING 3: no decision: three vectors per two workgroups (even workgroups two together, odd ones one) — 12 vectors in flight per CU, between
+//              the 8 and the 16 of the two shapes of k_decode_column
+// Not the default anywhere: tools/sweep_pairing.py measures them (profiles/r04_decode_floor.txt, section 4).
+__device__ __forceinline__ bool vector_is_narrow(const alpgpu_vector_desc& d) {
+	return d.scheme == ALPGPU_SCHEME_ALP && static_cast<int>(d.bw) <= (d.exc_cnt >= 2 ? 20 : 16);
+}
+__device__ __forceinline__ void prepare_exceptions(DecodeLds& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, uint32_t pos, int tid) {
+	if (d.exc_cnt != 0) { // workgroup-uniform
+		if (tid < 32) { L.mask[tid] = 0; }
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		land_exceptions(L, d, rec, pos, tid);
+	}
+}
+__device__ __forceinline__ void loads_have_landed() {
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+}
+template <bool NT_STORE, int PAIRING>
+__global__ __launch_bounds__(64 * kDecWaves) void k_decode_pairs(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                 const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
+                                                                 uint64_t n_vectors, uint64_t wg_offset) {
+	__shared__ DecodeLds L[2];
+	const int      tid  = static_cast<int>(threadIdx.x);
+	const int      lane = tid & 63;
+	const int      wave = wave_in_wg();
+	const uint64_t g    = wg_offset + blockIdx.x;
+	uint64_t       v0;
+	int            n_here;
+	if constexpr (PAIRING == 3) {
+		v0     = 3 * (g >> 1) + ((g & 1) ? 2 : 0);
+		n_here = (g & 1) ? 1 : 2;
+	} else {
+		v0     = 2 * g;
+		n_here = 2;
+	}
+	if (v0 >= n_vectors) { return; }
+	if (v0 + n_here > n_vectors) { n_here = 1; }
+	const uint64_t           v1 = n_here == 2 ? v0 + 1 : v0;
+	const alpgpu_vector_desc d0 = descs[v0], d1 = descs[v1];
+	const VectorConsts       c0 = load_vector_consts(rgs, v0, d0), c1 = load_vector_consts(rgs, v1, d1);
+	double2*                 o0 = reinterpret_cast<double2*>(out + v0 * kVec);
+	double2*                 o1 = reinterpret_cast<double2*>(out + v1 * kVec);
+	const bool together = n_here == 2 && (PAIRING == 3 || (vector_is_narrow(d0) && vector_is_narrow(d1))); // workgroup-uniform
+	if (together) {
+		const uint32_t p0 = issue_vector_loads(L[0], d0, packed, excs + d0.exc_off, tid, wave);
+		const uint32_t p1 = issue_vector_loads(L[1], d1, packed, excs + d1.exc_off, tid, wave);
+		if (d0.exc_cnt != 0 || d1.exc_cnt != 0) {
+			if (tid < 64) { L[tid >> 5].mask[tid & 31] = 0; }
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			land_exceptions(L[0], d0, excs + d0.exc_off, p0, tid);
+			land_exceptions(L[1], d1, excs + d1.exc_off, p1, tid);
+		}
+		loads_have_landed();
+		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[0], d0, c0, excs + d0.exc_off, o0, wave, lane);
+		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[1], d1, c1, excs + d1.exc_off, o1, wave, lane);
+		return;
+	}
+	const uint32_t p0 = issue_vector_loads(L[0], d0, packed, excs + d0.exc_off, tid, wave);
+	prepare_exceptions(L[0], d0, excs + d0.exc_off, p0, tid);
+	loads_have_landed();
+	uint32_t p1 = 0;
+	if (PAIRING == 2 && n_here == 2) { p1 = issue_vector_loads(L[1], d1, packed, excs + d1.exc_off, tid, wave); }
+	decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[0], d0, c0, excs + d0.exc_off, o0, wave, lane);
+	if (n_here == 2) {
+		if (PAIRING != 2) { p1 = issue_vector_loads(L[1], d1, packed, excs + d1.exc_off, tid, wave); }
+		prepare_exceptions(L[1], d1, excs + d1.exc_off, p1, tid);
+		loads_have_landed();
+		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[1], d1, c1, excs + d1.exc_off, o1, wave, lane);
+	}
+}
+
 // ---- the sinks with ONE wavefront per vector, packed words read from HBM as they are needed (no stage, no barrier) ---------------------
 // What the four-wavefront sinks run out of is instruction issue — the scalar unit first, the VALU right behind — because every wavefront of a
 // workgroup repeats the wave-uniform prologue of both its vectors (profiles/r03_consumers.txt).  Here a wavefront owns a vector: one
@@ -732,8 +810,22 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	const uint64_t n = col->n_vectors;
 	// variant bit 0: one vector per workgroup (default) instead of two; bit 1: plain instead of non-temporal stores; bit 2: FOUR vectors per
 	// workgroup over the narrow stage (columns of <= 16-bit vectors)
-	const int      V        = (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
 	const bool     nt       = !(variant & 2);
+	const int      pairing  = (variant >> 3) & 3; // experiment: k_decode_pairs
+	if (pairing != 0) {
+		const uint64_t n_wg_p   = pairing == 3 ? 2 * ((n + 2) / 3) : (n + 1) / 2;
+		const uint64_t kMaxGridP = 1ull << 30;
+		for (uint64_t off = 0; off < n_wg_p; off += kMaxGridP) {
+			const dim3 grid(static_cast<unsigned>(n_wg_p - off < kMaxGridP ? n_wg_p - off : kMaxGridP)), block(64 * kDecWaves);
+#define ALPGPU_LAUNCH_PAIRS(NT, P) hipLaunchKernelGGL((k_decode_pairs<NT, P>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off)
+			if (pairing == 1) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 1); } else { ALPGPU_LAUNCH_PAIRS(false, 1); } }
+			if (pairing == 2) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 2); } else { ALPGPU_LAUNCH_PAIRS(false, 2); } }
+			if (pairing == 3) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 3); } else { ALPGPU_LAUNCH_PAIRS(false, 3); } }
+#undef ALPGPU_LAUNCH_PAIRS
+		}
+		return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+	}
+	const int      V        = (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {

@@ -133,6 +133,27 @@ __device__ __forceinline__ VecIn load_vector(const double* __restrict__ in, uint
 	return r;
 }
 
+// The same with a cache policy chosen per wavefront (k_encode_lean): `streaming` = non-temporal loads, for a vector that is read exactly once.
+__device__ __forceinline__ VecIn load_vector_policy(const double* __restrict__ in, uint64_t v, int lane, bool streaming) {
+	typedef double d2v __attribute__((ext_vector_type(2)));
+	const d2v* p = reinterpret_cast<const d2v*>(in + v * kVec);
+	VecIn      r;
+	if (streaming) { // wave-uniform
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			const d2v q = __builtin_nontemporal_load(p + 64 * m + lane);
+			r.x[m]      = make_double2(q.x, q.y);
+		}
+	} else {
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			const d2v q = p[64 * m + lane];
+			r.x[m]      = make_double2(q.x, q.y);
+		}
+	}
+	return r;
+}
+
 // ---- second-level sampling (encoder.hpp:241-305) --------------------------------------------------------
 // 32 samples = input[32*s]; both half-waves evaluate one candidate each per round (lane & 31 = sample).
 // All candidates are evaluated; the reference's early exit (two consecutive non-improvements) only stops
@@ -298,12 +319,15 @@ __device__ __forceinline__ void encode_alp_registers(const VecIn& in, int e, int
 				// never decode to v — for |P| < 2^64 it has the opposite sign of v and is not zero, for larger |P| its magnitude is below
 				// 2^63 while |v| 10^e > 0.96 * 2^64 — so the value is an exception without computing it.  Two-decimal values up to 10^5
 				// land here all the time: the reference's search gives them (e,f) = (14,12), and |v| >= 92 233.72 wraps.  Only
-				// |t| >= 2^51 (incl. Inf), NaN and |prod| == 2^63 exactly (P = -2^63 is representable) take the literal route.
+				// |t| >= 2^51 (incl. Inf) and NaN take the literal route.
 				// Every test goes straight from its compare into a lane mask (ballot of a compare = the compare's own SGPR result) and
 				// the masks are combined as 64-bit integers on the scalar unit.
 				const double ap = __builtin_fabs(prod);
 				over_m[g][j]    = ballot64(ap > 0x1p63);                                                                   // the product wraps for sure
-				wide_m[g][j]    = ballot64(!(__builtin_fabs(t) < 0x1p51)) | (ballot64(!(ap < 0x1p63)) & ~over_m[g][j]); // |t| >= 2^51, NaN, |prod| == 2^63
+				// (round 4: until now a third compare also sent |prod| == 2^63 down the literal route.  It cannot happen on the shortcut route:
+				//  there r is an integer with |r| <= 2^51, and r * 10^f rounds to +-2^63 only from [2^63 - 512, 2^63 + 1024], which holds no
+				//  multiple of 10^f for f >= 4 and needs |r| > 2^51 for f <= 3 — tools/check_no_product_at_2p63.py enumerates it.)
+				wide_m[g][j]    = ballot64(!(__builtin_fabs(t) < 0x1p51)); // |t| >= 2^51 (incl. Inf), NaN
 				any_wide |= wide_m[g][j];
 			}
 		}

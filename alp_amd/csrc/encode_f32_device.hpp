@@ -31,7 +31,11 @@ __device__ __forceinline__ VecInF load_vector_f32(const float* __restrict__ in, 
 	const f32x4* p = reinterpret_cast<const f32x4*>(in + v * kVec);
 	VecInF       r;
 #pragma unroll
+#ifdef ALPGPU_F32_PLAIN_POLICY // (A/B: plain loads and stores, as until late in round 4)
 	for (int m = 0; m < 4; ++m) { r.x[m] = p[64 * m + lane]; }
+#else
+	for (int m = 0; m < 4; ++m) { r.x[m] = __builtin_nontemporal_load(p + 64 * m + lane); } // read once (the two-pass form's second read misses the caches of a long column anyway)
+#endif
 	return r;
 }
 
@@ -402,7 +406,11 @@ __device__ __forceinline__ void store_image_f32(const uint32_t* image, int bw, u
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
 		const int u = lane + 64 * t;
+#ifdef ALPGPU_F32_PLAIN_POLICY
 		if (64 * t < n_units && u < n_units) { out[u] = img4[u]; }
+#else
+		if (64 * t < n_units && u < n_units) { __builtin_nontemporal_store(img4[u], out + u); } // written once
+#endif
 	}
 }
 __device__ __forceinline__ void store_packed_units_f32(const PackedUnitsF32& P, int bw, u32x4* __restrict__ out, int lane) {

@@ -96,7 +96,7 @@ __device__ __forceinline__ void lean_analyze_alp(const VecIn& in, int e, int f, 
 				dec[g][j] = prod * frac_e;
 				const double ap = __builtin_fabs(prod);
 				over_m[g][j]    = ballot64(ap > 0x1p63);
-				wide_m[g][j]    = ballot64(!(__builtin_fabs(t) < 0x1p51)) | (ballot64(!(ap < 0x1p63)) & ~over_m[g][j]);
+				wide_m[g][j]    = ballot64(!(__builtin_fabs(t) < 0x1p51)); // (|prod| == 2^63 cannot occur with |t| < 2^51: encode_device.hpp)
 				any_wide |= wide_m[g][j];
 			}
 		}
@@ -315,7 +315,11 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 #pragma unroll
 	for (int t = 0; t < kLeanImageBytes / 1024; ++t) {
 		const int u = lane + 64 * t;
+#ifdef ALPGPU_LEAN_PLAIN_STORES // (A/B: until late in round 4 the lean kernel wrote its packed words with plain stores)
 		if (64 * t < n_units && u < n_units) { out[u] = img2[u]; }
+#else
+		if (64 * t < n_units && u < n_units) { __builtin_nontemporal_store(img2[u], out + u); } // written once, read by nobody on this device soon
+#endif
 	}
 }
 
@@ -347,7 +351,14 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	// the first poll of the rowgroup's state (or its plain read) in FRONT of the 8 KiB everything waits for, the look at it behind them
 	const alpgpu_rowgroup_state* rgp      = rgs + v_read / kRowgroup;
 	const uint32_t               st_word  = async_states ? rowgroup_state_poll_begin(rgp, lane) : reinterpret_cast<const uint32_t*>(rgp)[lane & 7];
+	// The input is read once and the packed words are written once: both non-temporal (round 4: 3.02 -> 2.91 ms per 1 Mi vectors on the mixed
+	// column with both, 2.95 with the stores alone) — except the input of wavefront 0, which reads its vector a second time when it is wider
+	// than the image (every ALP_RD vector) and should find it in the L2 / Infinity Cache then (all loads non-temporal: ALP_RD column 4.28 -> 4.41 ms).
+#ifdef ALPGPU_LEAN_PLAIN_LOADS
 	const VecIn                  x        = load_vector(in, v_read, lane);
+#else
+	const VecIn                  x        = load_vector_policy(in, v_read, lane, wave != 0);
+#endif
 	bool                         state_ok = true;
 	const alpgpu_rowgroup_state  st       = async_states ? rowgroup_state_poll_finish(rgp, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
 	if (!state_ok) { // wave-uniform
@@ -510,7 +521,11 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 			const uint64_t* img64 = reinterpret_cast<const uint64_t*>(img);
 			uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
 			const int       n_w   = static_cast<int>(my_e >> 3);
+#ifdef ALPGPU_LEAN_PLAIN_STORES
 			for (int w = lane; w < n_w; w += 64) { rec64[w] = img64[w]; }
+#else
+			for (int w = lane; w < n_w; w += 64) { __builtin_nontemporal_store(img64[w], rec64 + w); }
+#endif
 		} else { // a record larger than its staging room (rare): the vector is read again and the record written from it (as the two-pass form's pack kernel does)
 			const VecIn xr   = load_vector(in, v, lane);
 			uint16_t*   rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);

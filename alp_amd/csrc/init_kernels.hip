@@ -293,7 +293,8 @@ constexpr int init_waves_per_simd() { // (a float encode tile has 64 registers p
 template <class P, bool FROM_SAMPLES, int W, bool ASYNC>
 __global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W, P::kBits>())) void k_rowgroup_init(const typename P::value_t* __restrict__ in, uint64_t n_vectors,
                                                           alpgpu_rowgroup_state* __restrict__ rgs, int force_rd,
-                                                          uint16_t* __restrict__ rd_order, uint64_t rg_first, uint64_t rg_end, double* __restrict__ cut_est_out) {
+                                                          uint16_t* __restrict__ rd_order, uint64_t rg_first, uint64_t rg_end, double* __restrict__ cut_est_out,
+                                                          uint32_t adaptive_base) {
 	static_assert(!ASYNC || !FROM_SAMPLES, "the persistent form gathers its own samples");
 	static_assert(W >= 2 && W <= kMaxSampledVectors, "the scratch arrays are sized for 9 wavefronts; wavefront 0 and the order replay use two of them");
 	__shared__ typename P::value_t smp[kMaxSampledVectors * 32];
@@ -320,7 +321,21 @@ __global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W, P::kBits>())
 	const int      wave    = wave_in_wg();
 	const int      tid     = static_cast<int>(threadIdx.x);
 	(void)rg_end;
-	for (uint64_t rg = rg_first + blockIdx.x; ASYNC ? rg < rg_end : rg == rg_first + blockIdx.x; rg += ASYNC ? gridDim.x : 1u << 30) {
+	// How many workgroups walk the rowgroups (the persistent form only).  A column of ALP rowgroups wants ONE search workgroup per CU beside the
+	// encode (it takes one of the CU's three tile slots for two thirds of the encode's time); a column of ALP_RD rowgroups, whose search is a
+	// chain of dependent latencies the encode has to wait for anyway, wants all three (profiles/r04_encode_levers.txt, point 2: 3.02 / 4.58 ms with
+	// one, 3.27 / 4.28 ms with three).  The launch brings three per CU; every workgroup looks at the states of the column's head (searched in
+	// front of this kernel, on this stream: finished and visible) and those beyond `adaptive_base` leave unless ALP_RD is the majority there.
+	uint32_t walkers = gridDim.x;
+	if constexpr (ASYNC) {
+		if (adaptive_base != 0 && adaptive_base < gridDim.x) { // (kernel argument: uniform)
+			const bool     rd    = rgs[4 * lane].scheme == ALPGPU_SCHEME_ALP_RD; // 64 of the head's 256 rowgroups (api.hip: kAsyncHeadRowgroups)
+			const bool     heavy = __builtin_popcountll(ballot64(rd)) >= 32;
+			walkers              = heavy ? gridDim.x : adaptive_base;
+			if (blockIdx.x >= walkers) { return; }
+		}
+	}
+	for (uint64_t rg = rg_first + blockIdx.x; ASYNC ? rg < rg_end : rg == rg_first + blockIdx.x; rg += ASYNC ? walkers : 1u << 30) {
 	if (ASYNC) { __syncthreads(); } // the previous rowgroup's last readers of the shared arrays
 	int n_sv, n_smp, samples_size;
 	if constexpr (FROM_SAMPLES) {
@@ -675,31 +690,31 @@ int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vect
 	// (4-wavefront workgroups, six of them per CU instead of three of nine wavefronts, take exactly as long — 0.578 ms per 1 Mi vectors, 1.00 ms all-ALP_RD:
 	//  the search is bound by its arithmetic, not by its fixed latencies; profiles/r03_async_init.txt)
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, false, kMaxSampledVectors, false>), dim3(static_cast<unsigned>(rg_count)), dim3(kInitThreads), 0, stream, d_in,
-	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
+	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr), 0u);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 // The persistent, publishing form for rowgroups [rg_first, rg_first + rg_count): `grid` workgroups of kInitAsyncWaves wavefronts.
 template <class P>
 static int launch_rowgroup_init_async_t(hipStream_t stream, const typename P::value_t* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
-                                        uint64_t rg_first, uint64_t rg_count, int grid, bool tile_shaped) {
+                                        uint64_t rg_first, uint64_t rg_count, int grid, bool tile_shaped, uint32_t adaptive_base = 0) {
 	if (rg_count == 0) { return ALPGPU_OK; }
 	const uint64_t g = rg_count < static_cast<uint64_t>(grid) ? rg_count : static_cast<uint64_t>(grid);
 	if (g == rg_count) { // one workgroup per rowgroup (the head in front of the encode): the 9-wavefront shape, publishing
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kMaxSampledVectors, true>), dim3(static_cast<unsigned>(g)), dim3(kInitThreads), 0, stream, d_in, n_vectors, d_rgs, 0,
-		                   d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
+		                   d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr), 0u);
 	} else if (tile_shaped) {
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kInitAsyncTileWaves, true>), dim3(static_cast<unsigned>(g)), dim3(64 * kInitAsyncTileWaves), 0, stream, d_in, n_vectors,
-		                   d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
+		                   d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr), adaptive_base);
 	} else {
 		hipLaunchKernelGGL((k_rowgroup_init<P, false, kInitAsyncWaves, true>), dim3(static_cast<unsigned>(g)), dim3(64 * kInitAsyncWaves), 0, stream, d_in, n_vectors, d_rgs,
-		                   0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
+		                   0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr), adaptive_base);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
-                               uint64_t rg_count, int grid, bool tile_shaped) {
-	return launch_rowgroup_init_async_t<PrecF64>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, tile_shaped);
+                               uint64_t rg_count, int grid, bool tile_shaped, uint32_t adaptive_base) {
+	return launch_rowgroup_init_async_t<PrecF64>(stream, d_in, n_vectors, d_rgs, d_rd_order, rg_first, rg_count, grid, tile_shaped, adaptive_base);
 }
 int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                    uint64_t rg_count, int grid) {
@@ -709,7 +724,7 @@ int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64
 
 int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF64, true, kMaxSampledVectors, false>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples),
-	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull, d_cut_estimate);
+	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull, d_cut_estimate, 0u);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
@@ -720,13 +735,13 @@ int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_v
 	if (rg_first >= n_rg) { return ALPGPU_OK; }
 	if (rg_count == 0 || rg_first + rg_count > n_rg) { rg_count = n_rg - rg_first; }
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, false, kMaxSampledVectors, false>), dim3(static_cast<unsigned>(rg_count)), dim3(kInitThreads), 0, stream, d_in,
-	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr));
+	                   n_vectors, d_rgs, 0, d_rd_order, rg_first, rg_first + rg_count, static_cast<double*>(nullptr), 0u);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate) {
 	hipLaunchKernelGGL((k_rowgroup_init<PrecF32, true, kMaxSampledVectors, false>), dim3(1), dim3(kInitThreads), 0, stream, d_samples, static_cast<uint64_t>(n_samples),
-	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull, d_cut_estimate);
+	                   d_state, force_rd, static_cast<uint16_t*>(nullptr), 0ull, 1ull, d_cut_estimate, 0u);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

@@ -38,7 +38,8 @@ int launch_state_from_samples(hipStream_t stream, const double* d_samples, uint3
 // the persistent, publishing form (runs beside the single-pass encode on a second stream) and the tag clean-up behind it
 // tile_shaped: eight-wavefront workgroups that fit a lean encode tile's slot (init_kernels.hip), else four wavefronts beside two classic tiles
 int launch_rowgroup_init_async(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
-                               uint64_t rg_count, int grid, bool tile_shaped = false);
+                               uint64_t rg_count, int grid, bool tile_shaped = false, uint32_t adaptive_base = 0);
+// adaptive_base != 0: `grid` workgroups are launched, those beyond adaptive_base leave at once unless the column's head is mostly ALP_RD (init_kernels.hip)
 int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first,
                                    uint64_t rg_count, int grid);
 

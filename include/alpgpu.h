@@ -191,6 +191,10 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 #define ALPGPU_OPT_ENCODE_KERNEL 7
 #define ALPGPU_ENCODE_KERNEL_LEAN 0
 #define ALPGPU_ENCODE_KERNEL_CLASSIC 1
+/* ALPGPU_OPT_DECODE_PAIRING (experiment, double store decode only; 0 = off, the default): workgroups that own two consecutive vectors and choose how to
+ * run them from the two descriptors — 1: together when both are narrow, else one after the other; 2: as 1 with the second vector's loads issued in front
+ * of the first one's unpack; 3: three vectors per two workgroups.  Same output bytes as every other shape (tests/test_decode_gpu.py). */
+#define ALPGPU_OPT_DECODE_PAIRING 8
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */

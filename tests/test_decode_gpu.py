@@ -104,3 +104,25 @@ def test_tuning_options_do_not_change_results(ctx, oracle, vectors_per_wg, plain
     finally:
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
         ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, 0)
+
+
+@pytest.mark.parametrize("pairing", [1, 2, 3])
+def test_pairing_workgroups_write_the_same_bytes(ctx, oracle, pairing):
+    """ALPGPU_OPT_DECODE_PAIRING (k_decode_pairs: workgroups that own two vectors and decide from their descriptors how to run them): every
+    column class incl. odd vector counts, ALP_RD, exception-heavy and adversarial vectors decodes to the same bits as the default shape"""
+    from alp_amd import capi
+    try:
+        ctx.set_option(capi.OPT_DECODE_PAIRING, pairing)
+        for name in ("mixed_1pct", "mixed_30pct", "rd_latlon", "adversarial", "one_vector", "decimal2"):
+            if name not in COLUMNS:
+                continue
+            col = COLUMNS[name]()
+            for cut in (len(col), max(1024, (len(col) // 1024 - 1) * 1024), 3 * 1024, 4 * 1024, 5 * 1024):  # even, odd and short vector counts
+                part = col[: min(cut, len(col))]
+                if len(part) == 0:
+                    continue
+                enc = oracle.encode_column(part)
+                got = gpu_decode(ctx, enc)
+                assert np.array_equal(got.view(np.uint64), part.view(np.uint64)), (name, pairing, len(part))
+    finally:
+        ctx.set_option(capi.OPT_DECODE_PAIRING, 0)
