@@ -355,4 +355,17 @@ __device__ __forceinline__ U64Pair unpack_pair_u64(const Units& units, int bw, u
 	return r;
 }
 
+// A kernel argument read from the kernarg segment WHERE IT IS USED.  The compiler loads every argument a kernel names at its entry; arguments the
+// single-pass encode kernels need only behind their wait for the ordered offset (descriptor / stream pointers, capacities: ten scalar registers)
+// then live through the analysis and the pack, which run at the limit of the scalar register file — the allocator parked exactly these in VGPR
+// lanes at the entry and fetched them back with v_readlane at the end (vector instructions).  byte_offset: the parameters in order, naturally aligned.
+template <class T>
+__device__ __forceinline__ T late_kernel_arg(int byte_offset) {
+	typedef const __attribute__((address_space(4))) uint8_t* kernarg_t;
+	kernarg_t ka = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+	return *reinterpret_cast<const __attribute__((address_space(4))) T*>(ka + byte_offset);
+}
+// k_encode_lean and k_encode_fused_f32 begin with the same seven pointers and two capacities
+constexpr int kArgDescs = 16, kArgPacked = 24, kArgExcs = 32, kArgPackedCap = 56, kArgExcCap = 64;
+
 } // namespace alpgpu

@@ -34,7 +34,8 @@ struct alpgpu_ctx {
 	hipStream_t init_stream;     // ... on this stream (highest priority: its few workgroups are placed first)
 	hipEvent_t  ev_fork, ev_head, ev_join;
 	int         encode_kernel;   // ALPGPU_ENCODE_KERNEL_LEAN (default) / _CLASSIC
-	int         decode_pairing;  // ALPGPU_OPT_DECODE_PAIRING (experiment): 0 off, 1..3 -> k_decode_pairs
+	int         decode_pairing;  // ALPGPU_OPT_DECODE_PAIRING: 0 auto, 1..3 -> k_decode_pairs
+	int         decode_pairs_auto; // the auto rule may pick the pair kernel (ALPGPU_DECODE_PAIRS_AUTO=0 for A/B runs)
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -126,6 +127,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
 	ctx->pipelined_consumer = 0;
+	ctx->decode_pairs_auto = std::getenv("ALPGPU_DECODE_PAIRS_AUTO") ? std::atoi(std::getenv("ALPGPU_DECODE_PAIRS_AUTO")) : 1;
 	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
 	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
 	ctx->workspace       = nullptr;
@@ -463,7 +465,15 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const bool   four     = bits <= (with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits);
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
 	}
-	return (variant & 7) | (ctx->decode_pairing << 3);
+	// Narrow vectors WITH exceptions: the pair kernel (k_decode_pairs, both vectors' loads in flight together when both are narrow, one after the
+	// other otherwise) is 1-4 % ahead of k_decode_column<2> up to 18 bits (tools/sweep_pairing.py, profiles/r04_decode_floor.txt section 4); without
+	// exceptions it is not.  ALPGPU_OPT_DECODE_PAIRING overrides.
+	int pairing = ctx->decode_pairing;
+	if (ctx->decode_auto && pairing == 0 && ctx->decode_pairs_auto && col->packed_bytes_hint != 0) {
+		const double n = static_cast<double>(col->n_vectors);
+		if (static_cast<double>(col->exc_bytes_hint) >= 16.0 * n && static_cast<double>(col->packed_bytes_hint) <= 18.0 * 128.0 * n) { pairing = 1; }
+	}
+	return (variant & 7) | (pairing << 3);
 }
 
 // what alpgpu_decode_f64 / _f32 would launch for this column right now (option + size hints): vectors per decode workgroup
@@ -471,6 +481,7 @@ int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int 
 	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
 	if (is_f32) { return ctx->decode_vpw ? ctx->decode_vpw : 2; }
 	const int variant = decode_variant_for(ctx, col);
+	if ((variant >> 3) & 3) { return 2; } // (the pair kernel: two vectors per workgroup, run together or one after the other)
 	return (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
 }
 

@@ -36,6 +36,17 @@ struct FusedSharedF32 {
 };
 
 // one tile (kFusedWaves vectors, one per wavefront) of k_encode_fused_f32
+// Measurement builds (-DALPGPU_F32_STOP_AT=n, as ALPGPU_LEAN_STOP_AT in encode_lean_kernels.hip): every wavefront of the single pass ends behind
+// stage n with one dependent store; the column is garbage, the counters of successive builds difference into instructions per stage.
+#ifdef ALPGPU_F32_STOP_AT
+#define ALPGPU_F32_STOP(n, expr)                                                                    \
+	if (MODE == kSinglePass && ALPGPU_F32_STOP_AT == (n)) {                                         \
+		if (lane == 0) { arg_descs()[v_read].base = static_cast<int64_t>(expr); }                   \
+		return;                                                                                     \
+	}
+#else
+#define ALPGPU_F32_STOP(n, expr)
+#endif
 template <int MODE>
 __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_t tile, const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                 alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed, uint8_t* __restrict__ excs,
@@ -47,6 +58,18 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		if ((threadIdx.x & 63) == 0 && vo < v_first + n_vectors_launch) { descs[vo] = empty_descriptor(); }
 		return;
 	}
+	// single pass: the arguments needed only behind the wait come from the kernarg segment where they are used (alp_device.hpp: late_kernel_arg;
+	// -DALPGPU_F32_ARGS_AT_ENTRY: the old form).  The other two modes are not short of scalar registers.
+#ifdef ALPGPU_F32_ARGS_AT_ENTRY
+	constexpr bool kLate = false;
+#else
+	constexpr bool kLate = MODE == kSinglePass;
+#endif
+	auto arg_descs      = [&]() { if constexpr (kLate) { return late_kernel_arg<alpgpu_vector_desc*>(kArgDescs); } else { return descs; } };
+	auto arg_packed     = [&]() { if constexpr (kLate) { return late_kernel_arg<uint8_t*>(kArgPacked); } else { return packed; } };
+	auto arg_excs       = [&]() { if constexpr (kLate) { return late_kernel_arg<uint8_t*>(kArgExcs); } else { return excs; } };
+	auto arg_packed_cap = [&]() { if constexpr (kLate) { return late_kernel_arg<uint64_t>(kArgPackedCap); } else { return packed_capacity; } };
+	auto arg_exc_cap    = [&]() { if constexpr (kLate) { return late_kernel_arg<uint64_t>(kArgExcCap); } else { return exc_capacity; } };
 	EncodeLdsF32 (&lds)[kFusedWaves] = S.lds;
 	uint64_t (&s_size)[kFusedWaves]  = S.s_size;
 	uint64_t& s_excl                 = S.s_excl;
@@ -96,6 +119,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	// bytes used by earlier launches of this column: constant while this launch runs (k_fused_finish updates them), read now so
 	// that nothing but the ordered offset stands between the wait and the stores
 	const uint64_t base_p = totals[0], base_e = totals[1];
+	ALPGPU_F32_STOP(1, __float_as_uint(x.x[0][0] + x.x[3][3]) + st.k);
 	if (live) {
 		d.scheme = rgp->scheme;
 		if (rgp->scheme == ALPGPU_SCHEME_ALP) {
@@ -106,8 +130,10 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 				e = rgp->combos[0];
 				f = rgp->combos[1];
 			}
+			ALPGPU_F32_STOP(2, e * 32 + f);
 			AlpEncodedF R;
 			encode_alp_registers_f32(x, e, f, lane, R);
+			ALPGPU_F32_STOP(3, R.base + R.bw + R.cnt + static_cast<int64_t>(R.ballot[0][0] ^ R.ballot[3][3] ^ R.ballot[1][2] ^ R.ballot[2][1]) + R.enc[0][0] + R.enc[3][3] + R.enc[1][1] + R.enc[2][2]);
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
 			cnt = R.cnt;
 			const uint32_t base = static_cast<uint32_t>(R.base);
@@ -169,6 +195,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		}
 		d.exc_cnt = static_cast<uint16_t>(cnt);
 	}
+	ALPGPU_F32_STOP(4, d.base + d.bw + cnt + pvals[0][0] + pvals[3][3] + pvals[1][2] + pvals[2][1] + static_cast<int64_t>(ballots[0][0] ^ ballots[3][3] ^ ballots[1][1]));
 	uint64_t my_p = 0, my_e = 0;
 	if (live) { record_sizes<4>(d, my_p, my_e); }
 	if (MODE == kAnalyze) { // the sizes are all the scan needs
@@ -190,7 +217,9 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	// input itself is live across the wait.  The exception record is laid out behind the image's 128 * bw bytes when it fits what is left of the
 	// 4 KiB, and leaves as contiguous stores after the wait; else (a wide vector with many exceptions) it is written from the registers then.
 	// Pad bytes are zero.
+	ALPGPU_F32_STOP(5, base_p + base_e + my_p + my_e + pvals[0][0] + pvals[3][3]);
 	pack_u32_scatter_image(reinterpret_cast<uint32_t*>(L.vals), pvals, d.bw, lane);
+	ALPGPU_F32_STOP(6, reinterpret_cast<uint32_t*>(L.vals)[lane] + base_p + static_cast<int64_t>(ballots[0][0] ^ ballots[3][3]));
 	const bool     alp_rec    = d.scheme == ALPGPU_SCHEME_ALP;
 	const uint32_t val_bytes  = alp_rec ? 4u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
 	const uint32_t rec_off    = 128u * d.bw;
@@ -211,6 +240,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		});
 		wave_lds_sync();
 	}
+	ALPGPU_F32_STOP(7, reinterpret_cast<uint32_t*>(L.vals)[lane] + reinterpret_cast<uint32_t*>(L.vals)[960 + lane] + base_p);
 	if (MODE == kSinglePass) {
 		// wavefront 0 finds the tile's offset; the others park at a workgroup barrier meanwhile (see k_encode_lean: a worker that spins on an LDS
 		// word takes issue slots from the wavefronts that still compute)
@@ -228,16 +258,17 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		d.packed_off       = descs[v].packed_off + status[2 * st_];
 		d.exc_off          = descs[v].exc_off + status[2 * st_ + 1];
 	}
+	ALPGPU_F32_STOP(8, d.packed_off + d.exc_off + reinterpret_cast<uint32_t*>(L.vals)[lane]);
 	if (!live) { return; }
-	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) { // see k_encode_fused
+	if (d.packed_off + my_p > arg_packed_cap() || d.exc_off + my_e > arg_exc_cap()) { // see k_encode_fused
 		if (lane == 0) {
 			__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			descs[v] = empty_descriptor();
+			arg_descs()[v] = empty_descriptor();
 		}
 		return;
 	}
-	uint8_t* dst = packed + d.packed_off;
-	uint8_t* rec = excs + d.exc_off;
+	uint8_t* dst = arg_packed() + d.packed_off;
+	uint8_t* rec = arg_excs() + d.exc_off;
 	if (cnt > 0) {
 		if (rec_staged) {
 			const uint64_t* img64 = reinterpret_cast<const uint64_t*>(img);
@@ -270,7 +301,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 			out64[16 * k + lane] = w;
 		}
 	}
-	if (lane == 0) { descs[v] = d; }
+	if (lane == 0) { arg_descs()[v] = d; }
 }
 
 // kSinglePass: `status` = look-back words, one workgroup per tile.  kAnalyze / kPack: `status` = the scan's tile bases ([tile][2], kPack only),

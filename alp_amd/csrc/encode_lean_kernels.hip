@@ -30,6 +30,18 @@ namespace alpgpu {
 #define ALPGPU_LEAN_OCC 6 // __launch_bounds__ second argument (wavefronts per SIMD the register budget must admit): 6 -> <= 80 VGPRs (what three 48 KiB tiles per CU need), 7 -> <= 72, 8 -> <= 64
 #endif
 
+// Measurement builds (-DALPGPU_LEAN_STOP_AT=n): every wavefront ends behind stage n with ONE store that depends on what the stage produced, so the
+// counters of successive builds (tools/pmc_busy.sh) difference into instructions per stage.  The column such a build writes is garbage.
+#ifdef ALPGPU_LEAN_STOP_AT
+#define ALPGPU_LEAN_STOP(n, expr)                                             \
+	if (ALPGPU_LEAN_STOP_AT == (n)) {                                         \
+		if (lane == 0) { LEAN_ARG_DESCS[v_read].base = static_cast<int64_t>(expr); }   \
+		return;                                                               \
+	}
+#else
+#define ALPGPU_LEAN_STOP(n, expr)
+#endif
+
 constexpr int kLeanImageWords = 32;                    // stream words per column pair that fit the image
 constexpr int kLeanImageBytes = 128 * kLeanImageWords; // 4 KiB
 constexpr int kLeanBufBytes   = 6144;                  // image + exception record, per wavefront
@@ -126,6 +138,11 @@ __device__ __forceinline__ void lean_analyze_alp(const VecIn& in, int e, int f, 
 			}
 		}
 	}
+#if defined(ALPGPU_LEAN_STOP_AT) && ALPGPU_LEAN_STOP_AT == 3
+	R.base = __double_as_longlong(rmin) ^ __double_as_longlong(rmax) ^ static_cast<int64_t>(R.ballot[0][0] ^ R.ballot[7][1] ^ R.ballot[3][0] ^ R.ballot[5][1]);
+	R.filler = 0, R.bw = R.cnt;
+	return;
+#endif
 	// filler = encoded value at the first non-exception position p (encoder.hpp:382-388); 0 when there is none or when p == 1023
 	int64_t      filler  = 0;
 	bool         found   = false;
@@ -323,12 +340,32 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 	}
 }
 
+// The five arguments needed only behind the wait are read from the kernarg segment where they are used (alp_device.hpp: late_kernel_arg):
+// v_writelane 46 -> 24 and 1034 -> 981 vector instructions per vector (-DALPGPU_LEAN_ARGS_AT_ENTRY: the old form).
+#ifndef ALPGPU_LEAN_ARGS_AT_ENTRY
+#define ALPGPU_LEAN_LATE_ARGS 1
+#endif
+
 __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_lean(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                                                    alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
-                                                                                    uint8_t* __restrict__ excs, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
-                                                                                    uint64_t packed_capacity, uint64_t exc_capacity, uint64_t v_first, uint64_t n_vectors_launch,
+                                                                                    alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
+                                                                                    uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
+                                                                                    uint64_t packed_capacity_entry, uint64_t exc_capacity_entry, uint64_t v_first, uint64_t n_vectors_launch,
                                                                                     const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states) {
 	__builtin_amdgcn_s_setprio(ALPGPU_ENC_PRIO);
+#ifdef ALPGPU_LEAN_LATE_ARGS
+	(void)descs_entry, (void)packed_entry, (void)excs_entry, (void)packed_capacity_entry, (void)exc_capacity_entry;
+#define LEAN_ARG_DESCS late_kernel_arg<alpgpu_vector_desc*>(kArgDescs)
+#define LEAN_ARG_PACKED late_kernel_arg<uint8_t*>(kArgPacked)
+#define LEAN_ARG_EXCS late_kernel_arg<uint8_t*>(kArgExcs)
+#define LEAN_ARG_PACKED_CAP late_kernel_arg<uint64_t>(kArgPackedCap)
+#define LEAN_ARG_EXC_CAP late_kernel_arg<uint64_t>(kArgExcCap)
+#else
+#define LEAN_ARG_DESCS descs_entry
+#define LEAN_ARG_PACKED packed_entry
+#define LEAN_ARG_EXCS excs_entry
+#define LEAN_ARG_PACKED_CAP packed_capacity_entry
+#define LEAN_ARG_EXC_CAP exc_capacity_entry
+#endif
 	__shared__ LeanLds  lds[kFusedWaves];
 	__shared__ uint64_t s_size[kFusedWaves];
 	__shared__ uint64_t s_excl;
@@ -354,10 +391,23 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	// The input is read once and the packed words are written once: both non-temporal (round 4: 3.02 -> 2.91 ms per 1 Mi vectors on the mixed
 	// column with both, 2.95 with the stores alone) — except the input of wavefront 0, which reads its vector a second time when it is wider
 	// than the image (every ALP_RD vector) and should find it in the L2 / Infinity Cache then (all loads non-temporal: ALP_RD column 4.28 -> 4.41 ms).
+#ifdef ALPGPU_LEAN_PREFETCH_TILES
+	// Experiment: one 4-byte read per 128-byte line of the vector a wavefront ALPGPU_LEAN_PREFETCH_TILES tiles further on will load (about one
+	// wavefront's life later): the line is then in the memory-side cache, a shorter trip than HBM under load.  Issued in front of this
+	// wavefront's own loads and "used" right behind them, so that its register lives through the load phase only.
+	uint32_t pf_word = 0;
+	{
+		const uint64_t vp = vl + static_cast<uint64_t>(ALPGPU_LEAN_PREFETCH_TILES) * kFusedWaves;
+		if (vp < n_vectors_launch) { pf_word = *reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const uint8_t*>(in + (v_first + vp) * kVec) + 128 * lane); }
+	}
+#endif
 #ifdef ALPGPU_LEAN_PLAIN_LOADS
 	const VecIn                  x        = load_vector(in, v_read, lane);
 #else
 	const VecIn                  x        = load_vector_policy(in, v_read, lane, wave != 0);
+#endif
+#ifdef ALPGPU_LEAN_PREFETCH_TILES
+	asm volatile("" ::"v"(pf_word));
 #endif
 	bool                         state_ok = true;
 	const alpgpu_rowgroup_state  st       = async_states ? rowgroup_state_poll_finish(rgp, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
@@ -365,6 +415,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		if (lane == 0) { status_store(totals + 3, 1ull); }
 		return;
 	}
+	ALPGPU_LEAN_STOP(1, __double_as_longlong(x.x[0].x + x.x[7].y) + st.k);
 	alpgpu_vector_desc d;
 	d.packed_off = d.exc_off = 0;
 	d.base                   = 0;
@@ -393,8 +444,10 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 				e = st.combos[0];
 				f = st.combos[1];
 			}
+			ALPGPU_LEAN_STOP(2, e * 32 + f);
 			LeanAlp R;
 			lean_analyze_alp(x, e, f, lane, R);
+			ALPGPU_LEAN_STOP(3, R.base + R.bw);
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
 			cnt             = R.cnt;
 			wide_steps      = R.wide_steps;
@@ -417,6 +470,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		}
 		d.exc_cnt = static_cast<uint16_t>(cnt);
 	}
+	ALPGPU_LEAN_STOP(4, d.base + d.bw + cnt + static_cast<int64_t>(fill_minus_base ^ ballots[0][0] ^ ballots[7][1] ^ ballots[2][1] ^ ballots[5][0]) + wide_steps);
 	uint64_t my_p = 0, my_e = 0; // bytes
 	if (live) { record_sizes<8>(d, my_p, my_e); }
 	if (lane == 0) {
@@ -431,6 +485,12 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	}
 	const uint64_t base_p = totals[0], base_e = totals[1];
 
+	ALPGPU_LEAN_STOP(5, base_p + base_e + my_p + my_e);
+	LookbackFirst look_first {0, 0};
+	(void)look_first;
+#ifdef ALPGPU_LEAN_LOOK_AHEAD_EARLY // experiment: in front of the pack already (the predecessors are mostly not there yet)
+	if (wave == 0) { look_first = tile_lookback_begin(tile, status, lane); }
+#endif
 	// ---- pack (first window) and exception record: both into LDS, neither depends on where it will be stored ----
 	const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
 	const int  bw  = d.bw;
@@ -452,6 +512,13 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	} else {
 		lean_pack_rd(buf, x, bw, 0, words_a, lane);
 	}
+#endif
+	ALPGPU_LEAN_STOP(6, buf[lane] + base_p);
+	// Experiment (-DALPGPU_LEAN_LOOK_AHEAD): wavefront 0 asks for the status words of its look-back HERE, the exception record's stage below being
+	// about one trip across the fabric long.  Measured: 3.04-3.09 ms against 2.90-2.95 without (mixed column) — the predecessors are in the same
+	// stage at the same time, the early words are mostly not there yet and the round is simply spent twice.
+#if defined(ALPGPU_LEAN_LOOK_AHEAD) && !defined(ALPGPU_LEAN_LOOK_AHEAD_EARLY)
+	if (wave == 0) { look_first = tile_lookback_begin(tile, status, lane); }
 #endif
 	// exception record: cnt x value (8 B original bits, or the 2 B left part of an ALP_RD exception), then cnt x u16 position, pad zero; staged
 	// behind the image when it fits there, else written from the registers after the wait
@@ -478,6 +545,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		wave_lds_sync();
 	}
 
+	ALPGPU_LEAN_STOP(7, buf[lane] + buf[600 + lane] + base_p);
 	// ---- the ordered offset ----
 	// Wavefront 0 finds the tile's offset; the others have nothing left to do but their stores, so they PARK at a workgroup barrier until it
 	// arrives there too (k_encode_fused keeps its workers spinning on an LDS word: they used to pack meanwhile; here a spinning worker would
@@ -493,7 +561,11 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		}
 	}
 #else
+#if defined(ALPGPU_LEAN_LOOK_AHEAD) || defined(ALPGPU_LEAN_LOOK_AHEAD_EARLY)
+	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit, &look_first); }
+#else
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
+#endif
 	__syncthreads();
 #endif
 	// sizes posted by the tile's earlier wavefronts: lane w < wave takes s_size[w], one DPP tree (both 31-bit fields stay apart: no carry between them)
@@ -505,15 +577,16 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
 	d.exc_off          = base_e + (pre & 0x7FFFFFFFull) * 8ull;
 	if (!live) { return; }
-	if (d.packed_off + my_p > packed_capacity || d.exc_off + my_e > exc_capacity) {
+	if (d.packed_off + my_p > LEAN_ARG_PACKED_CAP || d.exc_off + my_e > LEAN_ARG_EXC_CAP) {
 		if (lane == 0) {
 			__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			descs[v] = empty_descriptor();
+			LEAN_ARG_DESCS[v] = empty_descriptor();
 		}
 		return;
 	}
-	uint8_t* dst = packed + d.packed_off;
-	uint8_t* rec = excs + d.exc_off;
+	ALPGPU_LEAN_STOP(8, d.packed_off + d.exc_off + buf[lane]);
+	uint8_t* dst = LEAN_ARG_PACKED + d.packed_off;
+	uint8_t* rec = LEAN_ARG_EXCS + d.exc_off;
 
 	// ---- stores at the final offsets ----
 	if (cnt > 0) {
@@ -565,7 +638,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 			out32[32 * k + lane] = (static_cast<uint32_t>(acc0 >> (16 * k)) & 0xFFFFu) | ((static_cast<uint32_t>(acc1 >> (16 * k)) & 0xFFFFu) << 16);
 		}
 	}
-	if (lane == 0) { descs[v] = d; }
+	if (lane == 0) { LEAN_ARG_DESCS[v] = d; }
 }
 
 // the same launch sequence as launch_encode_fused_range (encode_kernels.hip) with the kernel above

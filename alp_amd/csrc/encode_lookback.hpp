@@ -78,9 +78,25 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 // N_SIZES = vectors per tile (entries of s_size); s_count counts the tile's kFusedWaves wavefronts.
 // spin_limit: unsuccessful polls before the tile gives up (kSpinLimit; 0 makes every tile that has to wait give up at once —
 // the debug option that exercises the recovery route).
+// The first round of both levels, issued ahead of time (k_encode_lean: in front of the exception record's stage, whose work then covers the
+// trip across the fabric): the words a tile_lookback would begin with.  Words that are not there yet are simply polled again by tile_lookback.
+struct LookbackFirst {
+	uint64_t w1, w2;
+};
+__device__ __forceinline__ LookbackFirst tile_lookback_begin(uint64_t tile, const uint64_t* __restrict__ status, int lane) {
+	const uint64_t* bstatus = status + gridDim.x;
+	const uint64_t  block   = tile / kBlockTiles;
+	const int       i       = static_cast<int>(tile % kBlockTiles);
+	LookbackFirst   f;
+	f.w1 = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
+	f.w2 = (block != 0 && static_cast<int64_t>(block) - 1 - lane >= 0) ? status_load(bstatus + (block - 1 - lane)) : kFlagPrefix;
+	return f;
+}
+
 template <int N_SIZES = kFusedWaves>
 __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
-                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane, uint32_t spin_limit = kSpinLimit) {
+                                              uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane, uint32_t spin_limit = kSpinLimit,
+                                              const LookbackFirst* begun = nullptr) {
 	uint64_t*      bstatus = status + gridDim.x;
 	const uint64_t block   = tile / kBlockTiles;
 	const int      i       = static_cast<int>(tile % kBlockTiles);
@@ -100,8 +116,13 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	// level 1: the sizes of the i predecessors inside this block
 	uint64_t local = 0;
 	// both levels' first rounds are issued together: one trip across the fabric instead of two when nothing is late
-	uint64_t first1 = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
-	uint64_t first2 = (block != 0 && static_cast<int64_t>(block) - 1 - lane >= 0) ? status_load(bstatus + (block - 1 - lane)) : kFlagPrefix;
+	uint64_t first1, first2;
+	if (begun != nullptr) { // (a compile-time fact at every call site)
+		first1 = begun->w1, first2 = begun->w2;
+	} else {
+		first1 = lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate;
+		first2 = (block != 0 && static_cast<int64_t>(block) - 1 - lane >= 0) ? status_load(bstatus + (block - 1 - lane)) : kFlagPrefix;
+	}
 	bool     fresh1 = true, fresh2 = true;
 	if (i != 0) {
 		for (;;) {

@@ -18,6 +18,9 @@ else:
     x = synthetic_input(kind, n, dev, seed=42)
 col = capi.DeviceColumn(n, 0)
 med, mean = time_launches(lambda: ctx.encode(x, col), 5, 2)
+if os.environ.get("ALPGPU_PROF_ENCODE_ONLY"):  # measurement builds that write garbage columns (-DALPGPU_LEAN_STOP_AT): nothing may read what they wrote
+    print(f"{kind}: n={n} encode median {med:.3f} ms (encode only)")
+    sys.exit(0)
 pb, eb, ov = ctx.column_totals(col)
 print(f"{kind}: n={n} encode median {med:.3f} ms -> {n*8192/med/1e6:.1f} GB/s in; packed {pb/n:.0f} B/vec exc {eb/n:.0f} B/vec overflow {ov}")
 # ... and the decode of what was just encoded (the ALP_RD column's decode has no other row in the round's profile)
