@@ -72,6 +72,23 @@ def test_search_beside_the_encode_writes_the_same_column(ctx, dtype, async_mode)
     same_column(front, encode_with(ctx, x, dtype, async_mode, force_stall=True))
 
 
+def test_search_beside_the_encode_of_a_mostly_alp_rd_column(ctx):
+    """a column whose head is mostly ALP_RD: the persistent search keeps all three of its workgroups per CU (k_rowgroup_init: `walkers`) and walks
+    the rowgroups with the larger stride; same column as with the search in front, three times over, and through the recovery route"""
+    pieces = [datagen.rd_column(1200, seed=11), datagen.mixed_column(300, seed=12, exc_rate=0.02), datagen.rd_column(1300, seed=13, kind="latlon"), datagen.drifting_column(200, seed=14)]
+    dev = torch.from_numpy(np.concatenate(pieces)).cuda()
+    reps = (N_VECTORS * 1024 + dev.numel() - 1) // dev.numel()
+    x = dev.repeat(reps)[: N_VECTORS * 1024].contiguous()
+    front = encode_with(ctx, x, "f64", 0)
+    rg = front[0].rowgroups.cpu().numpy().view(capi.ROWGROUP_DTYPE)[: (N_VECTORS + 99) // 100]
+    assert (rg["scheme"][:256] != capi.SCHEME_ALP).mean() > 0.5 and (rg["scheme"] == capi.SCHEME_ALP).any()
+    for rep in range(3):
+        same_column(front, encode_with(ctx, x, "f64", 1))
+    same_column(front, encode_with(ctx, x, "f64", 1, force_stall=True))
+    out = ctx.decode(front[0])
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+
+
 def test_search_beside_the_encode_agrees_with_the_oracle(ctx, oracle):
     x, _ = long_column("f64")
     col, pb, eb = encode_with(ctx, x, "f64", 1)
