@@ -310,6 +310,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 // vectors just to find the gate closed (profiles/r03_float_encode.txt).
 // (the single pass is held to 96 VGPRs — __launch_bounds__' second argument, wavefronts per SIMD: four of them per SIMD then leave the 96
 // registers the persistent rowgroup search needs to share the CU)
+// (the first nine parameters are read by offset in the single pass — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
 template <int MODE>
 __global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_ENC_OCC : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,

@@ -346,6 +346,7 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 #define ALPGPU_LEAN_LATE_ARGS 1
 #endif
 
+// (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
 __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_lean(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                                     alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
                                                                                     uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
