@@ -473,7 +473,20 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const double n = static_cast<double>(col->n_vectors);
 		if (static_cast<double>(col->exc_bytes_hint) >= 16.0 * n && static_cast<double>(col->packed_bytes_hint) <= 18.0 * 128.0 * n) { pairing = 1; }
 	}
-	return (variant & 7) | (pairing << 3);
+	// Residency of the one-vector-per-workgroup shape by width (decode_kernels.hip: launch_decode_column): eight workgroups per CU up to 33 bits,
+	// seven up to 38, six beyond; seven for ALP_RD columns.  ALPGPU_DECODE_PAD_LDS_KIB overrides (A/B runs; 0 = never cap).
+	static const int pad_env = std::getenv("ALPGPU_DECODE_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_PAD_LDS_KIB")) & 0xFF : -1;
+	int pad_kib = pad_env >= 0 ? pad_env : 0;
+	if (pad_env < 0 && ctx->decode_auto && (variant & 5) == 1 && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
+		const double n        = static_cast<double>(col->n_vectors);
+		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
+		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n;
+		const bool   mostly_rd = col->alp_rd_rowgroups_hint != 0 && 2.0 * static_cast<double>(col->alp_rd_rowgroups_hint - 1) * 100.0 > n;
+		// (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on; with ~2 % exceptions the cap pays from ~42 bits on only;
+		//  ALP_RD columns — more arithmetic per value — sit between: seven)
+		pad_kib = mostly_rd ? 11 : (with_exc ? (bits >= 41.5 ? 14 : 0) : (bits >= 38.5 ? 14 : (bits >= 33.5 ? 11 : 0)));
+	}
+	return (variant & 7) | (pairing << 3) | (pad_kib << 8);
 }
 
 // what alpgpu_decode_f64 / _f32 would launch for this column right now (option + size hints): vectors per decode workgroup

@@ -14,6 +14,7 @@
 // per CU at the level of the double-precision kernel (V = 2 moves as many bytes per workgroup as one double vector).
 #include "alp_device_f32.hpp"
 #include "launch.hpp"
+#include <cstdlib>
 
 namespace alpgpu {
 
@@ -351,12 +352,14 @@ static void launch_v(hipStream_t stream, const alpgpu_column* col, float* d_out,
 	const uint64_t n        = col->n_vectors;
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30;
+	// experiment (ALPGPU_DECODE_F32_PAD_LDS_KIB): unused dynamic LDS that caps the workgroups resident per CU, as the double decode does for wide columns
+	static const unsigned pad_lds = std::getenv("ALPGPU_DECODE_F32_PAD_LDS_KIB") ? static_cast<unsigned>(std::atoi(std::getenv("ALPGPU_DECODE_F32_PAD_LDS_KIB"))) * 1024u : 0u;
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
 		if (nt) {
-			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
+			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
 		} else {
-			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
+			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
 		}
 	}
 }

@@ -826,6 +826,11 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 		return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 	}
 	const int      V        = (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
+	// Unused dynamic LDS that caps the workgroups resident per CU (one vector per workgroup only; variant bits 8.. = KiB).  Wide vectors want FEWER
+	// streams in flight per CU than the eight the wavefront slots allow: a column of 40-53-bit vectors decodes at 0.81 of the HBM peak with six
+	// workgroups per CU and at 0.75 with eight, 34-38 bits like seven; up to 33 bits eight are best (tools/sweep_residency.py,
+	// profiles/r04_decode_floor.txt section 6).  decode_variant_for (api.hip) sets it from the column's size hints.
+	const unsigned pad_lds  = static_cast<unsigned>((variant >> 8) & 0xFF) * 1024u;
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
@@ -839,9 +844,9 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 		} else if (V == 2) {
 			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (nt) {
-			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
