@@ -461,7 +461,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		// kNarrowAutoBits bits FOUR vectors share a workgroup over the narrow stage (round 4).
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * (n > 0 ? n : 1.0));
-		const bool   narrow   = bits <= (with_exc ? 20.0 : 16.0);
+		const bool   narrow   = bits <= (with_exc ? 20.0 : 17.5); // (17.5: with the residency caps below two vectors per workgroup win through 17 bits)
 		const bool   four     = bits <= (with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits);
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
 	}
@@ -473,18 +473,26 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const double n = static_cast<double>(col->n_vectors);
 		if (static_cast<double>(col->exc_bytes_hint) >= 16.0 * n && static_cast<double>(col->packed_bytes_hint) <= 18.0 * 128.0 * n) { pairing = 1; }
 	}
-	// Residency of the one-vector-per-workgroup shape by width (decode_kernels.hip: launch_decode_column): eight workgroups per CU up to 33 bits,
-	// seven up to 38, six beyond; seven for ALP_RD columns.  ALPGPU_DECODE_PAD_LDS_KIB overrides (A/B runs; 0 = never cap).
+	// Residency by width (decode_kernels.hip: launch_decode_column; unused dynamic LDS): what a CU wants is a certain amount of bytes in flight, not a
+	// certain number of workgroups.  One vector per workgroup: eight workgroups per CU up to 33 bits, seven up to 38, six beyond; seven for ALP_RD
+	// columns.  Two vectors per workgroup: eight / seven / six workgroups by width.  ALPGPU_DECODE_PAD_LDS_KIB overrides (A/B runs; 0 = never cap).
 	static const int pad_env = std::getenv("ALPGPU_DECODE_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_PAD_LDS_KIB")) & 0xFF : -1;
 	int pad_kib = pad_env >= 0 ? pad_env : 0;
-	if (pad_env < 0 && ctx->decode_auto && (variant & 5) == 1 && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
+	if (pad_env < 0 && ctx->decode_auto && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
 		const double n        = static_cast<double>(col->n_vectors);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n;
 		const bool   mostly_rd = col->alp_rd_rowgroups_hint != 0 && 2.0 * static_cast<double>(col->alp_rd_rowgroups_hint - 1) * 100.0 > n;
-		// (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on; with ~2 % exceptions the cap pays from ~42 bits on only;
-		//  ALP_RD columns — more arithmetic per value — sit between: seven)
-		pad_kib = mostly_rd ? 11 : (with_exc ? (bits >= 41.5 ? 14 : 0) : (bits >= 38.5 ? 14 : (bits >= 33.5 ? 11 : 0)));
+		if ((variant & 5) == 1) {
+			// one vector per workgroup (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on; with ~2 % exceptions the
+			// cap pays from ~42 bits on only; ALP_RD columns — more arithmetic per value — sit between: seven)
+			pad_kib = mostly_rd ? 11 : (with_exc ? (bits >= 41.5 ? 14 : 0) : (bits >= 38.5 ? 14 : (bits >= 33.5 ? 11 : 0)));
+		} else if ((variant & 5) == 0 && !with_exc) {
+			// two vectors per workgroup, no exceptions (tools/sweep_residency.py with SWEEP_VPW=2): sixteen vectors in flight per CU up to 8 bits,
+			// fourteen (seven workgroups) for 9-11, twelve (six) for 12-17: 0.69-0.72 -> 0.75-0.78 of the HBM peak on 10-17 bits.  With exceptions the
+			// caps lose.
+			pad_kib = bits > 11.5 ? 6 : (bits > 8.5 ? 3 : 0);
+		}
 	}
 	return (variant & 7) | (pairing << 3) | (pad_kib << 8);
 }

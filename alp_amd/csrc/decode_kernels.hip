@@ -813,11 +813,12 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	const bool     nt       = !(variant & 2);
 	const int      pairing  = (variant >> 3) & 3; // experiment: k_decode_pairs
 	if (pairing != 0) {
+		const unsigned pad_lds_p = static_cast<unsigned>((variant >> 8) & 0xFF) * 1024u; // residency cap, as below
 		const uint64_t n_wg_p   = pairing == 3 ? 2 * ((n + 2) / 3) : (n + 1) / 2;
 		const uint64_t kMaxGridP = 1ull << 30;
 		for (uint64_t off = 0; off < n_wg_p; off += kMaxGridP) {
 			const dim3 grid(static_cast<unsigned>(n_wg_p - off < kMaxGridP ? n_wg_p - off : kMaxGridP)), block(64 * kDecWaves);
-#define ALPGPU_LAUNCH_PAIRS(NT, P) hipLaunchKernelGGL((k_decode_pairs<NT, P>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off)
+#define ALPGPU_LAUNCH_PAIRS(NT, P) hipLaunchKernelGGL((k_decode_pairs<NT, P>), grid, block, pad_lds_p, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off)
 			if (pairing == 1) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 1); } else { ALPGPU_LAUNCH_PAIRS(false, 1); } }
 			if (pairing == 2) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 2); } else { ALPGPU_LAUNCH_PAIRS(false, 2); } }
 			if (pairing == 3) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 3); } else { ALPGPU_LAUNCH_PAIRS(false, 3); } }
@@ -826,7 +827,7 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 		return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 	}
 	const int      V        = (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
-	// Unused dynamic LDS that caps the workgroups resident per CU (one vector per workgroup only; variant bits 8.. = KiB).  Wide vectors want FEWER
+	// Unused dynamic LDS that caps the workgroups resident per CU (variant bits 8.. = KiB).  Wide vectors want FEWER
 	// streams in flight per CU than the eight the wavefront slots allow: a column of 40-53-bit vectors decodes at 0.81 of the HBM peak with six
 	// workgroups per CU and at 0.75 with eight, 34-38 bits like seven; up to 33 bits eight are best (tools/sweep_residency.py,
 	// profiles/r04_decode_floor.txt section 6).  decode_variant_for (api.hip) sets it from the column's size hints.
@@ -836,13 +837,13 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 4 && nt) {
-			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (V == 4) {
-			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (V == 2 && nt) {
-			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else if (nt) {
 			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
 		} else {

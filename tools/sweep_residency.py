@@ -15,8 +15,9 @@ pad = os.environ.get("ALPGPU_DECODE_PAD_LDS_KIB", "0")
 row = []
 widths = [None if w == "mix" else int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [None, 18, 24, 32, 36, 40, 44, 48, 53]
 for bw in widths:
-    c, _, ab = bench.build_decode_column(n, 0, seed=7, bw_of_rowgroup=bw, exc_per_vec=0)
-    ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 1)
+    c, _, ab = bench.build_decode_column(n, 0, seed=7, bw_of_rowgroup=bw, exc_per_vec=int(os.environ.get("SWEEP_EXC", "0")))
+    ctx.set_option(capi.OPT_DECODE_PAIRING, int(os.environ.get("SWEEP_PAIRING", "0")))
+    ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, int(os.environ.get("SWEEP_VPW", "1")))
     best = 0.0
     for rnd in range(2):
         med, _ = bench.time_launches(lambda: ctx.decode(c, out), 7, 6)
