@@ -474,7 +474,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		if (static_cast<double>(col->exc_bytes_hint) >= 16.0 * n && static_cast<double>(col->packed_bytes_hint) <= 18.0 * 128.0 * n) { pairing = 1; }
 	}
 	// Residency by width (decode_kernels.hip: launch_decode_column; unused dynamic LDS): what a CU wants is a certain amount of bytes in flight, not a
-	// certain number of workgroups.  One vector per workgroup: eight workgroups per CU up to 33 bits, seven up to 38, six beyond; seven for ALP_RD
+	// certain number of workgroups.  One vector per workgroup: eight workgroups per CU up to 33 bits, seven up to 35, six beyond; seven for ALP_RD
 	// columns.  Two vectors per workgroup: eight / seven / six workgroups by width.  ALPGPU_DECODE_PAD_LDS_KIB overrides (A/B runs; 0 = never cap).
 	static const int pad_env = std::getenv("ALPGPU_DECODE_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_PAD_LDS_KIB")) & 0xFF : -1;
 	int pad_kib = pad_env >= 0 ? pad_env : 0;
@@ -484,9 +484,9 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n;
 		const bool   mostly_rd = col->alp_rd_rowgroups_hint != 0 && 2.0 * static_cast<double>(col->alp_rd_rowgroups_hint - 1) * 100.0 > n;
 		if ((variant & 5) == 1) {
-			// one vector per workgroup (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on; with ~2 % exceptions the
+			// one vector per workgroup (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on — seven at 34-35, six beyond; with ~2 % exceptions the
 			// cap pays from ~42 bits on only; ALP_RD columns — more arithmetic per value — sit between: seven)
-			pad_kib = mostly_rd ? 11 : (with_exc ? (bits >= 41.5 ? 14 : 0) : (bits >= 38.5 ? 14 : (bits >= 33.5 ? 11 : 0)));
+			pad_kib = mostly_rd ? 11 : (with_exc ? (bits >= 41.5 ? 14 : 0) : (bits >= 35.5 ? 14 : (bits >= 33.5 ? 11 : 0)));
 		} else if ((variant & 5) == 0 && !with_exc) {
 			// two vectors per workgroup, no exceptions (tools/sweep_residency.py with SWEEP_VPW=2): sixteen vectors in flight per CU up to 8 bits,
 			// fourteen (seven workgroups) for 9-11, twelve (six) for 12-17: 0.69-0.72 -> 0.75-0.78 of the HBM peak on 10-17 bits.  With exceptions the
