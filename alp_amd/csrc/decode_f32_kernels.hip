@@ -432,11 +432,17 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	// Round 4: a narrow ALP vector's words whole into the wavefront's LDS by LDS-DMA (1 KiB per instruction, no registers): ONE round trip for all
 	// of them instead of eight 16-byte buffer loads per lane — what took the double sink from 0.85 to 0.73 ms (profiles/r03_consumers.txt) and what
 	// the float one never had ("is the stage arm even taken for float?" — there was none).
-	const bool staged = is_alp && 128u * d.bw <= static_cast<uint32_t>(ALPGPU_SINK_STAGE_F32) && cnt <= ALPGPU_SINK_STAGE_F32_MAX_EXC; // wave-uniform
+	// (late round 4: ALP_RD vectors too — right words, then left words, as they lie in the stream; -DALPGPU_SINK_STAGE_F32_ALP_ONLY: the first form)
+#ifdef ALPGPU_SINK_STAGE_F32_ALP_ONLY
+	const int  stage_words = is_alp ? static_cast<int>(d.bw) : 1000;
+#else
+	const int  stage_words = static_cast<int>(d.bw) + (is_alp ? 0 : static_cast<int>(d.lbw));
+#endif
+	const bool staged = 128 * stage_words <= ALPGPU_SINK_STAGE_F32 && cnt <= ALPGPU_SINK_STAGE_F32_MAX_EXC; // wave-uniform
 	if (staged) {
 		typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 		const ull2* g       = reinterpret_cast<const ull2*>(packed + d.packed_off);
-		const int   n_units = 8 * d.bw;
+		const int   n_units = 8 * stage_words;
 		for (int j = 0; 64 * j < n_units; ++j) {
 			if (64 * j + lane < n_units) { __builtin_amdgcn_global_load_lds(g + 64 * j + lane, reinterpret_cast<ull2*>(L.stage) + 64 * j, 16, 0, 0); }
 		}

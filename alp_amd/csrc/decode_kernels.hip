@@ -29,6 +29,7 @@
 // 8192 B written (rocprofv3 FETCH_SIZE/WRITE_SIZE: profiles/*_pmc.json); no intermediate goes to HBM.
 #include "alp_device.hpp"
 #include "launch.hpp"
+#include <cstdlib>
 
 namespace alpgpu {
 
@@ -794,12 +795,14 @@ int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, 
 	const uint64_t n        = col->n_vectors;
 	const uint64_t n_wg     = (n + kDecWaves - 1) / kDecWaves;
 	const uint64_t kMaxGrid = 1ull << 30;
+	// experiment (ALPGPU_SINK_PAD_LDS_KIB): unused dynamic LDS that caps the workgroups resident per CU, as launch_decode_column does by width
+	static const unsigned pad_lds = std::getenv("ALPGPU_SINK_PAD_LDS_KIB") ? static_cast<unsigned>(std::atoi(std::getenv("ALPGPU_SINK_PAD_LDS_KIB"))) * 1024u : 0u;
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (count) {
-			hipLaunchKernelGGL((k_sink_direct<kSinkCount>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, lo, hi);
+			hipLaunchKernelGGL((k_sink_direct<kSinkCount>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, lo, hi);
 		} else {
-			hipLaunchKernelGGL((k_sink_direct<kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_sink_direct<kSinkSum>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, 0.0, 0.0);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;

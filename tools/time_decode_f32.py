@@ -9,6 +9,7 @@ from alp_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 dev = torch.device("cuda:0")
 ctx = capi.Context(0)
+ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, int(os.environ.get("SWEEP_VPW", "0")))
 row = []
 for kind in ("decimal_mixed", "rd"):
     g = torch.Generator(device=dev); g.manual_seed(43)
@@ -32,4 +33,4 @@ for kind in ("decimal_mixed", "rd"):
     ok = bool(torch.equal(out.view(torch.int32), xf.view(torch.int32)))
     row.append(f"{kind}: {best:.3f} ms = {(n * (4096 + 13) + pb + eb) / best / 1e6 / 8000:.3f} of peak (round trip {ok})")
     del xf, col, out
-print(f"float decode, pad {os.environ.get('ALPGPU_DECODE_F32_PAD_LDS_KIB', '0'):>2s} KiB: " + " | ".join(row), flush=True)
+print(f"float decode, vectors per workgroup {os.environ.get('SWEEP_VPW', 'auto')}, pad {os.environ.get('ALPGPU_DECODE_F32_PAD_LDS_KIB', '0'):>2s} KiB: " + " | ".join(row), flush=True)
