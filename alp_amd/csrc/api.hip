@@ -396,7 +396,8 @@ int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 // SIMD fits beside two encode tiles, registers and LDS — the 0.55 ms the search took in front of a 1 Mi-vector encode disappear into it.
 // (Round 1 tried the search of the NEXT chunk as a full-width grid on a second stream: 26 % slower — its 9-wavefront, 62 KiB workgroups
 // displaced encode tiles.)  Everything rejoins the context's stream: callers see one stream, as before.
-constexpr uint64_t kAsyncHeadRowgroups = 256;  // searched in front: what the persistent search needs to get ahead of the encode's front
+constexpr uint64_t kAsyncHeadRowgroups = 256;
+static_assert(kAsyncHeadRowgroups >= 4 * 64, "the persistent search looks at the states of rowgroups 0, 4, .., 252 of the head (init_kernels.hip: walkers)");  // searched in front: what the persistent search needs to get ahead of the encode's front
 constexpr uint64_t kAsyncMinRowgroups  = 1024; // shorter columns are not worth two streams
 static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col, bool async_states);
 extern "C++" {
