@@ -300,6 +300,179 @@ __device__ __forceinline__ void for_each_exception_f32(const uint64_t (&ballot)[
 	}
 }
 
+// ---- the same analysis with NO lane mask outliving its value step (late round 4) -----------------------------------------------------------
+// At eight wavefronts per SIMD a wavefront may hold 80 scalar registers (800 per SIMD, 16 of each wavefront's share reserved for the trap
+// handler); the sixteen exception masks of encode_alp_registers_f32 are 32 of them, live from the first value step to the exception record, and
+// the single-pass kernel spilled 89 scalar registers into VGPR lanes — every spill a v_writelane, every use a v_readlane, ~170 of its ~1020
+// vector instructions per vector (profiles/r04_float_encode.txt, late round 4, point d).  Here a lane keeps its OWN sixteen exception bits in one
+// VGPR (one v_addc per value: bits = 2 * bits + exception) next to four scalar per-step counts; the filler is settled right behind the first value
+// step (a vector that begins with 256 exceptions takes the old analysis: rare), so that every later step selects it straight from its compare;
+// the record's stage asks the bits for each step's masks again (for_each_exception_bits_f32).  Same integers, same bytes.
+struct AlpEncodedLeanF {
+	int32_t  enc[4][4];   // exception slots already hold the filler
+	uint32_t excbits;     // per lane: value k = 4 m + j at bit 15 - k
+	uint32_t cnt_m[4];    // exceptions per value step (wave-uniform)
+	int      cnt;
+	int32_t  base;
+	int      bw;
+};
+// bits = 2 * bits + (this lane in mask): one vector instruction (the mask goes in as the carry)
+__device__ __forceinline__ uint32_t push_exception_bit(uint32_t bits, uint64_t mask) {
+	uint32_t out;
+	asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(out) : "v"(bits), "s"(mask) : "vcc");
+	return out;
+}
+// lane mask of value (m, j) out of the lanes' bits
+__device__ __forceinline__ uint64_t exception_mask_of(uint32_t excbits, int m, int j) { return ballot64(((excbits >> (15 - (4 * m + j))) & 1u) != 0u); }
+
+__device__ __forceinline__ void encode_alp_lean_f32(const VecInF& in, int e, int f, int lane, AlpEncodedLeanF& R) {
+	const float    exp10  = kExpArrF[e];
+	const float    frac_f = kFracArrF[f];
+	const uint32_t fact   = kFactArrF[f];
+	const float    frac_e = kFracArrF[e];
+	R.cnt     = 0;
+	R.excbits = 0;
+	int32_t filler = 0;
+	int32_t mn = INT32_MAX, mx = INT32_MIN;
+	// one value step: encoded integers, the step's four lane masks (they die with the step), count, the lanes' bits
+	auto value_step = [&](int m, uint64_t (&b)[4]) {
+		uint32_t c = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float    v    = in.x[m][j];
+			const uint32_t bits = __float_as_uint(v);
+			// pass 1 (encoder.hpp:326-338): NaN, +-Inf and -0.0 are replaced by (float)ENCODING_UPPER_LIMIT
+			const bool    special = ((bits & 0x7FFFFFFFu) >= 0x7F800000u) || bits == 0x80000000u;
+			const float   vv      = special ? kUpperLimitF : v;
+			const int32_t enc     = encode_value_f32(vv, exp10, frac_f);
+			const float   dec     = decode_value_f32(enc, fact, frac_e);
+			R.enc[m][j]           = enc;
+			b[j]                  = ballot64(dec != vv);
+			c += static_cast<uint32_t>(__builtin_popcountll(b[j]));
+			R.excbits = push_exception_bit(R.excbits, b[j]);
+		}
+		R.cnt_m[m] = c;
+		R.cnt += static_cast<int>(c);
+	};
+	auto fill_step = [&](int m, const uint64_t (&b)[4]) {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { R.enc[m][j] = lane_in_f32(b[j]) ? filler : R.enc[m][j]; }
+	};
+	uint64_t b0[4];
+	value_step(0, b0);
+	// filler = encoded value at the first non-exception position (encoder.hpp:382-388), 0 when that position is 1023.  It lies in step 0 unless the
+	// vector begins with 256 exceptions (`late`, rare): then the steps run with a provisional 0 and the fix-up below settles it from the lanes' bits.
+	const bool late = R.cnt_m[0] == 256u; // wave-uniform
+	auto first_clean_of = [&](int m, const uint64_t (&b)[4], int& pos) {
+		int     best_pos = 1 << 20, best_j = 0, best_l = 0;
+		int32_t cand     = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint64_t nj = ~b[j];
+			const int      lj = nj ? __builtin_ctzll(nj) : 64;
+			const int      pj = nj ? 4 * lj + j : (1 << 20);
+			if (pj < best_pos) {
+				best_pos = pj;
+				best_j   = j;
+				best_l   = lj;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (best_j == j) { cand = __builtin_amdgcn_readlane(R.enc[m][j], best_l & 63); }
+		}
+		pos = 256 * m + best_pos;
+		return cand;
+	};
+	if (!late) {
+		int pos;
+		filler = first_clean_of(0, b0, pos); // (pos < 256: never 1023)
+	}
+	fill_step(0, b0);
+#pragma unroll
+	for (int m = 1; m < 4; ++m) {
+		uint64_t b[4];
+		value_step(m, b);
+		fill_step(m, b);
+	}
+	if (__builtin_expect(late, 0)) { // the non-exceptions are untouched, the exception slots hold the provisional 0: settle the filler, fill again
+		bool found = false;
+#pragma unroll
+		for (int m = 1; m < 4; ++m) {
+			if (!found && R.cnt_m[m] != 256u) {
+				uint64_t b[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { b[j] = exception_mask_of(R.excbits, m, j); }
+				int           pos;
+				const int32_t cand = first_clean_of(m, b, pos);
+				filler             = pos == 1023 ? 0 : cand;
+				found              = true;
+			}
+		}
+		if (filler != 0) {
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { R.enc[m][j] = lane_in_f32(exception_mask_of(R.excbits, m, j)) ? filler : R.enc[m][j]; }
+			}
+		}
+	}
+	// (min / max behind the value steps, not inside them: two more live registers there and the kernel no longer fits its 64)
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			mn = R.enc[m][j] < mn ? R.enc[m][j] : mn;
+			mx = R.enc[m][j] > mx ? R.enc[m][j] : mx;
+		}
+	}
+#define ALPGPU_MINMAX_STEP(CTRL, ROWS)                                                                                  \
+	{                                                                                                                   \
+		const int32_t omn = __builtin_amdgcn_update_dpp(mn, mn, CTRL, ROWS, 0xf, false);                                \
+		const int32_t omx = __builtin_amdgcn_update_dpp(mx, mx, CTRL, ROWS, 0xf, false);                                \
+		mn                = omn < mn ? omn : mn;                                                                        \
+		mx                = omx > mx ? omx : mx;                                                                        \
+	}
+	ALPGPU_MINMAX_STEP(0x111, 0xf) // row_shr:1
+	ALPGPU_MINMAX_STEP(0x112, 0xf) // row_shr:2
+	ALPGPU_MINMAX_STEP(0x114, 0xf) // row_shr:4
+	ALPGPU_MINMAX_STEP(0x118, 0xf) // row_shr:8
+	ALPGPU_MINMAX_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+	ALPGPU_MINMAX_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3
+#undef ALPGPU_MINMAX_STEP
+	mn     = __builtin_amdgcn_readlane(mn, 63);
+	mx     = __builtin_amdgcn_readlane(mx, 63);
+	R.base = mn;
+	R.bw   = count_bits32(mx, mn);
+}
+
+// for_each_exception_f32 over the lanes' bits: a step's four masks are asked for again (two vector instructions each) only if the step has exceptions
+template <class F>
+__device__ __forceinline__ void for_each_exception_bits_f32(uint32_t excbits, const uint32_t (&cnt_m)[4], int lane, F&& emit) {
+	const uint64_t lt   = lanemask_lt64(lane);
+	int            soff = 0;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		if (cnt_m[m] != 0) { // wave-uniform
+			uint64_t b[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { b[j] = exception_mask_of(excbits, m, j); }
+			int rank = soff;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { rank += __builtin_popcountll(b[j] & lt); }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (lane_in_f32(b[j])) {
+					emit(rank, m, j);
+					++rank;
+				}
+			}
+			soff += static_cast<int>(cnt_m[m]);
+		}
+	}
+}
+
+
 // ---- FFOR u32 pack from LDS: vals[i] = value - base (< 2^bw), natural order.  Output unit u = 8*k + a is the 16-byte group
 // of stream word k for lane32 columns 4a..4a+3; lane handles units lane, lane + 64, ... -> 1-KiB contiguous stores.
 // The same packing kept in registers (unit lane + 64*t in acc[t], t < ceil(8*bw / 64) <= 4): the single-pass encode packs

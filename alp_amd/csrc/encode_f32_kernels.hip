@@ -92,7 +92,21 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	VecInF             x;
 	alpgpu_vector_desc d;
 	uint64_t           lacc[4] = {0, 0, 0, 0}; // ALP_RD: packed left streams of this lane's four lane64 columns
+	// Where the vector's exceptions are.  Default: sixteen lane masks (scalar register pairs), live from the value steps to the exception record.
+	// -DALPGPU_F32_BITS_ANALYSIS (late round 4, measured, NOT the default): per lane its own sixteen bits in one VGPR plus the count of every value
+	// step — no lane mask outlives its value step (encode_f32_device.hpp: encode_alp_lean_f32): 89 -> 41 spilled scalar registers and 1017 -> 964
+	// vector instructions per vector, but the kernel then needs 66 VGPRs, seven of them go through scratch, and it is 3-4 % SLOWER
+	// (profiles/r04_float_encode.txt, late round 4, point f).
+#ifdef ALPGPU_F32_BITS_ANALYSIS
+	uint32_t           excbits  = 0;
+	uint32_t           cnt_m[4] = {0u, 0u, 0u, 0u};
+#define ALPGPU_F32_EXC_WITNESS excbits
+#define ALPGPU_F32_FOR_EACH_EXCEPTION(...) for_each_exception_bits_f32(excbits, cnt_m, lane, __VA_ARGS__)
+#else
 	uint64_t           ballots[4][4];
+#define ALPGPU_F32_EXC_WITNESS static_cast<int64_t>(ballots[0][0] ^ ballots[3][3] ^ ballots[1][1])
+#define ALPGPU_F32_FOR_EACH_EXCEPTION(...) for_each_exception_f32(ballots, lane, __VA_ARGS__)
+#endif
 	uint32_t           pvals[4][4]; // what gets packed: value - base (ALP), right parts (ALP_RD)
 #pragma unroll
 	for (int m = 0; m < 4; ++m) { pvals[m][0] = pvals[m][1] = pvals[m][2] = pvals[m][3] = 0u; }
@@ -131,9 +145,16 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 				f = rgp->combos[1];
 			}
 			ALPGPU_F32_STOP(2, e * 32 + f);
+#ifdef ALPGPU_F32_BITS_ANALYSIS
+			AlpEncodedLeanF R;
+			encode_alp_lean_f32(x, e, f, lane, R);
+			ALPGPU_F32_STOP(3, R.base + R.bw + R.cnt + R.excbits + R.enc[0][0] + R.enc[3][3] + R.enc[1][1] + R.enc[2][2]);
+			excbits = R.excbits;
+#else
 			AlpEncodedF R;
 			encode_alp_registers_f32(x, e, f, lane, R);
 			ALPGPU_F32_STOP(3, R.base + R.bw + R.cnt + static_cast<int64_t>(R.ballot[0][0] ^ R.ballot[3][3] ^ R.ballot[1][2] ^ R.ballot[2][1]) + R.enc[0][0] + R.enc[3][3] + R.enc[1][1] + R.enc[2][2]);
+#endif
 			d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
 			cnt = R.cnt;
 			const uint32_t base = static_cast<uint32_t>(R.base);
@@ -141,10 +162,13 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 			for (int m = 0; m < 4; ++m) {
 				u32x4 q;
 #pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					q[j]          = static_cast<uint32_t>(R.enc[m][j]) - base;
-					ballots[m][j] = R.ballot[m][j];
-				}
+				for (int j = 0; j < 4; ++j) { q[j] = static_cast<uint32_t>(R.enc[m][j]) - base; }
+#ifdef ALPGPU_F32_BITS_ANALYSIS
+				cnt_m[m] = R.cnt_m[m];
+#else
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { ballots[m][j] = R.ballot[m][j]; }
+#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) { pvals[m][j] = q[j]; }
 			}
@@ -175,18 +199,27 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 					for (int dd = 7; dd >= 0; --dd) {
 						if (dd < ds && dict[dd] == left) { idx = dd; }
 					}
-					const bool exc = idx == ds;
-					ballots[m][j]  = ballot64(exc);
-					if (order.valid && ballots[m][j] != 0) { // the reference's index for a left part outside the dictionary
+					const bool     exc = idx == ds;
+					const uint64_t bj  = ballot64(exc);
+					if (order.valid && bj != 0) { // the reference's index for a left part outside the dictionary
 						const int ridx = rd_exception_index(order, left);
 						idx            = exc ? ridx : idx;
 					}
-					cnt += __builtin_popcountll(ballots[m][j]);
+#ifdef ALPGPU_F32_BITS_ANALYSIS
+					cnt_m[m] += static_cast<uint32_t>(__builtin_popcountll(bj));
+					excbits = push_exception_bit(excbits, bj);
+#else
+					ballots[m][j] = bj;
+					cnt += __builtin_popcountll(bj);
+#endif
 					lacc[j] |= (static_cast<uint64_t>(idx) & lmask) << (row * lbw);
 				}
 #pragma unroll
 				for (int j = 0; j < 4; ++j) { pvals[m][j] = q[j]; }
 			}
+#ifdef ALPGPU_F32_BITS_ANALYSIS
+			cnt = static_cast<int>(cnt_m[0] + cnt_m[1] + cnt_m[2] + cnt_m[3]);
+#endif
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				lacc[j] |= static_cast<uint64_t>(__shfl_xor(static_cast<long long>(lacc[j]), 16));
@@ -195,7 +228,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		}
 		d.exc_cnt = static_cast<uint16_t>(cnt);
 	}
-	ALPGPU_F32_STOP(4, d.base + d.bw + cnt + pvals[0][0] + pvals[3][3] + pvals[1][2] + pvals[2][1] + static_cast<int64_t>(ballots[0][0] ^ ballots[3][3] ^ ballots[1][1]));
+	ALPGPU_F32_STOP(4, d.base + d.bw + cnt + pvals[0][0] + pvals[3][3] + pvals[1][2] + pvals[2][1] + ALPGPU_F32_EXC_WITNESS);
 	uint64_t my_p = 0, my_e = 0;
 	if (live) { record_sizes<4>(d, my_p, my_e); }
 	if (MODE == kAnalyze) { // the sizes are all the scan needs
@@ -219,7 +252,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	// Pad bytes are zero.
 	ALPGPU_F32_STOP(5, base_p + base_e + my_p + my_e + pvals[0][0] + pvals[3][3]);
 	pack_u32_scatter_image(reinterpret_cast<uint32_t*>(L.vals), pvals, d.bw, lane);
-	ALPGPU_F32_STOP(6, reinterpret_cast<uint32_t*>(L.vals)[lane] + base_p + static_cast<int64_t>(ballots[0][0] ^ ballots[3][3]));
+	ALPGPU_F32_STOP(6, reinterpret_cast<uint32_t*>(L.vals)[lane] + base_p + ALPGPU_F32_EXC_WITNESS);
 	const bool     alp_rec    = d.scheme == ALPGPU_SCHEME_ALP;
 	const uint32_t val_bytes  = alp_rec ? 4u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
 	const uint32_t rec_off    = 128u * d.bw;
@@ -229,7 +262,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		if (lane == 0) { reinterpret_cast<uint64_t*>(img)[(my_e >> 3) - 1] = 0ull; } // the pad lives in the last word
 		wave_lds_sync();
 		const int rbw = d.bw;
-		for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
+		ALPGPU_F32_FOR_EACH_EXCEPTION([&](int r, int m, int j) {
 			const uint32_t bits = __float_as_uint(x.x[m][j]);
 			if (alp_rec) {
 				reinterpret_cast<uint32_t*>(img)[r] = bits;
@@ -278,7 +311,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		} else { // no room behind the image: values, positions and pad straight from the registers
 			uint16_t* rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
 			const int rbw  = d.bw;
-			for_each_exception_f32(ballots, lane, [&](int r, int m, int j) {
+			ALPGPU_F32_FOR_EACH_EXCEPTION([&](int r, int m, int j) {
 				const uint32_t bits = __float_as_uint(x.x[m][j]);
 				if (alp_rec) {
 					reinterpret_cast<uint32_t*>(rec)[r] = bits;
