@@ -77,6 +77,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	uint32_t& s_ready                = S.s_ready;
 	const int lane = lane_id();
 	const int wave = wave_in_wg();
+#ifdef ALPGPU_F32_INIT_BARRIER_FIRST // (A/B: until late in round 4 the tile's two LDS words were set, and waited for, in front of the loads)
 	if (MODE == kSinglePass) { // (the other two modes share nothing between wavefronts)
 		if (threadIdx.x == 0) {
 			s_count = 0;
@@ -84,6 +85,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		}
 		__syncthreads();
 	}
+#endif
 
 	EncodeLdsF32&  L    = lds[wave];
 	const uint64_t vl   = tile * kFusedWaves + wave;
@@ -123,6 +125,15 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	const bool                   polling  = MODE == kSinglePass && async_states;
 	const uint32_t               st_word  = polling ? rowgroup_state_poll_begin(rg_ptr, lane) : reinterpret_cast<const uint32_t*>(rg_ptr)[lane & 7];
 	x                                     = load_vector_f32(in, v_read, lane);
+#ifndef ALPGPU_F32_INIT_BARRIER_FIRST
+	if (MODE == kSinglePass) { // the tile's two LDS words, set behind the ISSUE of the loads (k_encode_lean): the barrier falls into the shadow of their round trip
+		if (threadIdx.x == 0) {
+			s_count = 0;
+			s_ready = 0;
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
+	}
+#endif
 	bool                         state_ok = true;
 	const alpgpu_rowgroup_state  st       = polling ? rowgroup_state_poll_finish(rg_ptr, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
 	const alpgpu_rowgroup_state* rgp      = &st;

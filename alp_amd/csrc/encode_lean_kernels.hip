@@ -375,11 +375,13 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	const int           lane = lane_id();
 	const int           wave = wave_in_wg();
 	const uint64_t      tile = blockIdx.x;
+#ifdef ALPGPU_LEAN_INIT_BARRIER_FIRST // (A/B: until late in round 4 the tile's two LDS words were set, and waited for, in front of the loads)
 	if (threadIdx.x == 0) {
 		s_count = 0;
 		s_ready = 0;
 	}
 	__syncthreads();
+#endif
 
 	uint64_t*      buf  = lds[wave].buf;
 	const uint64_t vl   = tile * kFusedWaves + wave;
@@ -409,6 +411,15 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 #endif
 #ifdef ALPGPU_LEAN_PREFETCH_TILES
 	asm volatile("" ::"v"(pf_word));
+#endif
+#ifndef ALPGPU_LEAN_INIT_BARRIER_FIRST
+	// the tile's two LDS words, set behind the ISSUE of the loads: the barrier that publishes them falls into the shadow of the input's round trip
+	// (no wavefront touches them before its analysis is done)
+	if (threadIdx.x == 0) {
+		s_count = 0;
+		s_ready = 0;
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
 #endif
 	bool                         state_ok = true;
 	const alpgpu_rowgroup_state  st       = async_states ? rowgroup_state_poll_finish(rgp, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
