@@ -70,10 +70,12 @@ _sig("alpgpu_set_stream", _int, _vp, _vp)
 _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
 OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL, OPT_CONSUMER_PIPELINED, OPT_ENCODE_ASYNC_INIT, OPT_ENCODE_KERNEL, OPT_DECODE_PAIRING = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_DECODE_PATCH_AFTER, OPT_ENCODE_UNORDERED = 9, 10
 ENCODE_KERNEL_LEAN, ENCODE_KERNEL_CLASSIC = 0, 1
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
+_sig("alpgpu_debug_traffic_probe_with_search", _int, _vp, _vp, _vp, _u64, C.c_uint32, C.POINTER(CColumn))
 _sig("alpgpu_malloc_host", _int, _vp, C.POINTER(_vp), _sz)
 for _t in ("f64", "f32"):
     _sig("alpgpu_compress_host_" + _t, _int, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64))
@@ -256,6 +258,11 @@ class Context:
     def traffic_probe(self, x, out, n_vectors: int, write_bytes_per_vector: int):
         """the single-pass encode's loads and stores without its arithmetic (include/alpgpu.h: alpgpu_debug_traffic_probe)"""
         _check(lib.alpgpu_debug_traffic_probe(self.h, _vp(x.data_ptr()), _vp(out.data_ptr()), n_vectors, write_bytes_per_vector), "alpgpu_debug_traffic_probe")
+
+    def traffic_probe_with_search(self, x, out, n_vectors: int, write_bytes_per_vector: int, scratch: "DeviceColumn"):
+        """the same probe with the encode's rowgroup search (over x, a double column) running beside it as beside alpgpu_encode_f64"""
+        _check(lib.alpgpu_debug_traffic_probe_with_search(self.h, _vp(x.data_ptr()), _vp(out.data_ptr()), n_vectors, write_bytes_per_vector, C.byref(scratch.c)),
+               "alpgpu_debug_traffic_probe_with_search")
 
     def decode_vectors_per_wg(self, col: "DeviceColumn") -> int:
         """the launch shape decode() would use for this column now (vectors per decode workgroup)"""

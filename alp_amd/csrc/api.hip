@@ -34,8 +34,11 @@ struct alpgpu_ctx {
 	hipStream_t init_stream;     // ... on this stream (highest priority: its few workgroups are placed first)
 	hipEvent_t  ev_fork, ev_head, ev_join;
 	int         encode_kernel;   // ALPGPU_ENCODE_KERNEL_LEAN (default) / _CLASSIC
+	int         encode_unordered; // ALPGPU_OPT_ENCODE_UNORDERED: tiles reserve their stream bytes with one atomic add (lean kernel, device columns only)
 	int         decode_pairing;  // ALPGPU_OPT_DECODE_PAIRING: 0 auto, 1..3 -> k_decode_pairs
 	int         decode_pairs_auto; // the auto rule may pick the pair kernel (ALPGPU_DECODE_PAIRS_AUTO=0 for A/B runs)
+	int         decode_patch_max;  // ALPGPU_OPT_DECODE_PATCH_AFTER: ALP vectors with 1..this many exceptions are patched after their stores (0: never; <= 64)
+	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -128,8 +131,12 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->force_stall     = 0;
 	ctx->pipelined_consumer = 0;
 	ctx->decode_pairs_auto = std::getenv("ALPGPU_DECODE_PAIRS_AUTO") ? std::atoi(std::getenv("ALPGPU_DECODE_PAIRS_AUTO")) : 1;
+	ctx->decode_patch_max   = std::getenv("ALPGPU_DECODE_PATCH_AFTER") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_AFTER")) : 64; // (A/B runs)
+	if (ctx->decode_patch_max < 0 || ctx->decode_patch_max > 64) { ctx->decode_patch_max = 64; }
+	ctx->decode_patch_shape = std::getenv("ALPGPU_DECODE_PATCH_SHAPE") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_SHAPE")) : 1;
 	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
 	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
+	ctx->encode_unordered = std::getenv("ALPGPU_ENCODE_UNORDERED") ? std::atoi(std::getenv("ALPGPU_ENCODE_UNORDERED")) : 0; // (A/B runs)
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	ctx->ws_stream       = nullptr;
@@ -208,6 +215,13 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_ENCODE_KERNEL:
 		if (value != ALPGPU_ENCODE_KERNEL_LEAN && value != ALPGPU_ENCODE_KERNEL_CLASSIC) { return fail(ALPGPU_ERR_INVALID, "encode kernel: 0 (lean) or 1 (classic)"); }
 		ctx->encode_kernel = static_cast<int>(value);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_ENCODE_UNORDERED:
+		ctx->encode_unordered = value ? 1 : 0;
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_PATCH_AFTER:
+		if (value < 0 || value > 64) { return fail(ALPGPU_ERR_INVALID, "decode patch-after: 0 (never) .. 64 exceptions per vector"); }
+		ctx->decode_patch_max = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_CONSUMER_PIPELINED:
 		if (value < 0 || value > 3) { return fail(ALPGPU_ERR_INVALID, "consumer kernel: 0 (chosen per column), 1 (persistent LDS-ring kernel), 2 (one wavefront per vector, no stage) or 3 (four wavefronts per vector)"); }
@@ -379,7 +393,8 @@ static int encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	if (ctx->encode_two_pass) {
 		rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus);
 	} else {
-		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head, ctx->encode_kernel); // (waits for / joins the search's stream)
+		const int kernel = ctx->encode_kernel | ((ctx->encode_unordered && ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN) ? alpgpu::kEncodeUnorderedFlag : 0);
+		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head, kernel); // (waits for / joins the search's stream)
 		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus, col->d_totals + 6); }
 	}
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
@@ -450,6 +465,17 @@ int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, a
 	return encode_with_side_search(ctx, d_in, n_vectors, col);
 }
 
+// "the column's vectors carry exceptions" as far as the decode's launch shape is concerned: about two or more per vector — unless they are
+// patched in after the stores (ALPGPU_OPT_DECODE_PATCH_AFTER: an average of at most half the arm's limit, 10 bytes of record each), which
+// costs a wavefront a handful of instructions: such a column behaves like one without exceptions
+static bool column_decodes_with_exceptions(const alpgpu_ctx* ctx, const alpgpu_column* col) {
+	const double n = static_cast<double>(col->n_vectors);
+	const double e = static_cast<double>(col->exc_bytes_hint);
+	if (e < 16.0 * n) { return false; }
+	if (ctx->decode_patch_shape && ctx->decode_patch_max > 0 && e <= 5.0 * static_cast<double>(ctx->decode_patch_max) * n) { return false; }
+	return true;
+}
+
 static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	int variant = ctx->decode_variant;
 	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
@@ -460,10 +486,11 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		// profiles/r04_decode_floor.txt): without exceptions one vector per workgroup wins from 17 bits on (16 itself — whole KiB per vector —
 		// still prefers more), with ~2 or more exceptions per vector from 21 bits on; every ALP_RD column is far beyond either.  Up to
 		// kNarrowAutoBits bits FOUR vectors share a workgroup over the narrow stage (round 4).
-		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n; // ~2 exceptions per vector
+		const bool   with_exc = column_decodes_with_exceptions(ctx, col);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * (n > 0 ? n : 1.0));
 		const bool   narrow   = bits <= (with_exc ? 20.0 : 17.5); // (17.5: with the residency caps below two vectors per workgroup win through 17 bits)
-		const bool   four     = bits <= (with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits);
+		const double four_max = with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits; // (0 = never: the four-vector shape lost at every width, it is chosen by tuning runs only)
+		const bool   four     = four_max > 0.0 && bits <= four_max;
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
 	}
 	// Narrow vectors WITH exceptions: the pair kernel (k_decode_pairs, both vectors' loads in flight together when both are narrow, one after the
@@ -472,7 +499,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	int pairing = ctx->decode_pairing;
 	if (ctx->decode_auto && pairing == 0 && ctx->decode_pairs_auto && col->packed_bytes_hint != 0) {
 		const double n = static_cast<double>(col->n_vectors);
-		if (static_cast<double>(col->exc_bytes_hint) >= 16.0 * n && static_cast<double>(col->packed_bytes_hint) <= 18.0 * 128.0 * n) { pairing = 1; }
+		if (column_decodes_with_exceptions(ctx, col) && static_cast<double>(col->packed_bytes_hint) <= 18.0 * 128.0 * n) { pairing = 1; }
 	}
 	// Residency by width (decode_kernels.hip: launch_decode_column; unused dynamic LDS): what a CU wants is a certain amount of bytes in flight, not a
 	// certain number of workgroups.  One vector per workgroup: eight workgroups per CU up to 33 bits, seven up to 35, six beyond; seven for ALP_RD
@@ -482,7 +509,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	if (pad_env < 0 && ctx->decode_auto && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
 		const double n        = static_cast<double>(col->n_vectors);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
-		const bool   with_exc = static_cast<double>(col->exc_bytes_hint) >= 16.0 * n;
+		const bool   with_exc = column_decodes_with_exceptions(ctx, col);
 		const bool   mostly_rd = col->alp_rd_rowgroups_hint != 0 && 2.0 * static_cast<double>(col->alp_rd_rowgroups_hint - 1) * 100.0 > n;
 		if ((variant & 5) == 1) {
 			// one vector per workgroup (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on — seven at 34-35, six beyond; with ~2 % exceptions the
@@ -525,6 +552,35 @@ int alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, u
 	if (alpgpu::launch_traffic_probe(ctx->stream, d_in, d_out, n_vectors, write_bytes_per_vector) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "traffic probe launch failed", hipGetLastError());
 	}
+	return ALPGPU_OK;
+}
+
+// measurement aid: the same probe with the encode's rowgroup search running BESIDE it exactly as beside alpgpu_encode_f64 (head in front on the
+// side stream, then the persistent kernel, same grid and adaptive rule) — what the encode's loads and stores cost when they share the CUs with
+// the search.  The probe does not read the states; `scratch` receives them (d_rowgroups, d_rd_order of a column of n_vectors vectors).
+int alpgpu_debug_traffic_probe_with_search(alpgpu_ctx* ctx, const double* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector, alpgpu_column* scratch) {
+	ALPGPU_CHECK_CTX(ctx);
+	const uint64_t n_rg = (n_vectors + 99) / 100;
+	if (!d_in || !d_out || !scratch || !scratch->d_rowgroups || write_bytes_per_vector % 16u != 0 || write_bytes_per_vector > 8192u) { return fail(ALPGPU_ERR_INVALID, "bad probe arguments"); }
+	if (n_rg < kAsyncMinRowgroups) { return fail(ALPGPU_ERR_INVALID, "the search runs beside the encode from 1024 rowgroups on only"); }
+	ALPGPU_HIP(hipMemsetAsync(scratch->d_rowgroups, alpgpu::kStateUnpublished, 32ull * n_rg, ctx->stream));
+	ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+	ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
+	const bool lean = ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN;
+	if (alpgpu::launch_rowgroup_init_async(ctx->init_stream, d_in, n_vectors, scratch->d_rowgroups, scratch->d_rd_order, 0, kAsyncHeadRowgroups, static_cast<int>(kAsyncHeadRowgroups), false, 0) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
+	}
+	ALPGPU_HIP(hipEventRecord(ctx->ev_head, ctx->init_stream));
+	const bool adaptive  = ctx->async_init_adaptive && lean && ctx->async_init_wg_per_cu < 3;
+	const int  wg_per_cu = adaptive ? 3 : ctx->async_init_wg_per_cu;
+	if (alpgpu::launch_rowgroup_init_async(ctx->init_stream, d_in, n_vectors, scratch->d_rowgroups, scratch->d_rd_order, kAsyncHeadRowgroups, n_rg - kAsyncHeadRowgroups, ctx->n_cus * wg_per_cu,
+	                                       lean, adaptive ? static_cast<uint32_t>(ctx->n_cus * ctx->async_init_wg_per_cu) : 0u) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "rowgroup init launch failed", hipGetLastError());
+	}
+	ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
+	ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_head, 0));
+	if (alpgpu::launch_traffic_probe(ctx->stream, d_in, d_out, n_vectors, write_bytes_per_vector) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "traffic probe launch failed", hipGetLastError()); }
+	ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
 	return ALPGPU_OK;
 }
 
@@ -610,7 +666,7 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
 	const int variant = decode_variant_for(ctx, col);
-	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus);
+	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max));
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
@@ -1111,9 +1167,13 @@ struct HostPipe { // everything a call allocates, released on every return path
 	void*       dev[16]   = {nullptr};
 	int         n_dev     = 0;
 	hipStream_t saved     = nullptr;
+	int         saved_unordered = 0;
 	alpgpu_ctx* ctx       = nullptr;
 	~HostPipe() {
-		if (ctx) { ctx->stream = saved; }
+		if (ctx) {
+			ctx->stream           = saved;
+			ctx->encode_unordered = saved_unordered;
+		}
 		for (int k = 0; k < 2; ++k) {
 			if (stream[k]) { (void)hipStreamSynchronize(stream[k]); }
 		}
@@ -1145,6 +1205,8 @@ int compress_host_piece(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, ui
 	HostPipe P;
 	P.ctx   = ctx;
 	P.saved = ctx->stream;
+	P.saved_unordered     = ctx->encode_unordered;
+	ctx->encode_unordered = 0; // a blob's streams are in vector order (byte for byte the reference's; the chunked decompression relies on it)
 	uint64_t total_p = 0, total_e = 0;
 	bool     blob_full = false;
 	std::vector<uint64_t> chunk_p, chunk_e; // bytes in front of every chunk

@@ -433,6 +433,51 @@ __device__ __forceinline__ void decode_staged_vector(const LDS& L, const alpgpu_
 	decode_vector_quarters<NT_STORE, SINK, 1>(L, StagedWords {L.stage}, d, dict, em, rec, dst, wave, lane, acc, range_lo, range_hi);
 }
 
+// ---- exceptions patched AFTER the stores (round 5; the reference's own order: decode everything, then scatter, decoder.hpp:141-149) ---------------
+// An ALP vector with a few exceptions is decoded as if it had none — no mask, no prefix, no per-value lookup (the +60 % vector instructions of
+// profiles/r01_pmc_sq_decode_exceptions.txt) — and its exceptions are then written over the freshly stored values: exception j (positions ascend, so
+// j is also its rank) by lane j of the wavefront that OWNS the quarter the position lies in, i.e. the same wavefront that stored that quarter a few
+// instructions earlier.  A wavefront's vector stores reach memory in issue order (both go down the same L1 queue to the same L2 channel, same cache
+// policy), so the 8-byte patch lands on the 16-byte store it overlaps; no barrier, no fence, no LDS.  Position and value are loaded (2 + 8 bytes
+// per lane, straight from the record) together with the packed words and wait in two / three registers.  Vectors with more exceptions than
+// `patch_max` (a kernel argument, <= 64: one lane each; 0 switches the arm off) and ALP_RD vectors (their exceptions replace the LEFT part only:
+// the patched double needs the right part the lane no longer has) take the mask route below.  -DALPGPU_DECODE_PATCH_FENCE: s_waitcnt vmcnt(0)
+// between a wavefront's stores and its patches (the conservative form, for A/B runs).
+struct PatchRegs {
+	uint32_t pos;
+	uint64_t val;
+};
+__device__ __forceinline__ bool vector_patches_after(const alpgpu_vector_desc& d, uint32_t patch_max) { // wave-uniform
+	return d.scheme == ALPGPU_SCHEME_ALP && d.exc_cnt != 0 && static_cast<uint32_t>(d.exc_cnt) <= patch_max;
+}
+__device__ __forceinline__ PatchRegs issue_patch_loads(const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, int lane) {
+	PatchRegs   r {0u, 0ull};
+	const int   cnt = d.exc_cnt;
+	if (lane < cnt) {
+		r.val = reinterpret_cast<const uint64_t*>(rec)[lane];
+		r.pos = reinterpret_cast<const uint16_t*>(rec + 8u * static_cast<uint32_t>(cnt))[lane];
+	}
+	return r;
+}
+template <bool NT_STORE>
+__device__ __forceinline__ void apply_patches(const PatchRegs& r, int cnt, double* __restrict__ out_vec, int wave, int lane) {
+#ifdef ALPGPU_DECODE_PATCH_FENCE
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	if (lane < cnt && static_cast<int>(r.pos >> 8) == wave) { // this wavefront stored values 256 wave .. 256 wave + 255 (steps 2 wave, 2 wave + 1)
+		const double x = __longlong_as_double(static_cast<long long>(r.val));
+		if constexpr (NT_STORE) {
+			__builtin_nontemporal_store(x, out_vec + r.pos);
+		} else {
+			out_vec[r.pos] = x;
+		}
+	}
+}
+__device__ __forceinline__ alpgpu_vector_desc without_exceptions(alpgpu_vector_desc d) {
+	d.exc_cnt = 0;
+	return d;
+}
+
 // Issues every load of one vector: packed words and the values of its exceptions straight into LDS (global_load_lds, 16 resp. 4 bytes per
 // lane, no VGPR round trip), exception positions into registers.  (Until round 3 the values went through registers too, behind a branch on the
 // scheme for their width — and the compiler's wait-count pass put an s_waitcnt vmcnt(0) between the two arms, i.e. a whole HBM round trip in
@@ -444,7 +489,7 @@ __device__ __forceinline__ bool vector_fits_stage(const alpgpu_vector_desc& d) {
 }
 template <class LDS>
 __device__ __forceinline__ uint32_t issue_vector_loads(LDS& L, const alpgpu_vector_desc& d, const uint8_t* __restrict__ packed,
-                                                       const uint8_t* __restrict__ rec, int tid, int wave) {
+                                                       const uint8_t* __restrict__ rec, int tid, int wave, bool record_elsewhere = false) {
 	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 	constexpr int T       = 64 * kDecWaves;
 	const bool    is_alp  = d.scheme == ALPGPU_SCHEME_ALP;
@@ -459,7 +504,7 @@ __device__ __forceinline__ uint32_t issue_vector_loads(LDS& L, const alpgpu_vect
 		}
 	}
 	uint32_t  pos = 0u;
-	const int cnt = d.exc_cnt;
+	const int cnt = record_elsewhere ? 0 : d.exc_cnt; // (record_elsewhere: the vector's exceptions are patched in after its stores, issue_patch_loads)
 	if (cnt > 0) { // wave-uniform
 		const uint32_t val_bytes = (is_alp ? 8u : 2u) * static_cast<uint32_t>(cnt);
 		const int      dwords    = static_cast<int>(((val_bytes < kExcStageBytes ? val_bytes : kExcStageBytes) + 3u) >> 2); // (records are 8-byte multiples)
@@ -491,7 +536,7 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                   const uint8_t* __restrict__ packed,
                                                                   const uint8_t* __restrict__ excs, double* __restrict__ out,
-                                                                  uint64_t n_vectors, uint64_t wg_offset, double lo, double hi) {
+                                                                  uint64_t n_vectors, uint64_t wg_offset, double lo, double hi, uint32_t patch_max) {
 	static_assert(LDS::kStage == kStageBytes || SINK == kSinkStore, "the sinks pass their lane partials through a full stage");
 	__shared__ LDS L[V];
 		const int      tid  = static_cast<int>(threadIdx.x);
@@ -510,19 +555,29 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	VectorConsts dict[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
+	// vectors whose (few) exceptions are written over their stored values afterwards (apply_patches): nothing of them goes through the mask
+	bool      patched[V];
+	PatchRegs pr[V];
 #pragma unroll
-	for (int i = 0; i < V; ++i) { pos[i] = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+	for (int i = 0; i < V; ++i) {
+		patched[i] = SINK == kSinkStore && vector_patches_after(d[i], patch_max); // workgroup-uniform
+		pos[i]     = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave, patched[i]);
+		pr[i]      = PatchRegs {0u, 0ull};
+		if (patched[i]) { pr[i] = issue_patch_loads(d[i], excs + d[i].exc_off, lane); }
+	}
 	// Only a workgroup that has exceptions zeroes its masks, and it does so behind the issue of all its loads: the barrier that fences the
 	// zeroes from the atomics waits for LDS only, so it falls into the shadow of the HBM round trip.  (Until round 3 every workgroup,
 	// exceptions or not, began with the zeroing write and a barrier in front of its first load.)
 	bool any_exc = false;
 #pragma unroll
-	for (int i = 0; i < V; ++i) { any_exc |= d[i].exc_cnt != 0; }
+	for (int i = 0; i < V; ++i) { any_exc |= d[i].exc_cnt != 0 && !patched[i]; }
 	if (any_exc) { // workgroup-uniform
 		if (tid < 32 * V) { L[tid >> 5].mask[tid & 31] = 0; }
 		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
 #pragma unroll
-		for (int i = 0; i < V; ++i) { land_exceptions(L[i], d[i], excs + d[i].exc_off, pos[i], tid); }
+		for (int i = 0; i < V; ++i) {
+			if (!patched[i]) { land_exceptions(L[i], d[i], excs + d[i].exc_off, pos[i], tid); }
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
 	__syncthreads();
@@ -577,19 +632,21 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {
+			const alpgpu_vector_desc dd = patched[i] ? without_exceptions(d[i]) : d[i]; // (a patched vector unpacks as one without exceptions)
 			if (LDS::kStage == kStageBytes || vector_fits_stage<LDS>(d[i])) { // (always, with the full stage)
-				decode_staged_vector<NT_STORE, kSinkStore, LDS>(L[i], d[i], dict[i], excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
+				decode_staged_vector<NT_STORE, kSinkStore, LDS>(L[i], dd, dict[i], excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
 			} else { // a wide vector in a narrow-stage launch: its words straight from HBM (bounded buffer loads, as in k_sink_direct)
 				ExcMask em {0u, 0};
-				if (d[i].exc_cnt > 0) { em = load_exception_mask(L[i], lane); }
+				if (dd.exc_cnt > 0) { em = load_exception_mask(L[i], lane); }
 				uint8_t*          first      = const_cast<uint8_t*>(packed + d[i].packed_off);
 				constexpr int     kRsrcFlags = 0x00020000;
 				const bool        is_alp     = d[i].scheme == ALPGPU_SCHEME_ALP;
 				const BufferWords words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d[i].bw, kRsrcFlags),
 				                         __builtin_amdgcn_make_buffer_rsrc(first + 128u * d[i].bw, 0, is_alp ? 0 : 128 * d[i].lbw, kRsrcFlags)};
-				decode_vector_quarters<NT_STORE, kSinkStore, 1>(L[i], words, d[i], dict[i], em, excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane,
+				decode_vector_quarters<NT_STORE, kSinkStore, 1>(L[i], words, dd, dict[i], em, excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane,
 				                                                nullptr, 0.0, 0.0);
 			}
+			if (patched[i]) { apply_patches<NT_STORE>(pr[i], d[i].exc_cnt, out + (v0 + i) * kVec, wave, lane); }
 		}
 	}
 }
@@ -621,7 +678,7 @@ __device__ __forceinline__ void loads_have_landed() {
 template <bool NT_STORE, int PAIRING>
 __global__ __launch_bounds__(64 * kDecWaves) void k_decode_pairs(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                  const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
-                                                                 uint64_t n_vectors, uint64_t wg_offset) {
+                                                                 uint64_t n_vectors, uint64_t wg_offset, uint32_t patch_max) {
 	__shared__ DecodeLds L[2];
 	const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
@@ -644,31 +701,48 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_pairs(const alpgpu_ve
 	double2*                 o0 = reinterpret_cast<double2*>(out + v0 * kVec);
 	double2*                 o1 = reinterpret_cast<double2*>(out + v1 * kVec);
 	const bool together = n_here == 2 && (PAIRING == 3 || (vector_is_narrow(d0) && vector_is_narrow(d1))); // workgroup-uniform
+	// vectors whose exceptions are patched in after their stores (apply_patches): decoded as if they had none
+	const bool               pa0 = vector_patches_after(d0, patch_max), pa1 = vector_patches_after(d1, patch_max);
+	const alpgpu_vector_desc m0 = pa0 ? without_exceptions(d0) : d0, m1 = pa1 ? without_exceptions(d1) : d1;
+	PatchRegs                r0 {0u, 0ull}, r1 {0u, 0ull};
 	if (together) {
-		const uint32_t p0 = issue_vector_loads(L[0], d0, packed, excs + d0.exc_off, tid, wave);
-		const uint32_t p1 = issue_vector_loads(L[1], d1, packed, excs + d1.exc_off, tid, wave);
-		if (d0.exc_cnt != 0 || d1.exc_cnt != 0) {
+		const uint32_t p0 = issue_vector_loads(L[0], m0, packed, excs + d0.exc_off, tid, wave);
+		const uint32_t p1 = issue_vector_loads(L[1], m1, packed, excs + d1.exc_off, tid, wave);
+		if (pa0) { r0 = issue_patch_loads(d0, excs + d0.exc_off, lane); }
+		if (pa1) { r1 = issue_patch_loads(d1, excs + d1.exc_off, lane); }
+		if (m0.exc_cnt != 0 || m1.exc_cnt != 0) {
 			if (tid < 64) { L[tid >> 5].mask[tid & 31] = 0; }
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			land_exceptions(L[0], d0, excs + d0.exc_off, p0, tid);
-			land_exceptions(L[1], d1, excs + d1.exc_off, p1, tid);
+			land_exceptions(L[0], m0, excs + d0.exc_off, p0, tid);
+			land_exceptions(L[1], m1, excs + d1.exc_off, p1, tid);
 		}
 		loads_have_landed();
-		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[0], d0, c0, excs + d0.exc_off, o0, wave, lane);
-		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[1], d1, c1, excs + d1.exc_off, o1, wave, lane);
+		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[0], m0, c0, excs + d0.exc_off, o0, wave, lane);
+		if (pa0) { apply_patches<NT_STORE>(r0, d0.exc_cnt, out + v0 * kVec, wave, lane); }
+		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[1], m1, c1, excs + d1.exc_off, o1, wave, lane);
+		if (pa1) { apply_patches<NT_STORE>(r1, d1.exc_cnt, out + v1 * kVec, wave, lane); }
 		return;
 	}
-	const uint32_t p0 = issue_vector_loads(L[0], d0, packed, excs + d0.exc_off, tid, wave);
-	prepare_exceptions(L[0], d0, excs + d0.exc_off, p0, tid);
+	const uint32_t p0 = issue_vector_loads(L[0], m0, packed, excs + d0.exc_off, tid, wave);
+	if (pa0) { r0 = issue_patch_loads(d0, excs + d0.exc_off, lane); }
+	prepare_exceptions(L[0], m0, excs + d0.exc_off, p0, tid);
 	loads_have_landed();
 	uint32_t p1 = 0;
-	if (PAIRING == 2 && n_here == 2) { p1 = issue_vector_loads(L[1], d1, packed, excs + d1.exc_off, tid, wave); }
-	decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[0], d0, c0, excs + d0.exc_off, o0, wave, lane);
+	if (PAIRING == 2 && n_here == 2) {
+		p1 = issue_vector_loads(L[1], m1, packed, excs + d1.exc_off, tid, wave);
+		if (pa1) { r1 = issue_patch_loads(d1, excs + d1.exc_off, lane); }
+	}
+	decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[0], m0, c0, excs + d0.exc_off, o0, wave, lane);
+	if (pa0) { apply_patches<NT_STORE>(r0, d0.exc_cnt, out + v0 * kVec, wave, lane); }
 	if (n_here == 2) {
-		if (PAIRING != 2) { p1 = issue_vector_loads(L[1], d1, packed, excs + d1.exc_off, tid, wave); }
-		prepare_exceptions(L[1], d1, excs + d1.exc_off, p1, tid);
+		if (PAIRING != 2) {
+			p1 = issue_vector_loads(L[1], m1, packed, excs + d1.exc_off, tid, wave);
+			if (pa1) { r1 = issue_patch_loads(d1, excs + d1.exc_off, lane); }
+		}
+		prepare_exceptions(L[1], m1, excs + d1.exc_off, p1, tid);
 		loads_have_landed();
-		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[1], d1, c1, excs + d1.exc_off, o1, wave, lane);
+		decode_staged_vector<NT_STORE, kSinkStore, DecodeLds>(L[1], m1, c1, excs + d1.exc_off, o1, wave, lane);
+		if (pa1) { apply_patches<NT_STORE>(r1, d1.exc_cnt, out + v1 * kVec, wave, lane); }
 	}
 }
 
@@ -808,8 +882,9 @@ int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, 
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus) {
+int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max) {
 	(void)n_cus;
+	if (patch_max > 64u) { patch_max = 64u; } // one lane per patched exception (apply_patches)
 	const uint64_t n = col->n_vectors;
 	// variant bit 0: one vector per workgroup (default) instead of two; bit 1: plain instead of non-temporal stores; bit 2: FOUR vectors per
 	// workgroup over the narrow stage (columns of <= 16-bit vectors)
@@ -821,7 +896,7 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 		const uint64_t kMaxGridP = 1ull << 30;
 		for (uint64_t off = 0; off < n_wg_p; off += kMaxGridP) {
 			const dim3 grid(static_cast<unsigned>(n_wg_p - off < kMaxGridP ? n_wg_p - off : kMaxGridP)), block(64 * kDecWaves);
-#define ALPGPU_LAUNCH_PAIRS(NT, P) hipLaunchKernelGGL((k_decode_pairs<NT, P>), grid, block, pad_lds_p, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off)
+#define ALPGPU_LAUNCH_PAIRS(NT, P) hipLaunchKernelGGL((k_decode_pairs<NT, P>), grid, block, pad_lds_p, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, patch_max)
 			if (pairing == 1) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 1); } else { ALPGPU_LAUNCH_PAIRS(false, 1); } }
 			if (pairing == 2) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 2); } else { ALPGPU_LAUNCH_PAIRS(false, 2); } }
 			if (pairing == 3) { if (nt) { ALPGPU_LAUNCH_PAIRS(true, 3); } else { ALPGPU_LAUNCH_PAIRS(false, 3); } }
@@ -840,17 +915,17 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 4 && nt) {
-			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
 		} else if (V == 4) {
-			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
 		} else if (V == 2 && nt) {
-			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
 		} else if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
 		} else if (nt) {
-			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
@@ -866,9 +941,9 @@ int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_su
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<2, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
+			hipLaunchKernelGGL((k_decode_column<1, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
@@ -881,7 +956,7 @@ int launch_decode_probe(hipStream_t stream, const alpgpu_column* col, double* d_
 	const uint64_t kMaxGrid = 1ull << 30;
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
-		hipLaunchKernelGGL((k_decode_column<2, false, kSinkProbe>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0);
+		hipLaunchKernelGGL((k_decode_column<2, false, kSinkProbe>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
@@ -894,7 +969,7 @@ int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, doub
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		hipLaunchKernelGGL((k_decode_column<2, false, kSinkCount>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc,
-		                   reinterpret_cast<double*>(d_counts), n, off, lo, hi);
+		                   reinterpret_cast<double*>(d_counts), n, off, lo, hi, 0u);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

@@ -82,6 +82,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		if (threadIdx.x == 0) {
 			s_count = 0;
 			s_ready = 0;
+			s_excl  = ~0ull; // "stalled" until the look-back says otherwise (k_encode_lean: a wavefront 0 that gave up on its state never runs it)
 		}
 		__syncthreads();
 	}
@@ -130,6 +131,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		if (threadIdx.x == 0) {
 			s_count = 0;
 			s_ready = 0;
+			s_excl  = ~0ull; // "stalled" until the look-back says otherwise (k_encode_lean: a wavefront 0 that gave up on its state never runs it)
 		}
 		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
 	}

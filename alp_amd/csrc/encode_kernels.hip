@@ -558,8 +558,15 @@ extern "C" __attribute__((visibility("default"))) int alpgpu_debug_fused_phases(
 // latches the stall flag into totals[6], the gate of the recovery kernels (k_scan_totals clears totals[3] on its way)
 // clear_rgs != nullptr (the last launch of an encode whose states were published beside it): the publishing tags (pad bytes) of the
 // n_clear states are reset, so that the column's states are the reference's bytes (256 threads stride over them)
-__global__ __launch_bounds__(256) void k_fused_finish(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear) {
+// reserve != nullptr (an UNORDERED launch, encode_lean_kernels.hip): nobody ran a look-back; the launch's bytes are what its tiles reserved
+__global__ __launch_bounds__(256) void k_fused_finish(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear,
+                                                      const uint64_t* __restrict__ reserve) {
 	if (threadIdx.x == 0) {
+		if (reserve != nullptr) {
+			const uint64_t incl = *reserve;
+			totals[4]           = totals[0] + ((incl >> 31) & 0x7FFFFFFFull) * 128ull;
+			totals[5]           = totals[1] + (incl & 0x7FFFFFFFull) * 8ull;
+		}
 		totals[0] = totals[4];
 		totals[1] = totals[5];
 		if (totals[3] != 0) { totals[6] = 1; }
@@ -611,19 +618,21 @@ int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col) {
 // async_head / async_join (with async_states): the events behind the head of the search and behind the persistent rest; the stream
 // waits for the first in front of the first encode launch, for the second in front of the LAST finish kernel, which then clears the tags
 void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
-                          uint32_t spin_limit, uint32_t async_states); // encode_lean_kernels.hip
+                          uint32_t spin_limit, uint32_t async_states, bool unordered); // encode_lean_kernels.hip
 int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
                               bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head, int kernel) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
-		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		if (hipMemsetAsync(d_workspace, 0, (lookback_words(n_tiles) + 1) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; } // (+ the unordered form's counter word)
 		if (async_states && first == v_first && async_head != nullptr) { // the head of the search (side stream) is what the first tiles need
 			if (hipStreamWaitEvent(stream, async_head, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		}
-		if (kernel == ALPGPU_ENCODE_KERNEL_LEAN) {
-			launch_k_encode_lean(stream, static_cast<unsigned>(n_tiles), d_in, col, d_workspace, first, n_launch, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u);
+		const bool      unordered = kernel == (ALPGPU_ENCODE_KERNEL_LEAN | kEncodeUnorderedFlag); // (the lean kernel only; force_stall has nothing to stall there)
+		const uint64_t* reserve   = unordered ? d_workspace + lookback_words(n_tiles) : nullptr;
+		if ((kernel & ~kEncodeUnorderedFlag) == ALPGPU_ENCODE_KERNEL_LEAN) {
+			launch_k_encode_lean(stream, static_cast<unsigned>(n_tiles), d_in, col, d_workspace, first, n_launch, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u, unordered);
 		} else {
 			hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 			                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
@@ -632,9 +641,9 @@ int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpg
 		const bool last = first + n_launch >= v_first + n_range;
 		if (async_states && last) {
 			if (hipStreamWaitEvent(stream, async_join, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
-			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(256), 0, stream, col->d_totals, col->d_rowgroups, col->n_rowgroups);
+			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(256), 0, stream, col->d_totals, col->d_rowgroups, col->n_rowgroups, reserve);
 		} else {
-			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(256), 0, stream, col->d_totals, static_cast<alpgpu_rowgroup_state*>(nullptr), 0ull);
+			hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(256), 0, stream, col->d_totals, static_cast<alpgpu_rowgroup_state*>(nullptr), 0ull, reserve);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;

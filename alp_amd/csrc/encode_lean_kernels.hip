@@ -346,7 +346,13 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 #define ALPGPU_LEAN_LATE_ARGS 1
 #endif
 
+// UNORDERED (ALPGPU_OPT_ENCODE_UNORDERED, round 5): the tile does not wait for its predecessors' sizes.  Its last-arriving wavefront reserves the
+// tile's packed / exception bytes with ONE agent-scope atomic add on a counter word behind the status words (same packing as a status word, so
+// the value that comes back IS the tile's exclusive prefix) and the look-back is not run at all.  Every vector's bytes are what the ordered form
+// writes, descriptor for descriptor; only WHERE a tile's bytes lie in the two streams follows the order in which tiles finished their analysis
+// instead of vector order (the eight vectors of a tile stay together, in order).  A decoder never notices: descriptors carry offsets.
 // (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
+template <bool UNORDERED>
 __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_lean(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                                     alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
                                                                                     uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	if (threadIdx.x == 0) {
 		s_count = 0;
 		s_ready = 0;
+		s_excl  = ~0ull;
 	}
 	__syncthreads();
 #endif
@@ -414,10 +421,13 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 #endif
 #ifndef ALPGPU_LEAN_INIT_BARRIER_FIRST
 	// the tile's two LDS words, set behind the ISSUE of the loads: the barrier that publishes them falls into the shadow of the input's round trip
-	// (no wavefront touches them before its analysis is done)
+	// (no wavefront touches them before its analysis is done).  s_excl starts as "stalled": should wavefront 0 give up on the rowgroup's state and
+	// leave, it never runs the look-back, and the wavefronts the barrier below then releases must find ~0 there, not an earlier workgroup's
+	// prefix: nothing of such a tile is written.
 	if (threadIdx.x == 0) {
 		s_count = 0;
 		s_ready = 0;
+		s_excl  = ~0ull;
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
 #endif
@@ -485,6 +495,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	ALPGPU_LEAN_STOP(4, d.base + d.bw + cnt + static_cast<int64_t>(fill_minus_base ^ ballots[0][0] ^ ballots[7][1] ^ ballots[2][1] ^ ballots[5][0]) + wide_steps);
 	uint64_t my_p = 0, my_e = 0; // bytes
 	if (live) { record_sizes<8>(d, my_p, my_e); }
+	uint64_t reserved = ~0ull; // UNORDERED: the tile's exclusive prefix, in the lane that asked for it
+	bool     reserver = false;
 	if (lane == 0) {
 		s_size[wave] = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -492,7 +504,12 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 			uint64_t aggregate = 0;
 #pragma unroll
 			for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
-			status_store(status + tile, kFlagAggregate | aggregate);
+			if constexpr (UNORDERED) {
+				reserved = __hip_atomic_fetch_add(status + lookback_words(gridDim.x), aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				reserver = true; // (the answer is looked at behind the pack and the record: one trip across the fabric in their shadow)
+			} else {
+				status_store(status + tile, kFlagAggregate | aggregate);
+			}
 		}
 	}
 	const uint64_t base_p = totals[0], base_e = totals[1];
@@ -576,7 +593,11 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 #if defined(ALPGPU_LEAN_LOOK_AHEAD) || defined(ALPGPU_LEAN_LOOK_AHEAD_EARLY)
 	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit, &look_first); }
 #else
-	if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
+	if constexpr (UNORDERED) {
+		if (reserver) { s_excl = reserved; } // (one lane of one wavefront; every wavefront of the tile had posted its size when it asked)
+	} else {
+		if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
+	}
 #endif
 	__syncthreads();
 #endif
@@ -655,9 +676,14 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 
 // the same launch sequence as launch_encode_fused_range (encode_kernels.hip) with the kernel above
 void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
-                          uint32_t spin_limit, uint32_t async_states) {
-	hipLaunchKernelGGL(k_encode_lean, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
-	                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
+                          uint32_t spin_limit, uint32_t async_states, bool unordered) {
+	if (unordered) {
+		hipLaunchKernelGGL(k_encode_lean<true>, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
+		                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
+	} else {
+		hipLaunchKernelGGL(k_encode_lean<false>, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
+		                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
+	}
 }
 
 } // namespace alpgpu

@@ -12,7 +12,8 @@ namespace alpgpu {
 constexpr int kStateUnpublished = 0xFF;
 
 // decode_kernels.hip
-int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus);
+// patch_max: ALP vectors with 1..patch_max (<= 64) exceptions are decoded without any per-value lookup and patched after their stores (0: never)
+int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max);
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg);
 int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
 // the same sinks, one wavefront per vector, packed words straight from HBM (no stage, no barrier); count = false: per-vector sums (double), true: counts (u32)
@@ -45,6 +46,9 @@ int launch_rowgroup_init_async_f32(hipStream_t stream, const float* d_in, uint64
 
 // encode_kernels.hip
 uint64_t encode_workspace_bytes(uint64_t n_vectors);
+// or-ed into `kernel` (lean kernel only): tiles reserve their bytes with one atomic add instead of waiting for their predecessors' sizes
+// (ALPGPU_OPT_ENCODE_UNORDERED; encode_lean_kernels.hip)
+constexpr int kEncodeUnorderedFlag = 0x100;
 // single pass (force_stall: debug, every look-back that has to wait gives up — exercises the recovery route)
 // kernel: ALPGPU_ENCODE_KERNEL_LEAN (encode_lean_kernels.hip: 6 KiB of LDS and <= 72 VGPRs per wavefront, three tiles per CU) or _CLASSIC (k_encode_fused)
 int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,

@@ -149,7 +149,7 @@ int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 or 2 consecutive vectors per decode
  * workgroup, or 0 (default) = choose from the column's size hints: 2 keeps twice the bytes in flight and is faster for
- * narrow columns (average packed width <= 16 bits; <= 20 bits when there are about two or more exceptions per vector: crossovers
+ * narrow columns (average packed width <= 17 bits; <= 20 bits when there are about two or more exceptions per vector that go through the mask: crossovers
  * re-measured at one-bit resolution in round 4), 1 for wider ones — every ALP_RD column — and when no hint is present.
  * 4 (double columns; round 4) = four vectors per workgroup over a 2.25 KiB stage, vectors wider than 17 bits read straight from HBM:
  * built to lift the narrow widths' floor, measured SLOWER than 2 at every width (profiles/r04_decode_floor.txt), never chosen by 0.
@@ -195,6 +195,21 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * run them from the two descriptors — 1: together when both are narrow, else one after the other; 2: as 1 with the second vector's loads issued in front
  * of the first one's unpack; 3: three vectors per two workgroups.  Same output bytes as every other shape (tests/test_decode_gpu.py). */
 #define ALPGPU_OPT_DECODE_PAIRING 8
+/* ALPGPU_OPT_DECODE_PATCH_AFTER (double store decode; round 5): an ALP vector with 1..value exceptions (value <= 64, the default; 0 = never) is unpacked
+ * and stored as if it had none — no exception mask, no per-value lookup — and its exceptions are then written over the stored values by the wavefront
+ * that stored them, the reference's own order (include/alp/decoder.hpp:141-149).  Vectors with more exceptions and ALP_RD vectors go through the
+ * mask.  Same output bytes (tests/test_decode_gpu.py runs every exception count 0..1024 both ways). */
+#define ALPGPU_OPT_DECODE_PATCH_AFTER 9
+/* ALPGPU_OPT_ENCODE_UNORDERED (double columns, ALPGPU_ENCODE_KERNEL_LEAN; round 5; default 0): 1 = alpgpu_encode_f64 / alpgpu_encode_vectors_f64 do not
+ * assign stream offsets in vector order.  Each 8-vector tile reserves its packed / exception bytes with ONE atomic add when its analysis is done,
+ * instead of waiting for the sizes of every tile before it (the ordered form's look-back).  Every vector's record — descriptor fields, packed words,
+ * exception values and positions — is byte for byte what the ordered form writes; what changes is WHERE in d_packed / d_exc a tile's records lie
+ * (tiles in the order they finished; the eight vectors of a tile stay adjacent, in order), so the two streams as a whole are a permutation of
+ * the reference's by tiles and differ from run to run.  Every decoder and consumer of this library follows the descriptors' offsets and
+ * does not care; alpgpu_column_to_blob serializes such a column as it is (alpgpu_column_from_blob's validation accepts it: records may lie
+ * anywhere inside the streams as long as they do not leave them).  The host pipeline (alpgpu_compress_host_*) always uses the ordered form.
+ * If the rowgroup search beside the encode stalls, the recovery route rewrites the column in vector order. */
+#define ALPGPU_OPT_ENCODE_UNORDERED 10
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
@@ -240,6 +255,12 @@ int alpgpu_decompress_host_multi_f32(alpgpu_ctx* const* ctxs, int n_ctx, const v
  * d_out + v * write_bytes_per_vector, stored data depending on all loaded data.  bench.py times it to put a measured ceiling for the
  * encode's read/write mix next to the nominal HBM peak. */
 int         alpgpu_debug_traffic_probe(alpgpu_ctx* ctx, const void* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector);
+/* ... and with the rowgroup search of alpgpu_encode_f64 (the search of /root/reference include/alp/encoder.hpp:139-235 and rd.hpp:89-104, over d_in, a column
+ * of doubles) running beside it on the context's second stream, launched exactly as the encode launches it; its states go to scratch->d_rowgroups
+ * (and d_rd_order).  n_vectors >= 102400 (the search runs beside the encode from 1024 rowgroups on).  write_bytes_per_vector = 0 makes either probe a
+ * read-only stream of the input.  Round 5: the measured speed of light of "the encode's bytes + the search's instructions" for bench.py. */
+int         alpgpu_debug_traffic_probe_with_search(alpgpu_ctx* ctx, const double* d_in, void* d_out, uint64_t n_vectors, uint32_t write_bytes_per_vector,
+                                                   alpgpu_column* scratch);
 /* Measurement aid, not part of the codec: alpgpu_decode_sum_f64 with the unpack arithmetic left out — the same descriptor and packed-word
  * loads into LDS, the same barrier and reduction, one double per vector written to d_out (its value means nothing).  bench.py times it
  * to say how much of the fused consumers' time is their chain of dependent loads. */

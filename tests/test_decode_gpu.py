@@ -126,3 +126,94 @@ def test_pairing_workgroups_write_the_same_bytes(ctx, oracle, pairing):
                 assert np.array_equal(got.view(np.uint64), part.view(np.uint64)), (name, pairing, len(part))
     finally:
         ctx.set_option(capi.OPT_DECODE_PAIRING, 0)
+
+
+def _alp_vectors_with_exception_counts(rng, counts, bw, placement="random"):
+    """hand-built ALP vectors (random packed words) with the given exception counts; placement: random / front (all in the first quarter) /
+    edges (quarter boundaries first: 0, 255, 256, 511, 512, 767, 768, 1023)"""
+    n = len(counts)
+    enc = dict(scheme=np.full(n, 2, np.uint8), e=np.zeros(n, np.uint8), f=np.zeros(n, np.uint8), bw=np.full(n, bw, np.uint8),
+               lbw=np.zeros(n, np.uint8), base=rng.integers(-2**40, 2**40, n), exc_cnt=np.zeros(n, np.uint16),
+               packed=np.zeros((n, 1024), np.int64), packed_left=np.zeros((n, 1024), np.uint16),
+               exc=np.zeros((n, 1024), np.float64), pos=np.zeros((n, 1024), np.uint16), dict=np.zeros((1, 8), np.uint16),
+               dict_size=np.zeros(1, np.uint8), k=np.ones(1, np.uint8), combos=np.zeros((1, 10), np.int32))
+    edges = np.array([0, 255, 256, 511, 512, 767, 768, 1023])
+    for v, c in enumerate(counts):
+        e = int(rng.integers(0, 19)); f = int(rng.integers(0, e + 1))
+        enc["e"][v], enc["f"][v] = e, f
+        enc["packed"][v, :16 * bw] = rng.integers(-2**63, 2**63 - 1, 16 * bw, dtype=np.int64)
+        if placement == "front":
+            pos = np.sort(rng.choice(256, min(c, 256), replace=False))
+            c = len(pos)
+        elif placement == "edges":
+            rest = np.setdiff1d(np.arange(1024), edges)
+            pos = np.sort(np.concatenate([edges[:min(c, 8)], rng.choice(rest, max(c - 8, 0), replace=False)]))
+        else:
+            pos = np.sort(rng.choice(1024, c, replace=False))
+        enc["exc_cnt"][v] = c
+        enc["pos"][v, :c] = pos.astype(np.uint16)
+        enc["exc"][v, :c] = rng.integers(0, 2**64, c, dtype=np.uint64).view(np.float64)  # arbitrary bit patterns incl. NaN payloads
+    return enc
+
+
+@pytest.mark.parametrize("placement", ["random", "front", "edges"])
+@pytest.mark.parametrize("bw", [0, 1, 6, 17, 33, 52])
+def test_exceptions_patched_after_the_stores_or_through_the_mask(ctx, oracle, bw, placement):
+    """ALPGPU_OPT_DECODE_PATCH_AFTER: vectors with 1..limit exceptions are stored as if they had none and patched by the wavefront that stored the
+    quarter (round 5); every limit, every launch shape, counts on both sides of every limit, positions on the quarter boundaries — the same bits
+    as the mask route (limit 0) and the oracle"""
+    from alp_amd import capi
+    rng = np.random.default_rng(7000 + bw)
+    counts = [0, 1, 2, 3, 7, 8, 9, 20, 31, 32, 33, 63, 64, 65, 100, 128, 129, 300, 1024, 1, 64, 0, 5]
+    enc = _alp_vectors_with_exception_counts(rng, counts, bw, placement)
+    want = oracle.decode_column(enc)
+    try:
+        for limit in (64, 0, 8, 32):
+            ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, limit)
+            for vpw, pairing, plain in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (4, 0, 0), (0, 1, 0), (0, 2, 0), (0, 3, 0), (1, 0, 1), (2, 0, 1)):
+                ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+                ctx.set_option(capi.OPT_DECODE_PAIRING, pairing)
+                ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, plain)
+                got = gpu_decode(ctx, enc)
+                assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (bw, placement, limit, vpw, pairing, plain)
+    finally:
+        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 64)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+        ctx.set_option(capi.OPT_DECODE_PAIRING, 0)
+        ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, 0)
+
+
+def test_patched_exceptions_on_a_full_chip(ctx, oracle):
+    """a column long enough to keep every CU busy for many waves of workgroups (store -> patch ordering under load): 40 000 narrow vectors with 20
+    exceptions each (the bench's 2 % sweep), decoded three times with each route; the patch route against the mask route bit for bit"""
+    import torch
+    from alp_amd import capi
+    rng = np.random.default_rng(99)
+    n, c, bw = 40000, 20, 3
+    enc = dict(scheme=np.full(n, 2, np.uint8), e=np.full(n, 2, np.uint8), f=np.zeros(n, np.uint8), bw=np.full(n, bw, np.uint8),
+               lbw=np.zeros(n, np.uint8), base=rng.integers(-1000, 1000, n), exc_cnt=np.full(n, c, np.uint16),
+               packed=np.zeros((n, 1024), np.int64), packed_left=np.zeros((n, 1024), np.uint16),
+               exc=np.zeros((n, 1024), np.float64), pos=np.zeros((n, 1024), np.uint16), dict=np.zeros((n // 100, 8), np.uint16),
+               dict_size=np.zeros(n // 100, np.uint8), k=np.ones(n // 100, np.uint8), combos=np.zeros((n // 100, 10), np.int32))
+    enc["packed"][:, :16 * bw] = rng.integers(-2**63, 2**63 - 1, (n, 16 * bw), dtype=np.int64)
+    pos = np.sort(np.argsort(rng.random((n, 1024)), axis=1)[:, :c], axis=1)
+    enc["pos"][:, :c] = pos.astype(np.uint16)
+    enc["exc"][:, :c] = rng.integers(0, 2**64, (n, c), dtype=np.uint64).view(np.float64)
+    rg, vec, packed, exc = layout.compact(enc)
+    col = capi.DeviceColumn.from_host(rg, vec, packed, exc)
+    try:
+        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 0)
+        ref = ctx.decode(col).clone()
+        ctx.synchronize()
+        # the mask route is the oracle's on a sample of the vectors
+        sample = {k: (a[:300] if a.shape[0] == n else a[:3]) for k, a in enc.items()}
+        assert np.array_equal(ref[:300 * 1024].cpu().numpy().view(np.uint64), oracle.decode_column(sample).view(np.uint64))
+        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 64)
+        for vpw in (0, 1, 2, 0):
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+            out = ctx.decode(col)
+            ctx.synchronize()
+            assert torch.equal(out.view(torch.int64), ref.view(torch.int64)), vpw
+    finally:
+        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 64)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)

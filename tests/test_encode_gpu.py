@@ -436,3 +436,100 @@ def test_rd_dictionary_of_one_cut_matches_the_reference_formula(ctx, dtype):
         assert chosen == bits - (1 + int(np.argmin(ests))), "find_best_dictionary takes the first strictly smaller estimate in cut order"
     with pytest.raises(capi.AlpGpuError, match="right_bit_width"):
         ctx.rd_dictionary_for_cut(d_smp, bits - 17, st, est)
+
+
+def _assert_records_tile_the_streams(vec, pb, eb, value_bytes=8):
+    """every vector's two records lie inside the streams, no two overlap, together they are the streams (no gap), and the eight vectors of a tile
+    are adjacent and in order — what ALPGPU_OPT_ENCODE_UNORDERED promises about WHERE records lie"""
+    psz, esz = layout.record_sizes(vec["scheme"], vec["bw"], vec["lbw"], vec["exc_cnt"], value_bytes)
+    assert int(psz.sum()) == pb and int(esz.sum()) == eb
+    for off, sz, total in ((vec["packed_off"].astype(np.int64), psz, pb), (vec["exc_off"].astype(np.int64), esz, eb)):
+        nz = sz > 0
+        o, s = off[nz], sz[nz]
+        order = np.argsort(o, kind="stable")
+        o, s = o[order], s[order]
+        if o.size:
+            assert o[0] == 0 and np.array_equal(o[1:], (o + s)[:-1]) and o[-1] + s[-1] == total
+    n = vec.size
+    for off, sz in ((vec["packed_off"].astype(np.int64), psz), (vec["exc_off"].astype(np.int64), esz)):
+        for w in range(1, 8):  # vector 8t + w follows vector 8t + w - 1 (launches restart the tile count every 2^20 vectors: 2^20 is a multiple of 8)
+            idx = np.arange(w, n, 8)
+            assert np.array_equal(off[idx], off[idx - 1] + sz[idx - 1])
+
+
+@pytest.mark.parametrize("name", ["mixed_1pct", "mixed_10pct", "drifting_k", "adversarial", "tiny", "rd_mix"])
+def test_unordered_encode_writes_the_same_records_somewhere_else(ctx, oracle, name):
+    """ALPGPU_OPT_ENCODE_UNORDERED: tiles reserve their bytes with one atomic add instead of the look-back.  Descriptor fields, packed words,
+    exception values and positions of EVERY vector are the oracle's; the records tile the streams without gaps or overlaps; decode gives the input"""
+    from alp_amd import capi
+    col_np = np.concatenate([datagen.mixed_column(130, seed=31), datagen.rd_column(100, seed=32), datagen.drifting_column(70, seed=33)]) if name == "rd_mix" else COLUMNS[name]()
+    want = oracle.encode_column(col_np)
+    try:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
+        dcol, x = gpu_encode(ctx, col_np)
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
+    rg, vec, packed, exc = dcol.to_host()
+    got = layout.expand(rg, vec, packed, exc)
+    assert np.array_equal(got["k"], want["k"]) and np.array_equal(got["combos"], want["combos"])
+    assert_parts_equal(got, want, name)
+    assert np.array_equal(got["packed_left"], want["packed_left"])
+    pb, eb, ov = ctx.column_totals(dcol)
+    assert ov == 0
+    _assert_records_tile_the_streams(vec, pb, eb)
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+    blob = ctx.to_blob(dcol, col_np.size)  # the container takes such a column as it is
+    back, n_values = ctx.from_blob(blob)
+    out2 = ctx.decode(back)
+    ctx.synchronize()
+    assert n_values == col_np.size and torch.equal(out2.view(torch.int64), x.view(torch.int64))
+
+
+def test_unordered_encode_of_a_large_column(ctx):
+    """1.05 Mi vectors (two chained launches, the search beside the encode, ALP_RD rowgroups in the middle): per-vector records equal the ordered
+    form's (compared through their offsets on the device), the streams are tiled, the round trip is exact; and the consumers read it"""
+    from alp_amd import capi
+    n = (1 << 20) + 4100
+    g = torch.Generator(device="cuda")
+    g.manual_seed(15)
+    x = torch.round((torch.rand(n * 1024, dtype=torch.float64, device="cuda", generator=g) - 0.5) * 2e7) / 100.0
+    m = torch.rand(n * 1024, device="cuda", generator=g) < 0.01
+    x[m] = x[m] * 3.141592653589793
+    del m
+    x[500_000 * 1024: 520_000 * 1024] = torch.rand(20_000 * 1024, dtype=x.dtype, device="cuda", generator=g)
+    ref = capi.DeviceColumn(n)
+    ctx.encode(x, ref)
+    ctx.synchronize()
+    try:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
+        col = capi.DeviceColumn(n)
+        ctx.encode(x, col)
+        ctx.synchronize()
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
+    pb, eb, ov = ctx.column_totals(col)
+    assert ov == 0 and (pb, eb) == ctx.column_totals(ref)[:2]
+    vec = col.vectors.cpu().numpy().view(capi.VECTOR_DTYPE)[:n]
+    rvec = ref.vectors.cpu().numpy().view(capi.VECTOR_DTYPE)[:n]
+    for k in ("base", "bw", "e", "f", "lbw", "exc_cnt", "scheme"):
+        assert np.array_equal(vec[k], rvec[k]), k
+    assert np.array_equal(col.rowgroups.cpu().numpy(), ref.rowgroups.cpu().numpy())
+    _assert_records_tile_the_streams(vec, pb, eb)
+    assert not np.array_equal(vec["packed_off"], rvec["packed_off"]) or n < 64  # (it IS another order on any real run; not a requirement)
+    # records byte for byte: a sample of vectors gathered from both columns by their own offsets
+    psz, esz = layout.record_sizes(vec["scheme"], vec["bw"], vec["lbw"], vec["exc_cnt"])
+    rng = np.random.default_rng(3)
+    for v in np.concatenate([np.arange(0, 64), rng.integers(0, n, 2000), np.arange(n - 64, n), np.arange(500_000 - 8, 500_000 + 8), np.arange((1 << 20) - 16, (1 << 20) + 16)]):
+        a, b, s = int(vec["packed_off"][v]), int(rvec["packed_off"][v]), int(psz[v])
+        assert torch.equal(col.packed[a:a + s], ref.packed[b:b + s]), v
+        a, b, s = int(vec["exc_off"][v]), int(rvec["exc_off"][v]), int(esz[v])
+        assert torch.equal(col.exc[a:a + s], ref.exc[b:b + s]), v
+    out = ctx.decode(col)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+    del out
+    sums_a, sums_b = ctx.decode_sum(col), ctx.decode_sum(ref)
+    ctx.synchronize()
+    assert torch.equal(sums_a.view(torch.int64), sums_b.view(torch.int64))
