@@ -37,6 +37,7 @@ struct alpgpu_ctx {
 	int         encode_unordered; // ALPGPU_OPT_ENCODE_UNORDERED: tiles reserve their stream bytes with one atomic add (lean kernel, device columns only)
 	int         decode_pairing;  // ALPGPU_OPT_DECODE_PAIRING: 0 auto, 1..3 -> k_decode_pairs
 	int         decode_pairs_auto; // the auto rule may pick the pair kernel (ALPGPU_DECODE_PAIRS_AUTO=0 for A/B runs)
+	int         decode_pad_kib;    // ALPGPU_OPT_DECODE_RESIDENCY_PAD: KiB of unused dynamic LDS per decode workgroup (-1: chosen from the column's hints)
 	int         decode_patch_max;  // ALPGPU_OPT_DECODE_PATCH_AFTER: ALP vectors with 1..this many exceptions are patched after their stores (0: never; <= 64)
 	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
@@ -130,8 +131,12 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->encode_two_pass = std::getenv("ALPGPU_ENCODE_TWO_PASS") ? 1 : 0;
 	ctx->force_stall     = 0;
 	ctx->pipelined_consumer = 0;
-	ctx->decode_pairs_auto = std::getenv("ALPGPU_DECODE_PAIRS_AUTO") ? std::atoi(std::getenv("ALPGPU_DECODE_PAIRS_AUTO")) : 1;
-	ctx->decode_patch_max   = std::getenv("ALPGPU_DECODE_PATCH_AFTER") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_AFTER")) : 64; // (A/B runs)
+	// (round 5: 0.  With the per-vector loops k_decode_column<2> is 10-20 % ahead of k_decode_pairs on narrow vectors with exceptions: profiles/r05_decode_exceptions.txt)
+	ctx->decode_pairs_auto = std::getenv("ALPGPU_DECODE_PAIRS_AUTO") ? std::atoi(std::getenv("ALPGPU_DECODE_PAIRS_AUTO")) : 0;
+	ctx->decode_pad_kib     = std::getenv("ALPGPU_DECODE_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_PAD_LDS_KIB")) & 0xFF : -1;
+	// the patch arm exists in -DALPGPU_DECODE_PATCH_MODE=1 / 2 builds of decode_kernels.hip only (measured slower than the mask route: profiles/r05_decode_exceptions.txt);
+	// the default build ignores the limit, and the launch rule must not count on an arm that is not there: 0 unless asked for
+	ctx->decode_patch_max   = std::getenv("ALPGPU_DECODE_PATCH_AFTER") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_AFTER")) : 0; // (A/B runs)
 	if (ctx->decode_patch_max < 0 || ctx->decode_patch_max > 64) { ctx->decode_patch_max = 64; }
 	ctx->decode_patch_shape = std::getenv("ALPGPU_DECODE_PATCH_SHAPE") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_SHAPE")) : 1;
 	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
@@ -215,6 +220,10 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_ENCODE_KERNEL:
 		if (value != ALPGPU_ENCODE_KERNEL_LEAN && value != ALPGPU_ENCODE_KERNEL_CLASSIC) { return fail(ALPGPU_ERR_INVALID, "encode kernel: 0 (lean) or 1 (classic)"); }
 		ctx->encode_kernel = static_cast<int>(value);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_RESIDENCY_PAD:
+		if (value < -1 || value > 150) { return fail(ALPGPU_ERR_INVALID, "decode residency pad: -1 (by the library's rule) or 0..150 KiB"); }
+		ctx->decode_pad_kib = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_UNORDERED:
 		ctx->encode_unordered = value ? 1 : 0;
@@ -472,7 +481,7 @@ static bool column_decodes_with_exceptions(const alpgpu_ctx* ctx, const alpgpu_c
 	const double n = static_cast<double>(col->n_vectors);
 	const double e = static_cast<double>(col->exc_bytes_hint);
 	if (e < 16.0 * n) { return false; }
-	if (ctx->decode_patch_shape && ctx->decode_patch_max > 0 && e <= 5.0 * static_cast<double>(ctx->decode_patch_max) * n) { return false; }
+	if (ctx->decode_patch_shape && ctx->decode_patch_max > 0 && e <= 5.0 * static_cast<double>(ctx->decode_patch_max) * n) { return false; } // (builds with a patch arm only: decode_patch_max is 0 otherwise)
 	return true;
 }
 
@@ -488,7 +497,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		// kNarrowAutoBits bits FOUR vectors share a workgroup over the narrow stage (round 4).
 		const bool   with_exc = column_decodes_with_exceptions(ctx, col);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * (n > 0 ? n : 1.0));
-		const bool   narrow   = bits <= (with_exc ? 20.0 : 17.5); // (17.5: with the residency caps below two vectors per workgroup win through 17 bits)
+		const bool   narrow   = bits <= (with_exc ? 22.0 : 17.5); // (17.5: with the residency caps below two vectors per workgroup win through 17 bits; with exceptions through 22: round 5)
 		const double four_max = with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits; // (0 = never: the four-vector shape lost at every width, it is chosen by tuning runs only)
 		const bool   four     = four_max > 0.0 && bits <= four_max;
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
@@ -504,22 +513,30 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	// Residency by width (decode_kernels.hip: launch_decode_column; unused dynamic LDS): what a CU wants is a certain amount of bytes in flight, not a
 	// certain number of workgroups.  One vector per workgroup: eight workgroups per CU up to 33 bits, seven up to 35, six beyond; seven for ALP_RD
 	// columns.  Two vectors per workgroup: eight / seven / six workgroups by width.  ALPGPU_DECODE_PAD_LDS_KIB overrides (A/B runs; 0 = never cap).
-	static const int pad_env = std::getenv("ALPGPU_DECODE_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_PAD_LDS_KIB")) & 0xFF : -1;
+	const int pad_env = ctx->decode_pad_kib; // ALPGPU_OPT_DECODE_RESIDENCY_PAD / ALPGPU_DECODE_PAD_LDS_KIB: -1 = by the rule below
 	int pad_kib = pad_env >= 0 ? pad_env : 0;
 	if (pad_env < 0 && ctx->decode_auto && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
 		const double n        = static_cast<double>(col->n_vectors);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
 		const bool   with_exc = column_decodes_with_exceptions(ctx, col);
 		const bool   mostly_rd = col->alp_rd_rowgroups_hint != 0 && 2.0 * static_cast<double>(col->alp_rd_rowgroups_hint - 1) * 100.0 > n;
+		// (re-measured in round 5 with the per-vector decode loops — a workgroup's stores no longer wait for one another, workgroups live shorter and a CU
+		//  wants somewhat fewer of them: tools/r05_decode_resid.py, profiles/r05_decode_exceptions.txt)
 		if ((variant & 5) == 1) {
-			// one vector per workgroup (measured, tools/sweep_residency_rule.py: without exceptions +7-9 % from 34 bits on — seven at 34-35, six beyond; with ~2 % exceptions the
-			// cap pays from ~42 bits on only; ALP_RD columns — more arithmetic per value — sit between: seven)
-			pad_kib = mostly_rd ? 11 : (with_exc ? (bits >= 41.5 ? 14 : 0) : (bits >= 35.5 ? 14 : (bits >= 33.5 ? 11 : 0)));
+			// one vector per workgroup: up to ~30 bits a 6 KiB pad (ten workgroups' worth of LDS for eight: 0.77-0.80 -> 0.79-0.81, with exceptions
+			// 0.75-0.79 -> 0.78-0.82 up to 38 bits); 30-38 bits without exceptions none; from 38 bits on seven, then six workgroups per CU
+			// (+5-7 %); ALP_RD columns — more arithmetic per value — seven
+			if (mostly_rd) {
+				pad_kib = 11;
+			} else if (with_exc) {
+				pad_kib = bits >= 46.0 ? 14 : (bits >= 38.0 ? 11 : 6);
+			} else {
+				pad_kib = bits >= 38.0 ? 14 : (bits >= 30.0 ? 0 : 6);
+			}
 		} else if ((variant & 5) == 0 && !with_exc) {
-			// two vectors per workgroup, no exceptions (tools/sweep_residency.py with SWEEP_VPW=2): sixteen vectors in flight per CU up to 8 bits,
-			// fourteen (seven workgroups) for 9-11, twelve (six) for 12-17: 0.69-0.72 -> 0.75-0.78 of the HBM peak on 10-17 bits.  With exceptions the
-			// caps lose.
-			pad_kib = bits > 11.5 ? 6 : (bits > 8.5 ? 3 : 0);
+			// two vectors per workgroup, no exceptions: sixteen vectors in flight per CU up to 8 bits, fourteen (seven workgroups) beyond.  With
+			// exceptions the caps lose.
+			pad_kib = bits > 8.5 ? 3 : 0;
 		}
 	}
 	return (variant & 7) | (pairing << 3) | (pad_kib << 8);

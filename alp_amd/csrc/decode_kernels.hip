@@ -274,6 +274,102 @@ struct BufferWords { // HBM through buffer loads: the resources are sized to the
 	}
 };
 
+// ---- exceptions patched AFTER the stores (round 5; the reference's own order: decode everything, then scatter, decoder.hpp:141-149) ---------------
+// An ALP vector with a few exceptions is decoded as if it had none — no mask, no prefix, no per-value lookup (the +60 % vector instructions of
+// profiles/r01_pmc_sq_decode_exceptions.txt) — and its exceptions are then written over the freshly stored values: exception j (positions ascend, so
+// j is also its rank) by lane j of the wavefront that OWNS the quarter the position lies in, i.e. the same wavefront that stored that quarter a few
+// instructions earlier.  A wavefront's vector stores reach memory in issue order (both go down the same L1 queue to the same L2 channel, same cache
+// policy), so the 8-byte patch lands on the 16-byte store it overlaps; no barrier, no fence, no LDS.  Position and value are loaded (2 + 8 bytes
+// per lane, straight from the record) together with the packed words and wait in two / three registers.  Vectors with more exceptions than
+// `patch_max` (a kernel argument, <= 64: one lane each; 0 switches the arm off) and ALP_RD vectors (their exceptions replace the LEFT part only:
+// the patched double needs the right part the lane no longer has) take the mask route below.  -DALPGPU_DECODE_PATCH_FENCE: s_waitcnt vmcnt(0)
+// between a wavefront's stores and its patches (the conservative form, for A/B runs).
+struct PatchRegs {
+	uint32_t pos;
+	uint64_t val;
+};
+__device__ __forceinline__ bool vector_patches_after(const alpgpu_vector_desc& d, uint32_t patch_max) { // wave-uniform
+	return d.scheme == ALPGPU_SCHEME_ALP && d.exc_cnt != 0 && static_cast<uint32_t>(d.exc_cnt) <= patch_max;
+}
+__device__ __forceinline__ PatchRegs issue_patch_loads(const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, int lane) {
+	PatchRegs   r {0u, 0ull};
+	const int   cnt = d.exc_cnt;
+	if (lane < cnt) {
+		r.val = reinterpret_cast<const uint64_t*>(rec)[lane];
+		r.pos = reinterpret_cast<const uint16_t*>(rec + 8u * static_cast<uint32_t>(cnt))[lane];
+	}
+	return r;
+}
+template <bool NT_STORE>
+__device__ __forceinline__ void apply_patches(const PatchRegs& r, int cnt, double* __restrict__ out_vec, int wave, int lane) {
+#ifdef ALPGPU_DECODE_PATCH_FENCE
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	if (lane < cnt && static_cast<int>(r.pos >> 8) == wave) { // this wavefront stored values 256 wave .. 256 wave + 255 (steps 2 wave, 2 wave + 1)
+		const double x = __longlong_as_double(static_cast<long long>(r.val));
+#if defined(ALPGPU_DECODE_PATCH_NO_STORE) // timing experiment (wrong output): what the patch stores themselves cost
+		asm volatile("" ::"v"(x), "v"(out_vec + r.pos));
+#elif defined(ALPGPU_DECODE_PATCH_PLAIN) // A/B: the patch as an ordinary store whatever the vector's own stores are
+		out_vec[r.pos] = x;
+#else
+		if constexpr (NT_STORE) {
+			__builtin_nontemporal_store(x, out_vec + r.pos);
+		} else {
+			out_vec[r.pos] = x;
+		}
+#endif
+	}
+}
+__device__ __forceinline__ alpgpu_vector_desc without_exceptions(alpgpu_vector_desc d) {
+	d.exc_cnt = 0;
+	return d;
+}
+// ALPGPU_DECODE_PATCH_MODE 1: as described above (a second, 8-byte store per exception).  2: the exceptions are put in their places IN REGISTERS, in
+// front of the one store: each wavefront keeps a 256-byte slot table in LDS (its quarter of the vector's exception stage: byte i = 1 + the index of
+// the exception at position 256 wave + i, 0 = none; zeroed behind the issue of the loads, filled once position and value have arrived), a lane reads
+// the two bytes of its pair per step, and a hit fetches the value from the lane that holds it (exception j sits in lane j: ds_bpermute).  No
+// partial-line write reaches HBM; no rank, no prefix, no mask.
+// 0 (the default build since the measurement below): no patch arm is compiled in and `patch_max` is ignored.  Round 5's result (profiles/
+// r05_decode_exceptions.txt): once the stores of a wavefront no longer wait for one another (ExcMode below), the mask route itself is 5-10 % FASTER
+// than it was, mode 1 is slower than it at every width (its 8-byte stores reach HBM as read-modify-writes of lines the L2 has already let go:
+// +20-30 % time on narrow vectors), mode 2 equals it on wide vectors and loses 5-10 % on narrow ones — and the mere presence of either arm's
+// code and registers costs the two-vectors-per-workgroup kernel 8 % on exception-free columns of 3-6 bits.
+#ifndef ALPGPU_DECODE_PATCH_MODE
+#define ALPGPU_DECODE_PATCH_MODE 0
+#endif
+template <class LDS>
+__device__ __forceinline__ void patch_table_zero(LDS& L, int wave, int lane) {
+	reinterpret_cast<uint32_t*>(L.excv)[64 * wave + lane] = 0u;
+}
+template <class LDS>
+__device__ __forceinline__ void patch_table_fill(LDS& L, const PatchRegs& r, int cnt, int wave, int lane) { // (behind the barrier that follows the loads)
+	if (lane < cnt && static_cast<int>(r.pos >> 8) == wave) { L.excv[256 * wave + (r.pos & 255u)] = static_cast<uint8_t>(lane + 1); }
+	wave_lds_sync();
+}
+// the pair of step m of this wavefront's quarter: exceptions (if any) over the decoded values
+template <class LDS>
+__device__ __forceinline__ void patch_pair_from_table(const LDS& L, const PatchRegs& r, int m, int wave, int lane, double& ox, double& oy) {
+	const uint32_t t = reinterpret_cast<const uint16_t*>(L.excv)[128 * wave + 64 * (m & (kStepsPerWave - 1)) + lane];
+	if (ballot64(t != 0u) != 0) { // wave-uniform: some lane's pair of this step holds an exception
+		const int i0 = static_cast<int>(t & 255u) - 1, i1 = static_cast<int>(t >> 8) - 1;
+		const int lo = static_cast<int>(static_cast<uint32_t>(r.val)), hi = static_cast<int>(static_cast<uint32_t>(r.val >> 32));
+		const uint64_t v0 = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * (i0 < 0 ? 0 : i0), hi))) << 32) |
+		                    static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * (i0 < 0 ? 0 : i0), lo));
+		const uint64_t v1 = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * (i1 < 0 ? 0 : i1), hi))) << 32) |
+		                    static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * (i1 < 0 ? 0 : i1), lo));
+		ox = i0 >= 0 ? __longlong_as_double(static_cast<long long>(v0)) : ox;
+		oy = i1 >= 0 ? __longlong_as_double(static_cast<long long>(v1)) : oy;
+	}
+}
+
+template <int V>
+struct ExcMode {
+	static constexpr int value = V;
+};
+template <int A> // 0: the literal arithmetic, 1: the IEEE-product shortcut on 64-bit fields, 2: the same on fields of <= 32 bits (32-bit unpack)
+struct ArithShortcut {
+	static constexpr int value = A;
+};
 // N_Q consecutive quarters of one vector, from quarter q0 on (a quarter = steps kStepsPerWave q .. + kStepsPerWave - 1 = what one wavefront of a
 // four-wavefront workgroup does; the sinks accumulate quarter q0 + i into acc[i]).  `em` = the vector's exception mask as this wavefront sees
 // it (ignored when the vector has none), L = where staged exception values live.
@@ -281,7 +377,9 @@ struct BufferWords { // HBM through buffer loads: the resources are sized to the
 template <bool NT_STORE, int SINK, int N_Q, int ONLY = 0, class LDS, class WORDS>
 __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS& units, const alpgpu_vector_desc& d, const VectorConsts& dict, const ExcMask& em,
                                                       const uint8_t* __restrict__ rec, double2* __restrict__ dst, int q0, int lane, double* acc,
-                                                       double range_lo, double range_hi) {
+                                                       double range_lo, double range_hi, bool use_patch = false, PatchRegs patch = PatchRegs {0u, 0ull}) {
+	// use_patch (ALPGPU_DECODE_PATCH_MODE 2; ALP store decode, one quarter per wavefront: q0 = the wavefront): d is the vector without its
+	// exceptions, which are looked up in the wavefront's slot table instead (patch_pair_from_table)
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
 	const bool     all_staged = cnt <= static_cast<int>(kExcStageBytes) / (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2); // wave-uniform
@@ -321,25 +419,49 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 		// |lo| <= bound first: lo + mask cannot overflow then (mask < 2^50); lo <= lo + mask, so the two ends bound everything between
 		const bool     shortcut = bw <= 50 && lo >= -bound && lo <= bound && static_cast<int64_t>(static_cast<uint64_t>(lo) + mask) <= bound;
 		const uint64_t kbits   = 0x4338000000000000ull + base;
-		// what follows the conversion of a pair: exceptions patched in, then the sink
-		auto finish_pair = [&](int m, double ox, double oy, double* acc_q) {
-			if (cnt > 0) {
+		// what follows the conversion of a pair: exceptions patched in, then the sink.
+		// EXC (compile time): 0 = the vector has no exceptions: nothing is looked up; 1 = it has some and all of their values are staged in LDS: no
+		// memory load anywhere in the loop; 2 = decided per step at run time (cnt > 0, staged or not) — the form every caller had until round 5.
+		// Why the first two exist (round 5): with the rare "value beyond the stage -> load it from HBM" arm inside the loop the compiler places
+		// s_waitcnt vmcnt(0) at the join in front of EVERY step's store — on gfx9 stores count in vmcnt, so each store of a wavefront waited for
+		// the acknowledgement of the one before it, exceptions or not — and every step was a basic block of its own.  The store decode now picks
+		// the loop per vector (wave-uniform); the sinks (register budgets tuned around the old form) stay on 2.
+		auto finish_pair = [&](auto exc_mode, int m, double ox, double oy, double* acc_q) {
+			constexpr int EXC = decltype(exc_mode)::value;
+			if constexpr (SINK == kSinkStore && N_Q == 1 && ALPGPU_DECODE_PATCH_MODE == 2) {
+				if (use_patch) { patch_pair_from_table(L, patch, m, q0, lane, ox, oy); } // (wave-uniform)
+			}
+			if (EXC == 1 || (EXC == 2 && cnt > 0)) {
+				const bool     staged = EXC == 1 ? true : all_staged;
 				int            rank;
 				uint32_t       hits;
 				if constexpr (LDS::kPrefixInLds) { hits = exception_hits_lds(L, m, lane, rank); } else { hits = exception_hits(em, m, lane, rank); }
 				if (hits & 1u) {
-					ox = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, all_staged)));
+					ox = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, staged)));
 					++rank;
 				}
-				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, all_staged))); }
+				if (hits & 2u) { oy = __longlong_as_double(static_cast<long long>(fetch_exception<8>(L, rec, rank, staged))); }
 			}
 			if constexpr (SINK != kSinkStore) {
 				consume_pair<SINK>(ox, oy, acc_q, range_lo, range_hi);
 			} else {
+#ifdef ALPGPU_DECODE_STORE_WAIT // A/B: every store waits for the one before it, as every build did until round 5 (see above)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
 			}
 		};
-		if (shortcut) { // wave-uniform; ONE branch per vector, not one per step (scalar instructions are the scarce ones here)
+		// ArithShortcut<2> (round 5; the store decode's vectors of <= 32 bits on the shortcut route — narrow vectors are bound by their vector
+		// instructions, not by HBM: profiles/r05_decode_exceptions.txt): the field lies in three of the four dwords of its two stream words and
+		// comes out with ONE 32-bit funnel shift (v_alignbit_b32; the amount is taken modulo 32) where the 64-bit form takes three 64-bit shifts;
+		// and (double)(base + digit) is the double whose bits are {0x43380000, digit} = M + digit (M = 2^52 + 2^51) minus the wave-uniform double
+		// M - base, whose bits are bits(M) - base (scalar integer arithmetic; |base| < 2^51 is the shortcut's condition) — every quantity an
+		// integer below 2^53, the difference exact — one v_add_f64 where the 64-bit form adds the base in integers (two instructions) first.
+		// The same value, hence the same bits, as ArithShortcut<1>: 7 vector instructions per value instead of 13.
+		const uint32_t mask32   = static_cast<uint32_t>(mask);
+		const double   magic_mb = __longlong_as_double(static_cast<long long>(0x4338000000000000ull - static_cast<uint64_t>(lo))); // M - base
+		auto alp_steps = [&](auto exc_mode, auto shortcut_arith) {
+			constexpr int SHORT = static_cast<int>(decltype(shortcut_arith)::value);
 #pragma unroll
 			for (int b = 0; b < kSteps; b += kBatch) {
 				WordPair w[kBatch];
@@ -348,25 +470,53 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 #pragma unroll
 				for (int i = 0; i < kBatch; ++i) {
 					const int     m = kStepsPerWave * q0 + b + i;
+					if constexpr (SHORT == 2) {
+						const uint32_t sft = static_cast<uint32_t>((8 * m + r0) * bw) & 63u;
+						const bool     low = sft < 32u; // the field begins in the first dword of word k (else in the second; it ends at most one dword later)
+						const uint32_t x0 = static_cast<uint32_t>(w[i].w0.x), x1 = static_cast<uint32_t>(w[i].w0.x >> 32), x2 = static_cast<uint32_t>(w[i].w1.x);
+						const uint32_t y0 = static_cast<uint32_t>(w[i].w0.y), y1 = static_cast<uint32_t>(w[i].w0.y >> 32), y2 = static_cast<uint32_t>(w[i].w1.y);
+						const uint32_t ux = __builtin_amdgcn_alignbit(low ? x1 : x2, low ? x0 : x1, sft) & mask32;
+						const uint32_t uy = __builtin_amdgcn_alignbit(low ? y1 : y2, low ? y0 : y1, sft) & mask32;
+						const double   dx = __longlong_as_double(static_cast<long long>(0x4338000000000000ull | ux)) - magic_mb;
+						const double   dy = __longlong_as_double(static_cast<long long>(0x4338000000000000ull | uy)) - magic_mb;
+						finish_pair(exc_mode, m, (dx * fact_d) * frac, (dy * fact_d) * frac, acc + (b + i) / kStepsPerWave);
+						continue;
+					}
 					const U64Pair u = extract(bw, mask, 8 * m + r0, w[i]);
-					finish_pair(m, ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac,
-					            ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac, acc + (b + i) / kStepsPerWave);
+					if constexpr (SHORT == 1) {
+						finish_pair(exc_mode, m, ((__longlong_as_double(static_cast<long long>(u.x + kbits)) - kMagic) * fact_d) * frac,
+						            ((__longlong_as_double(static_cast<long long>(u.y + kbits)) - kMagic) * fact_d) * frac, acc + (b + i) / kStepsPerWave);
+					} else {
+						finish_pair(exc_mode, m, decode_value(static_cast<int64_t>(u.x + base), fact, frac), decode_value(static_cast<int64_t>(u.y + base), fact, frac),
+						            acc + (b + i) / kStepsPerWave);
+					}
 				}
+			}
+		};
+		constexpr bool kPerVectorLoops = SINK == kSinkStore && N_Q == 1;
+#ifdef ALPGPU_DECODE_NO_NARROW_ARITH // A/B: without the 32-bit form
+		const bool narrow32 = false;
+#else
+		const bool narrow32 = kPerVectorLoops && bw <= 32;
+#endif
+		if (shortcut) { // wave-uniform; ONE branch per vector, not one per step (scalar instructions are the scarce ones here)
+			if (kPerVectorLoops && cnt == 0) {
+				if (narrow32) {
+					alp_steps(ExcMode<0> {}, ArithShortcut<2> {});
+				} else {
+					alp_steps(ExcMode<0> {}, ArithShortcut<1> {});
+				}
+			} else if (kPerVectorLoops && all_staged) {
+				if (narrow32) {
+					alp_steps(ExcMode<1> {}, ArithShortcut<2> {});
+				} else {
+					alp_steps(ExcMode<1> {}, ArithShortcut<1> {});
+				}
+			} else {
+				alp_steps(ExcMode<2> {}, ArithShortcut<1> {});
 			}
 		} else {
-#pragma unroll
-			for (int b = 0; b < kSteps; b += kBatch) {
-				WordPair w[kBatch];
-#pragma unroll
-				for (int i = 0; i < kBatch; ++i) { w[i] = request(bw, 8 * (kStepsPerWave * q0 + b + i) + r0); }
-#pragma unroll
-				for (int i = 0; i < kBatch; ++i) {
-					const int     m = kStepsPerWave * q0 + b + i;
-					const U64Pair u = extract(bw, mask, 8 * m + r0, w[i]);
-					finish_pair(m, decode_value(static_cast<int64_t>(u.x + base), fact, frac), decode_value(static_cast<int64_t>(u.y + base), fact, frac),
-					            acc + (b + i) / kStepsPerWave);
-				}
-			}
+			alp_steps(ExcMode<2> {}, ArithShortcut<0> {});
 		}
 	} else {
 		// ALP_RD: right parts = u64 lanes (bw = rbw, base 0); left parts = u16 lanes, 64 streams x 16 rows (value i ->
@@ -377,49 +527,61 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 		const uint64_t mask = bw_mask(rbw);
 		const uint32_t lmsk = (1u << lbw) - 1u;
 		const uint64_t dlo = dict.lo, dhi = dict.hi;
+		auto rd_steps = [&](auto exc_mode) {
+			constexpr int EXC = decltype(exc_mode)::value; // as in the ALP arm
 #pragma unroll
-		for (int b = 0; b < kSteps; b += kBatchRd) {
-		WordPair rw[kBatchRd];
-		uint2    lw[kBatchRd];
+			for (int b = 0; b < kSteps; b += kBatchRd) {
+				WordPair rw[kBatchRd];
+				uint2    lw[kBatchRd];
 #pragma unroll
-		for (int i = 0; i < kBatchRd; ++i) {
-			const int m = kStepsPerWave * q0 + b + i;
-			rw[i]       = request(rbw, 8 * m + r0);
-			lw[i]       = units.left_pair(rbw, 32 * (((2 * m + (lane >> 5)) * lbw) >> 4) + (lane & 31));
-		}
-#pragma unroll
-		for (int i = 0; i < kBatchRd; ++i) {
-			const int      m   = kStepsPerWave * q0 + b + i;
-			double*        acc_q = acc + (b + i) / kStepsPerWave;
-			U64Pair        u   = extract(rbw, mask, 8 * m + r0, rw[i]);
-			if constexpr (ONLY == 2) { asm volatile("" : "+v"(u.x), "+v"(u.y)); } // (k_sink_direct) the right parts extracted HERE: their four words die before the left parts' work begins
-			const int      s   = ((2 * m + (lane >> 5)) * lbw) & 15;
-			const uint32_t w0 = lw[i].x, w1 = lw[i].y;
-			const uint32_t i0  = (((w0 & 0xFFFFu) >> s) | ((w1 & 0xFFFFu) << (16 - s))) & lmsk;
-			const uint32_t i1  = (((w0 >> 16) >> s) | ((w1 >> 16) << (16 - s))) & lmsk;
-			uint64_t       l0  = ((i0 < 4 ? dlo >> (16 * i0) : dhi >> (16 * (i0 & 3))) & 0xFFFFull);
-			uint64_t       l1  = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
-			if (cnt > 0) {
-				int            rank;
-				uint32_t       hits;
-				if constexpr (LDS::kPrefixInLds) { hits = exception_hits_lds(L, m, lane, rank); } else { hits = exception_hits(em, m, lane, rank); }
-				if (hits & 1u) {
-					l0 = fetch_exception<2>(L, rec, rank, all_staged);
-					++rank;
+				for (int i = 0; i < kBatchRd; ++i) {
+					const int m = kStepsPerWave * q0 + b + i;
+					rw[i]       = request(rbw, 8 * m + r0);
+					lw[i]       = units.left_pair(rbw, 32 * (((2 * m + (lane >> 5)) * lbw) >> 4) + (lane & 31));
 				}
-				if (hits & 2u) { l1 = fetch_exception<2>(L, rec, rank, all_staged); }
-			}
-			const double ox = __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x));
-			const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
-			if constexpr (SINK != kSinkStore) {
-				consume_pair<SINK>(ox, oy, acc_q, range_lo, range_hi);
-				if constexpr (ONLY == 2) { asm volatile("" : "+v"(*acc_q)); } // ... and the pair added HERE: left to itself the compiler keeps all sixteen results for the end (208 bytes of scratch, 3.7 x the time)
-			} else {
-				store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
-			}
+#pragma unroll
+				for (int i = 0; i < kBatchRd; ++i) {
+					const int      m   = kStepsPerWave * q0 + b + i;
+					double*        acc_q = acc + (b + i) / kStepsPerWave;
+					U64Pair        u   = extract(rbw, mask, 8 * m + r0, rw[i]);
+					if constexpr (ONLY == 2) { asm volatile("" : "+v"(u.x), "+v"(u.y)); } // (k_sink_direct) the right parts extracted HERE: their four words die before the left parts' work begins
+					const int      s   = ((2 * m + (lane >> 5)) * lbw) & 15;
+					const uint32_t w0 = lw[i].x, w1 = lw[i].y;
+					const uint32_t i0  = (((w0 & 0xFFFFu) >> s) | ((w1 & 0xFFFFu) << (16 - s))) & lmsk;
+					const uint32_t i1  = (((w0 >> 16) >> s) | ((w1 >> 16) << (16 - s))) & lmsk;
+					uint64_t       l0  = ((i0 < 4 ? dlo >> (16 * i0) : dhi >> (16 * (i0 & 3))) & 0xFFFFull);
+					uint64_t       l1  = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
+					if (EXC == 1 || (EXC == 2 && cnt > 0)) {
+						const bool     staged = EXC == 1 ? true : all_staged;
+						int            rank;
+						uint32_t       hits;
+						if constexpr (LDS::kPrefixInLds) { hits = exception_hits_lds(L, m, lane, rank); } else { hits = exception_hits(em, m, lane, rank); }
+						if (hits & 1u) {
+							l0 = fetch_exception<2>(L, rec, rank, staged);
+							++rank;
+						}
+						if (hits & 2u) { l1 = fetch_exception<2>(L, rec, rank, staged); }
+					}
+					const double ox = __longlong_as_double(static_cast<long long>((l0 << rbw) | u.x));
+					const double oy = __longlong_as_double(static_cast<long long>((l1 << rbw) | u.y));
+					if constexpr (SINK != kSinkStore) {
+						consume_pair<SINK>(ox, oy, acc_q, range_lo, range_hi);
+						if constexpr (ONLY == 2) { asm volatile("" : "+v"(*acc_q)); } // ... and the pair added HERE: left to itself the compiler keeps all sixteen results for the end (208 bytes of scratch, 3.7 x the time)
+					} else {
+						store_pair<NT_STORE>(dst + 64 * m + lane, ox, oy);
+					}
+				}
+				if constexpr (ONLY == 2) { asm volatile("" ::: "memory"); } // (k_sink_direct) the next step's requests stay behind this one's use
+			} // batch
+		};
+		constexpr bool kPerVectorLoops = SINK == kSinkStore && N_Q == 1;
+		if (kPerVectorLoops && cnt == 0) {
+			rd_steps(ExcMode<0> {});
+		} else if (kPerVectorLoops && all_staged) {
+			rd_steps(ExcMode<1> {});
+		} else {
+			rd_steps(ExcMode<2> {});
 		}
-		if constexpr (ONLY == 2) { asm volatile("" ::: "memory"); } // (k_sink_direct) the next step's requests stay behind this one's use
-		} // batch
 	}
 }
 
@@ -427,55 +589,10 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 template <bool NT_STORE, int SINK = kSinkStore, class LDS = DecodeLds>
 __device__ __forceinline__ void decode_staged_vector(const LDS& L, const alpgpu_vector_desc& d, const VectorConsts& dict,
                                                      const uint8_t* __restrict__ rec, double2* __restrict__ dst, int wave, int lane, double* acc = nullptr,
-                                                     double range_lo = 0.0, double range_hi = 0.0) {
+                                                     double range_lo = 0.0, double range_hi = 0.0, bool use_patch = false, PatchRegs patch = PatchRegs {0u, 0ull}) {
 	ExcMask em {0u, 0};
 	if (d.exc_cnt > 0) { em = load_exception_mask(L, lane); }
-	decode_vector_quarters<NT_STORE, SINK, 1>(L, StagedWords {L.stage}, d, dict, em, rec, dst, wave, lane, acc, range_lo, range_hi);
-}
-
-// ---- exceptions patched AFTER the stores (round 5; the reference's own order: decode everything, then scatter, decoder.hpp:141-149) ---------------
-// An ALP vector with a few exceptions is decoded as if it had none — no mask, no prefix, no per-value lookup (the +60 % vector instructions of
-// profiles/r01_pmc_sq_decode_exceptions.txt) — and its exceptions are then written over the freshly stored values: exception j (positions ascend, so
-// j is also its rank) by lane j of the wavefront that OWNS the quarter the position lies in, i.e. the same wavefront that stored that quarter a few
-// instructions earlier.  A wavefront's vector stores reach memory in issue order (both go down the same L1 queue to the same L2 channel, same cache
-// policy), so the 8-byte patch lands on the 16-byte store it overlaps; no barrier, no fence, no LDS.  Position and value are loaded (2 + 8 bytes
-// per lane, straight from the record) together with the packed words and wait in two / three registers.  Vectors with more exceptions than
-// `patch_max` (a kernel argument, <= 64: one lane each; 0 switches the arm off) and ALP_RD vectors (their exceptions replace the LEFT part only:
-// the patched double needs the right part the lane no longer has) take the mask route below.  -DALPGPU_DECODE_PATCH_FENCE: s_waitcnt vmcnt(0)
-// between a wavefront's stores and its patches (the conservative form, for A/B runs).
-struct PatchRegs {
-	uint32_t pos;
-	uint64_t val;
-};
-__device__ __forceinline__ bool vector_patches_after(const alpgpu_vector_desc& d, uint32_t patch_max) { // wave-uniform
-	return d.scheme == ALPGPU_SCHEME_ALP && d.exc_cnt != 0 && static_cast<uint32_t>(d.exc_cnt) <= patch_max;
-}
-__device__ __forceinline__ PatchRegs issue_patch_loads(const alpgpu_vector_desc& d, const uint8_t* __restrict__ rec, int lane) {
-	PatchRegs   r {0u, 0ull};
-	const int   cnt = d.exc_cnt;
-	if (lane < cnt) {
-		r.val = reinterpret_cast<const uint64_t*>(rec)[lane];
-		r.pos = reinterpret_cast<const uint16_t*>(rec + 8u * static_cast<uint32_t>(cnt))[lane];
-	}
-	return r;
-}
-template <bool NT_STORE>
-__device__ __forceinline__ void apply_patches(const PatchRegs& r, int cnt, double* __restrict__ out_vec, int wave, int lane) {
-#ifdef ALPGPU_DECODE_PATCH_FENCE
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-	if (lane < cnt && static_cast<int>(r.pos >> 8) == wave) { // this wavefront stored values 256 wave .. 256 wave + 255 (steps 2 wave, 2 wave + 1)
-		const double x = __longlong_as_double(static_cast<long long>(r.val));
-		if constexpr (NT_STORE) {
-			__builtin_nontemporal_store(x, out_vec + r.pos);
-		} else {
-			out_vec[r.pos] = x;
-		}
-	}
-}
-__device__ __forceinline__ alpgpu_vector_desc without_exceptions(alpgpu_vector_desc d) {
-	d.exc_cnt = 0;
-	return d;
+	decode_vector_quarters<NT_STORE, SINK, 1>(L, StagedWords {L.stage}, d, dict, em, rec, dst, wave, lane, acc, range_lo, range_hi, use_patch, patch);
 }
 
 // Issues every load of one vector: packed words and the values of its exceptions straight into LDS (global_load_lds, 16 resp. 4 bytes per
@@ -560,10 +677,13 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	PatchRegs pr[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
-		patched[i] = SINK == kSinkStore && vector_patches_after(d[i], patch_max); // workgroup-uniform
+		patched[i] = ALPGPU_DECODE_PATCH_MODE != 0 && SINK == kSinkStore && vector_patches_after(d[i], patch_max); // workgroup-uniform
 		pos[i]     = issue_vector_loads(L[i], d[i], packed, excs + d[i].exc_off, tid, wave, patched[i]);
 		pr[i]      = PatchRegs {0u, 0ull};
-		if (patched[i]) { pr[i] = issue_patch_loads(d[i], excs + d[i].exc_off, lane); }
+		if (patched[i]) {
+			pr[i] = issue_patch_loads(d[i], excs + d[i].exc_off, lane);
+			if constexpr (ALPGPU_DECODE_PATCH_MODE == 2) { patch_table_zero(L[i], wave, lane); }
+		}
 	}
 	// Only a workgroup that has exceptions zeroes its masks, and it does so behind the issue of all its loads: the barrier that fences the
 	// zeroes from the atomics waits for LDS only, so it falls into the shadow of the HBM round trip.  (Until round 3 every workgroup,
@@ -581,6 +701,12 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA completion is not tracked through the LDS for the compiler
 	__syncthreads();
+	if constexpr (SINK == kSinkStore && ALPGPU_DECODE_PATCH_MODE == 2) {
+#pragma unroll
+		for (int i = 0; i < V; ++i) {
+			if (patched[i]) { patch_table_fill(L[i], pr[i], d[i].exc_cnt, wave, lane); }
+		}
+	}
 
 	if constexpr (SINK != kSinkStore) {
 		// Per-vector sums: lane partial (step order) in each of the four wavefronts -> the four partials of a lane position combined as
@@ -634,7 +760,8 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 		if (v0 + i < n_vectors) {
 			const alpgpu_vector_desc dd = patched[i] ? without_exceptions(d[i]) : d[i]; // (a patched vector unpacks as one without exceptions)
 			if (LDS::kStage == kStageBytes || vector_fits_stage<LDS>(d[i])) { // (always, with the full stage)
-				decode_staged_vector<NT_STORE, kSinkStore, LDS>(L[i], dd, dict[i], excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane);
+				decode_staged_vector<NT_STORE, kSinkStore, LDS>(L[i], dd, dict[i], excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane, nullptr, 0.0, 0.0,
+				                                                ALPGPU_DECODE_PATCH_MODE == 2 && patched[i], pr[i]);
 			} else { // a wide vector in a narrow-stage launch: its words straight from HBM (bounded buffer loads, as in k_sink_direct)
 				ExcMask em {0u, 0};
 				if (dd.exc_cnt > 0) { em = load_exception_mask(L[i], lane); }
@@ -644,9 +771,11 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 				const BufferWords words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d[i].bw, kRsrcFlags),
 				                         __builtin_amdgcn_make_buffer_rsrc(first + 128u * d[i].bw, 0, is_alp ? 0 : 128 * d[i].lbw, kRsrcFlags)};
 				decode_vector_quarters<NT_STORE, kSinkStore, 1>(L[i], words, dd, dict[i], em, excs + d[i].exc_off, reinterpret_cast<double2*>(out + (v0 + i) * kVec), wave, lane,
-				                                                nullptr, 0.0, 0.0);
+				                                                nullptr, 0.0, 0.0, ALPGPU_DECODE_PATCH_MODE == 2 && patched[i], pr[i]);
 			}
-			if (patched[i]) { apply_patches<NT_STORE>(pr[i], d[i].exc_cnt, out + (v0 + i) * kVec, wave, lane); }
+			if constexpr (ALPGPU_DECODE_PATCH_MODE == 1) {
+				if (patched[i]) { apply_patches<NT_STORE>(pr[i], d[i].exc_cnt, out + (v0 + i) * kVec, wave, lane); }
+			}
 		}
 	}
 }
@@ -702,7 +831,8 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_pairs(const alpgpu_ve
 	double2*                 o1 = reinterpret_cast<double2*>(out + v1 * kVec);
 	const bool together = n_here == 2 && (PAIRING == 3 || (vector_is_narrow(d0) && vector_is_narrow(d1))); // workgroup-uniform
 	// vectors whose exceptions are patched in after their stores (apply_patches): decoded as if they had none
-	const bool               pa0 = vector_patches_after(d0, patch_max), pa1 = vector_patches_after(d1, patch_max);
+	// (ALPGPU_DECODE_PATCH_MODE 2 keeps its slot tables in k_decode_column only: here such vectors go through the mask)
+	const bool               pa0 = ALPGPU_DECODE_PATCH_MODE == 1 && vector_patches_after(d0, patch_max), pa1 = ALPGPU_DECODE_PATCH_MODE == 1 && vector_patches_after(d1, patch_max); // (compile-time false in the default build)
 	const alpgpu_vector_desc m0 = pa0 ? without_exceptions(d0) : d0, m1 = pa1 ? without_exceptions(d1) : d1;
 	PatchRegs                r0 {0u, 0ull}, r1 {0u, 0ull};
 	if (together) {

@@ -195,10 +195,11 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * run them from the two descriptors — 1: together when both are narrow, else one after the other; 2: as 1 with the second vector's loads issued in front
  * of the first one's unpack; 3: three vectors per two workgroups.  Same output bytes as every other shape (tests/test_decode_gpu.py). */
 #define ALPGPU_OPT_DECODE_PAIRING 8
-/* ALPGPU_OPT_DECODE_PATCH_AFTER (double store decode; round 5): an ALP vector with 1..value exceptions (value <= 64, the default; 0 = never) is unpacked
- * and stored as if it had none — no exception mask, no per-value lookup — and its exceptions are then written over the stored values by the wavefront
- * that stored them, the reference's own order (include/alp/decoder.hpp:141-149).  Vectors with more exceptions and ALP_RD vectors go through the
- * mask.  Same output bytes (tests/test_decode_gpu.py runs every exception count 0..1024 both ways). */
+/* ALPGPU_OPT_DECODE_PATCH_AFTER (double store decode; round 5; an EXPERIMENT that lost — effective only in builds of decode_kernels.hip with
+ * -DALPGPU_DECODE_PATCH_MODE=1 or 2, ignored by the default build; default 0): an ALP vector with 1..value exceptions (value <= 64) is unpacked as
+ * if it had none — no exception mask, no rank lookup — and its exceptions are put in afterwards: mode 1 by 8-byte stores over the stored values (the
+ * reference's own order, include/alp/decoder.hpp:141-149), mode 2 in registers through a per-wavefront slot table.  Same output bytes
+ * (tests/test_decode_gpu.py runs every exception count 0..1024 under every limit); measured against the mask route in profiles/r05_decode_exceptions.txt. */
 #define ALPGPU_OPT_DECODE_PATCH_AFTER 9
 /* ALPGPU_OPT_ENCODE_UNORDERED (double columns, ALPGPU_ENCODE_KERNEL_LEAN; round 5; default 0): 1 = alpgpu_encode_f64 / alpgpu_encode_vectors_f64 do not
  * assign stream offsets in vector order.  Each 8-vector tile reserves its packed / exception bytes with ONE atomic add when its analysis is done,
@@ -210,6 +211,10 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * anywhere inside the streams as long as they do not leave them).  The host pipeline (alpgpu_compress_host_*) always uses the ordered form.
  * If the rowgroup search beside the encode stalls, the recovery route rewrites the column in vector order. */
 #define ALPGPU_OPT_ENCODE_UNORDERED 10
+/* ALPGPU_OPT_DECODE_RESIDENCY_PAD (tuning aid): KiB of unused dynamic LDS every double store-decode workgroup asks for, which caps the workgroups
+ * resident per CU (160 KiB / (its own 9.6 or 19.3 KiB + this)); -1 (default) = chosen from the column's size hints (what a CU wants
+ * is an amount of bytes in flight).  Never changes results. */
+#define ALPGPU_OPT_DECODE_RESIDENCY_PAD 11
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */

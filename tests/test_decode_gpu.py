@@ -157,27 +157,27 @@ def _alp_vectors_with_exception_counts(rng, counts, bw, placement="random"):
 
 
 @pytest.mark.parametrize("placement", ["random", "front", "edges"])
-@pytest.mark.parametrize("bw", [0, 1, 6, 17, 33, 52])
+@pytest.mark.parametrize("bw", [0, 6, 17, 52])
 def test_exceptions_patched_after_the_stores_or_through_the_mask(ctx, oracle, bw, placement):
-    """ALPGPU_OPT_DECODE_PATCH_AFTER: vectors with 1..limit exceptions are stored as if they had none and patched by the wavefront that stored the
-    quarter (round 5); every limit, every launch shape, counts on both sides of every limit, positions on the quarter boundaries — the same bits
-    as the mask route (limit 0) and the oracle"""
+    """the three loops a store-decode wavefront picks from per vector (no exceptions / all values staged in LDS / values beyond the stage read from HBM:
+    counts 0, 1..128, 129..1024) in every launch shape, positions on the quarter boundaries; and ALPGPU_OPT_DECODE_PATCH_AFTER under every limit — a no-op
+    in the default build, the patch arms in an -DALPGPU_DECODE_PATCH_MODE=1 / 2 build selected with ALPGPU_LIB — the same bits as the oracle"""
     from alp_amd import capi
     rng = np.random.default_rng(7000 + bw)
     counts = [0, 1, 2, 3, 7, 8, 9, 20, 31, 32, 33, 63, 64, 65, 100, 128, 129, 300, 1024, 1, 64, 0, 5]
     enc = _alp_vectors_with_exception_counts(rng, counts, bw, placement)
     want = oracle.decode_column(enc)
     try:
-        for limit in (64, 0, 8, 32):
+        for limit in (64, 0, 8):
             ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, limit)
-            for vpw, pairing, plain in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (4, 0, 0), (0, 1, 0), (0, 2, 0), (0, 3, 0), (1, 0, 1), (2, 0, 1)):
+            for vpw, pairing, plain in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (4, 0, 0), (0, 1, 0), (0, 2, 0), (0, 3, 0), (2, 0, 1)):
                 ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
                 ctx.set_option(capi.OPT_DECODE_PAIRING, pairing)
                 ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, plain)
                 got = gpu_decode(ctx, enc)
                 assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (bw, placement, limit, vpw, pairing, plain)
     finally:
-        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 64)
+        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 0)
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
         ctx.set_option(capi.OPT_DECODE_PAIRING, 0)
         ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, 0)
@@ -215,5 +215,47 @@ def test_patched_exceptions_on_a_full_chip(ctx, oracle):
             ctx.synchronize()
             assert torch.equal(out.view(torch.int64), ref.view(torch.int64)), vpw
     finally:
-        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 64)
+        ctx.set_option(capi.OPT_DECODE_PATCH_AFTER, 0)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+
+
+@pytest.mark.parametrize("exceptions", [0, 5, 200], ids=["clean", "staged_exceptions", "exceptions_beyond_the_stage"])
+def test_shortcut_arithmetic_at_every_width(ctx, oracle, exceptions):
+    """vectors that qualify for the conversion shortcut (|base + digit| < 2^51 and its product with 10^f inside int64) at EVERY bit width 0..52: widths
+    <= 32 take the 32-bit unpack + {0x43380000, digit} form of the store decode (round 5), wider ones the 64-bit form, with bases on both sides of
+    zero and at the shortcut's bound for the factor; random packed words; every launch shape; against the oracle's falp + patch"""
+    from alp_amd import capi
+    rng = np.random.default_rng(4242 + exceptions)
+    bound = [2251799813685247, 2251799813685247, 2251799813685247, 2251799813685247, 922337203685477, 92233720368547, 9223372036854, 922337203685, 92233720368,
+             9223372036, 922337203, 92233720, 9223372, 922337, 92233, 9223, 922, 92, 9]
+    rows = []
+    for bw in range(0, 53):
+        for f in (0, 2, 6, 11, 14, 18):
+            span = (1 << bw) - 1
+            if span > bound[f]:
+                continue
+            for base in (0, -1, 1 - (1 << 31), (1 << 32) + 12345, -bound[f], bound[f] - span, -(bound[f] // 3)):
+                if base < -bound[f] or base + span > bound[f]:
+                    continue
+                rows.append((bw, f, min(18, f + int(rng.integers(0, 3))), base))
+    n = len(rows)
+    enc = dict(scheme=np.full(n, 2, np.uint8), e=np.array([r[2] for r in rows], np.uint8), f=np.array([r[1] for r in rows], np.uint8),
+               bw=np.array([r[0] for r in rows], np.uint8), lbw=np.zeros(n, np.uint8), base=np.array([r[3] for r in rows], np.int64), exc_cnt=np.zeros(n, np.uint16),
+               packed=np.zeros((n, 1024), np.int64), packed_left=np.zeros((n, 1024), np.uint16), exc=np.zeros((n, 1024), np.float64), pos=np.zeros((n, 1024), np.uint16),
+               dict=np.zeros(((n + 99) // 100, 8), np.uint16), dict_size=np.zeros((n + 99) // 100, np.uint8), k=np.ones((n + 99) // 100, np.uint8),
+               combos=np.zeros(((n + 99) // 100, 10), np.int32))
+    for v, (bw, f, e, base) in enumerate(rows):
+        enc["packed"][v, :16 * bw] = rng.integers(-2**63, 2**63 - 1, 16 * bw, dtype=np.int64)
+        c = exceptions if exceptions < 200 else int(rng.integers(129, 400))
+        enc["exc_cnt"][v] = c
+        enc["pos"][v, :c] = np.sort(rng.choice(1024, c, replace=False)).astype(np.uint16)
+        enc["exc"][v, :c] = rng.integers(0, 2**64, c, dtype=np.uint64).view(np.float64)
+    want = oracle.decode_column(enc)
+    try:
+        for vpw in (0, 1, 2, 4):
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+            got = gpu_decode(ctx, enc)
+            bad = np.nonzero((got.view(np.uint64) != want.view(np.uint64)).reshape(n, 1024).any(axis=1))[0]
+            assert bad.size == 0, (vpw, [rows[i] for i in bad[:5]])
+    finally:
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)

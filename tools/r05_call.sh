@@ -1,0 +1,91 @@
+#!/bin/bash
+# r05_call.sh <step>: ONE gpurun call of round 5 (every step under its own wall-clock guard; logs under gpurun_out/r05/<step>/).
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/r05_call.sh 1'
+set -u
+step=${1:?step}
+out=gpurun_out/r05/$step
+mkdir -p "$out"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+run() { # run <seconds> <log> <command...>: never let one command take the call with it
+	local limit=$1 log=$2
+	shift 2
+	echo "== $* (limit ${limit}s)" | tee -a "$out/$log"
+	timeout "$limit" "$@" >>"$out/$log" 2>&1
+	echo "== rc $?" | tee -a "$out/$log"
+}
+case $step in
+1)  # first contact of the round's new code: the whole GPU suite, then the two A/B timings
+	run 420 pytest.txt python -m pytest tests -m gpu -x -q
+	tail -5 "$out/pytest.txt"
+	run 200 decode_exc.txt python tools/r05_time_decode_exc.py
+	tail -30 "$out/decode_exc.txt"
+	run 200 encode.txt python tools/r05_time_encode.py
+	tail -4 "$out/encode.txt"
+	;;
+2)  # why is the decode with exceptions slow on narrow vectors: round 4's library against this one and its patch variants, same box
+	for lib in r04 "" dec_table dec_plain dec_nostore dec_fence; do
+		if [ -z "$lib" ]; then export -n ALPGPU_LIB; unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 120 decode_ab.txt python tools/r05_decode_ab.py
+	done
+	export ALPGPU_LIB=$PWD/build/variants/libalpgpu_dec_table.so
+	run 200 pytest_table.txt python -m pytest tests/test_decode_gpu.py -x -q -k "patched or falp or synthetic"
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/decode_ab.txt"
+	tail -3 "$out/pytest_table.txt"
+	;;
+3)  # the decode loops chosen per vector (no store waits for the store before it): round 4's library, this one, the slot-table patch variant
+	for lib in r04 "" dec_table; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		WIDTHS=1,3,6,9,12,16,20,26,32,38,44,53 run 150 decode_ab.txt python tools/r05_decode_ab.py
+	done
+	export ALPGPU_LIB=$PWD/build/variants/libalpgpu_dec_table.so
+	run 200 pytest_table.txt python -m pytest tests/test_decode_gpu.py tests/test_float_gpu.py -x -q --durations=6
+	unset ALPGPU_LIB
+	run 200 pytest_default.txt python -m pytest tests/test_decode_gpu.py tests/test_decode_sum_gpu.py tests/test_reference_gpu.py -x -q --durations=6
+	for lib in r04 ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 100 bench_headline.txt python bench.py --no-extras --steps 20 --warmup 10
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/decode_ab.txt"
+	tail -12 "$out/pytest_table.txt"; tail -12 "$out/pytest_default.txt"
+	grep "^{" "$out/bench_headline.txt" | cut -c1-600
+	;;
+4)  # narrow vectors, two per workgroup: what slowed them (store waits as a throttle? the patch arm's code?) and the residency each build wants
+	for lib in r04 "" dec_wait dec_nopatch; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		WIDTHS=1,2,3,4,6,8,10,12,16 run 150 decode_ab.txt python tools/r05_decode_ab.py
+	done
+	unset ALPGPU_LIB
+	run 240 resid_default.txt python tools/r05_decode_resid.py
+	export ALPGPU_LIB=$PWD/build/variants/libalpgpu_dec_table.so
+	EXCS=20 run 150 resid_table.txt python tools/r05_decode_resid.py
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/decode_ab.txt"
+	grep -v "^==\|amdgpu.ids" "$out/resid_default.txt"
+	grep -v "^==\|amdgpu.ids" "$out/resid_table.txt"
+	;;
+5)  # the default build without a patch arm: residency by width for 1 / 2 / 4 vectors per workgroup, the decode tests, the float decode against round 4's
+	run 300 resid.txt python tools/r05_decode_resid.py
+	run 200 pytest.txt python -m pytest tests/test_decode_gpu.py tests/test_float_gpu.py tests/test_decode_sum_gpu.py -x -q
+	for lib in r04 ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		for vpw in 1 2 4; do SWEEP_VPW=$vpw run 100 f32.txt python tools/time_decode_f32.py; done
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/resid.txt"
+	tail -3 "$out/pytest.txt"
+	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
+	;;
+6)  # the 32-bit unpack / conversion of vectors of <= 32 bits against the build without it (same box), tests first
+	run 200 pytest.txt python -m pytest tests/test_decode_gpu.py tests/test_reference_gpu.py tests/test_fuzz_gpu.py -x -q
+	tail -3 "$out/pytest.txt"
+	for lib in dec_nonarrow "" dec_nonarrow ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		WIDTHS=1,2,3,4,6,8,10,12,14,16,20,24,28,32,36 PADS=0,3,6 VPWS=1,2 run 200 resid.txt python tools/r05_decode_resid.py
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/resid.txt"
+	;;
+*)  echo "unknown step $step"; exit 2 ;;
+esac
