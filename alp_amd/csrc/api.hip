@@ -1055,7 +1055,7 @@ static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vec
 	if (ctx->encode_two_pass) {
 		rc = alpgpu::launch_encode_vectors_f32(ctx->stream, d_in, n_vectors, col, ws);
 	} else {
-		rc = alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head);
+		rc = alpgpu::launch_encode_fused_f32(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head, ctx->encode_unordered != 0);
 		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors_f32(ctx->stream, d_in, n_vectors, col, ws, col->d_totals + 6); }
 	}
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }

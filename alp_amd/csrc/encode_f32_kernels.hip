@@ -47,7 +47,8 @@ struct FusedSharedF32 {
 #else
 #define ALPGPU_F32_STOP(n, expr)
 #endif
-template <int MODE>
+// UNORDERED (single pass only; ALPGPU_OPT_ENCODE_UNORDERED, encode_lean_kernels.hip): the tile reserves its bytes with one atomic add instead of the look-back
+template <int MODE, bool UNORDERED = false>
 __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_t tile, const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                 alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed, uint8_t* __restrict__ excs,
                                                 uint64_t* __restrict__ status, uint64_t* __restrict__ totals, uint64_t packed_capacity, uint64_t exc_capacity,
@@ -248,6 +249,8 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 		if (live && lane == 0) { descs[v] = d; }
 		return;
 	}
+	uint64_t reserved = ~0ull; // UNORDERED: the tile's exclusive prefix, in the lane that asked for it
+	bool     reserver = false;
 	if (MODE == kSinglePass && lane == 0) {
 		s_size[wave]           = status_pack(0, my_p >> 7, my_e >> 3);
 		const uint32_t arrived = __hip_atomic_fetch_add(&s_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -255,7 +258,12 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 			uint64_t aggregate = 0;
 #pragma unroll
 			for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[w]; }
-			status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
+			if constexpr (UNORDERED) {
+				reserved = __hip_atomic_fetch_add(status + lookback_words(gridDim.x), aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				reserver = true;
+			} else {
+				status_store(status + tile, kFlagAggregate | aggregate); // the tile word is written exactly once
+			}
 		}
 	}
 	// Pack while the ordered offset is on its way (see k_encode_fused) — into the wavefront's 4 KiB image, which STAYS in LDS until the offset is
@@ -290,7 +298,11 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 	if (MODE == kSinglePass) {
 		// wavefront 0 finds the tile's offset; the others park at a workgroup barrier meanwhile (see k_encode_lean: a worker that spins on an LDS
 		// word takes issue slots from the wavefronts that still compute)
-		if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
+		if constexpr (UNORDERED) {
+			if (reserver) { s_excl = reserved; }
+		} else {
+			if (wave == 0) { tile_lookback(tile, status, totals, s_size, &s_count, &s_excl, &s_ready, lane, spin_limit); }
+		}
 		__syncthreads();
 		const uint64_t mine_sz = lane < wave ? s_size[lane & (kFusedWaves - 1)] : 0ull;
 		const uint64_t local   = wave_sum_u64(mine_sz);
@@ -357,7 +369,7 @@ __device__ __forceinline__ void encode_tile_f32(FusedSharedF32& S, const uint64_
 // (the single pass is held to 96 VGPRs — __launch_bounds__' second argument, wavefronts per SIMD: four of them per SIMD then leave the 96
 // registers the persistent rowgroup search needs to share the CU)
 // (the first nine parameters are read by offset in the single pass — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
-template <int MODE>
+template <int MODE, bool UNORDERED = false>
 __global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_ENC_OCC : 1) void k_encode_fused_f32(const float* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                        alpgpu_vector_desc* __restrict__ descs, uint8_t* __restrict__ packed,
                                                                        uint8_t* __restrict__ excs, uint64_t* __restrict__ status,
@@ -368,8 +380,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_
 	__builtin_amdgcn_s_setprio(2); // over the persistent rowgroup search that may share the CU (see k_encode_fused)
 	__shared__ FusedSharedF32 S;
 	if constexpr (MODE == kSinglePass) {
-		encode_tile_f32<MODE>(S, blockIdx.x, in, rgs, descs, packed, excs, status, totals, packed_capacity, exc_capacity, v_first, n_vectors_launch, rd_order, spin_limit,
-		                      async_states);
+		encode_tile_f32<MODE, UNORDERED>(S, blockIdx.x, in, rgs, descs, packed, excs, status, totals, packed_capacity, exc_capacity, v_first, n_vectors_launch, rd_order, spin_limit,
+		                                 async_states);
 	} else {
 		const uint64_t n_tiles = (n_vectors_launch + kFusedWaves - 1) / kFusedWaves;
 		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -380,8 +392,14 @@ __global__ __launch_bounds__(64 * kFusedWaves, MODE == kSinglePass ? ALPGPU_F32_
 }
 
 // (see k_fused_finish in encode_kernels.hip)
-__global__ __launch_bounds__(256) void k_fused_finish_f32(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear) {
+__global__ __launch_bounds__(256) void k_fused_finish_f32(uint64_t* __restrict__ totals, alpgpu_rowgroup_state* __restrict__ clear_rgs, uint64_t n_clear,
+                                                          const uint64_t* __restrict__ reserve) {
 	if (threadIdx.x == 0) {
+		if (reserve != nullptr) { // an UNORDERED launch: its bytes are what its tiles reserved
+			const uint64_t incl = *reserve;
+			totals[4]           = totals[0] + ((incl >> 31) & 0x7FFFFFFFull) * 128ull;
+			totals[5]           = totals[1] + (incl & 0x7FFFFFFFull) * 8ull;
+		}
 		totals[0] = totals[4];
 		totals[1] = totals[5];
 		if (totals[3] != 0) { totals[6] = 1; } // the gate of the recovery kernels
@@ -392,32 +410,39 @@ __global__ __launch_bounds__(256) void k_fused_finish_f32(uint64_t* __restrict__
 }
 
 int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                                  bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
+                                  bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head, bool unordered) {
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
-		if (hipMemsetAsync(d_workspace, 0, lookback_words(n_tiles) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+		if (hipMemsetAsync(d_workspace, 0, (lookback_words(n_tiles) + 1) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; } // (+ the unordered form's counter word)
 		if (async_states && first == v_first && async_head != nullptr) {
 			if (hipStreamWaitEvent(stream, async_head, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		}
-		hipLaunchKernelGGL(k_encode_fused_f32<kSinglePass>, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
-		                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
-		                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, static_cast<const uint64_t*>(nullptr), async_states ? 1u : 0u);
+		const uint64_t* reserve = unordered ? d_workspace + lookback_words(n_tiles) : nullptr;
+		if (unordered) {
+			hipLaunchKernelGGL((k_encode_fused_f32<kSinglePass, true>), dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
+			                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
+			                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, static_cast<const uint64_t*>(nullptr), async_states ? 1u : 0u);
+		} else {
+			hipLaunchKernelGGL(k_encode_fused_f32<kSinglePass>, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
+			                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,
+			                   n_launch, col->d_rd_order, force_stall ? 0u : kSpinLimit, static_cast<const uint64_t*>(nullptr), async_states ? 1u : 0u);
+		}
 		if (async_states && first + n_launch >= v_first + n_range) {
 			if (hipStreamWaitEvent(stream, async_join, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
-			hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(256), 0, stream, col->d_totals, col->d_rowgroups, col->n_rowgroups);
+			hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(256), 0, stream, col->d_totals, col->d_rowgroups, col->n_rowgroups, reserve);
 		} else {
-			hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(256), 0, stream, col->d_totals, static_cast<alpgpu_rowgroup_state*>(nullptr), 0ull);
+			hipLaunchKernelGGL(k_fused_finish_f32, dim3(1), dim3(256), 0, stream, col->d_totals, static_cast<alpgpu_rowgroup_state*>(nullptr), 0ull, reserve);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
 int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall,
-                            bool async_states, hipEvent_t async_join, hipEvent_t async_head) {
+                            bool async_states, hipEvent_t async_join, hipEvent_t async_head, bool unordered) {
 	if (hipMemsetAsync(col->d_totals, 0, 64, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors, force_stall, async_states, async_join, async_head);
+	return launch_encode_fused_range_f32(stream, d_in, col, d_workspace, 0, n_vectors, force_stall, async_states, async_join, async_head, unordered);
 }
 
 // the two-pass form for float columns (gate: see launch_encode_vectors in encode_kernels.hip)

@@ -587,6 +587,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void k_traffic_probe(const ull2v*
 	ull2v acc = {v, 1ull};
 #pragma unroll
 	for (int m = 0; m < 8; ++m) { acc += in[v * 512 + 64 * m + lane]; }
+	if (units == 0) { // read-only stream: every lane's loads feed ONE 8-byte store per vector (a store that depends on one lane only lets the compiler sink the loads into that lane)
+		unsigned long long x = acc.x ^ acc.y;
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) { x += __shfl_xor(x, d); }
+		if (lane == 0) { reinterpret_cast<unsigned long long*>(out)[v] = x; }
+		return;
+	}
 	ull2v* dst = out + v * units;
 	for (uint32_t u = lane; u < units; u += 64) {
 		ull2v o = acc;

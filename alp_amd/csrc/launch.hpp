@@ -105,9 +105,10 @@ int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_v
                              uint64_t rg_first = 0, uint64_t rg_count = 0);
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate = nullptr);
 int launch_encode_fused_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,
-                            bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
+                            bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr, bool unordered = false);
 int launch_encode_fused_range_f32(hipStream_t stream, const float* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
-                                  bool force_stall = false, bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr);
+                                  bool force_stall = false, bool async_states = false, hipEvent_t async_join = nullptr, hipEvent_t async_head = nullptr,
+                                  bool unordered = false);
 int launch_encode_vectors_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, const uint64_t* gate = nullptr);
 int launch_pad_tail_f32(hipStream_t stream, float* d_in, uint64_t n_values);
 int launch_ffor_i32(hipStream_t stream, int n_cus, const int32_t* in, int32_t* packed, size_t stride, const uint8_t* bw, const int32_t* base, uint64_t n);

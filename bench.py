@@ -178,6 +178,14 @@ def synthetic_input(kind: str, n_vectors: int, device, seed: int):
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         return torch.rand(n_vectors * VEC, dtype=torch.float64, device=device, generator=g)
+    if kind == "uniform2":  # (tools only) two decimals in every rowgroup, 1 % full-precision values: a column whose rowgroups all pick the same (e, f)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        x = (torch.rand(n_vectors * VEC, dtype=torch.float64, device=device, generator=g) - 0.5) * 2e4
+        out = torch.round(x * 100.0) / 100.0
+        m = torch.rand(n_vectors * VEC, device=device, generator=g) < 0.01
+        out[m] = x[m] * 3.141592653589793
+        return out
     return mixed_column_shard(0, n_vectors, device, seed, exc_rate={"mixed": 0.01, "mixed_exc0": 0.0, "mixed_exc10": 0.10}[kind])
 
 
@@ -855,7 +863,7 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
         if kind == "mixed":
             torch.cuda.synchronize()
             enc_cpu = cpu_encode_baseline(x, ecol)
-            ro, _ = time_launches(lambda: ctx.traffic_probe(x, out, n, 0), 7, 5)  # read-only: 8 GiB in the encode's launch shape, nothing stored
+            ro, _ = time_launches(lambda: ctx.traffic_probe(x, out, n, 0), 7, 5)  # read-only: 8 GiB in the encode's launch shape, 8 bytes per vector stored
         del x, ecol
     # measured ceilings next to the nominal 8 TB/s: device-to-device copy (1 read + 1 write per byte) and fill of the 8 GiB
     # output buffer (torch's kernels), and the read-only stream above

@@ -38,9 +38,7 @@ struct rd_encoder {
 		}
 		auto&        s       = gpu::tls();
 		const size_t n       = stt.sampled_values_n;
-		const size_t n_block = (n + config::SAMPLES_PER_VECTOR - 1) / config::SAMPLES_PER_VECTOR;
-		const size_t n_up    = n < config::SAMPLES_PER_VECTOR ? n : n_block * config::SAMPLES_PER_VECTOR;
-		gpu::h2d(s.at<PT>(s.SAMPLES), in_p, n_up * sizeof(PT));
+		gpu::h2d(s.at<PT>(s.SAMPLES), in_p, n * sizeof(PT)); // exactly the stt.sampled_values_n values the reference reads (rd.hpp:40): the kernel is given n and reads no further
 		gpu::check(gpu::abi<PT>::rd_dictionary_for_cut(s.at<PT>(s.SAMPLES), static_cast<uint32_t>(n), right_bit_width, s.at<alpgpu_rowgroup_state>(s.STATE),
 		                                               s.at<double>(s.META + 32)),
 		           "alpgpu_rd_dictionary_for_cut");

@@ -201,14 +201,16 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * reference's own order, include/alp/decoder.hpp:141-149), mode 2 in registers through a per-wavefront slot table.  Same output bytes
  * (tests/test_decode_gpu.py runs every exception count 0..1024 under every limit); measured against the mask route in profiles/r05_decode_exceptions.txt. */
 #define ALPGPU_OPT_DECODE_PATCH_AFTER 9
-/* ALPGPU_OPT_ENCODE_UNORDERED (double columns, ALPGPU_ENCODE_KERNEL_LEAN; round 5; default 0): 1 = alpgpu_encode_f64 / alpgpu_encode_vectors_f64 do not
+/* ALPGPU_OPT_ENCODE_UNORDERED (double columns under ALPGPU_ENCODE_KERNEL_LEAN, and float columns; round 5; default 0): 1 = alpgpu_encode_* / alpgpu_encode_vectors_* do not
  * assign stream offsets in vector order.  Each 8-vector tile reserves its packed / exception bytes with ONE atomic add when its analysis is done,
  * instead of waiting for the sizes of every tile before it (the ordered form's look-back).  Every vector's record — descriptor fields, packed words,
  * exception values and positions — is byte for byte what the ordered form writes; what changes is WHERE in d_packed / d_exc a tile's records lie
  * (tiles in the order they finished; the eight vectors of a tile stay adjacent, in order), so the two streams as a whole are a permutation of
  * the reference's by tiles and differ from run to run.  Every decoder and consumer of this library follows the descriptors' offsets and
  * does not care; alpgpu_column_to_blob serializes such a column as it is (alpgpu_column_from_blob's validation accepts it: records may lie
- * anywhere inside the streams as long as they do not leave them).  The host pipeline (alpgpu_compress_host_*) always uses the ordered form.
+ * anywhere inside the streams as long as they do not leave them); alpgpu_decompress_host_* — which uploads a blob's streams chunk by chunk and relies on
+ * offsets that ascend with the vector index — refuses such a blob (ALPGPU_ERR_INVALID): decode it with alpgpu_column_from_blob + alpgpu_decode_*.
+ * The host pipeline (alpgpu_compress_host_*) always uses the ordered form.
  * If the rowgroup search beside the encode stalls, the recovery route rewrites the column in vector order. */
 #define ALPGPU_OPT_ENCODE_UNORDERED 10
 /* ALPGPU_OPT_DECODE_RESIDENCY_PAD (tuning aid): KiB of unused dynamic LDS every double store-decode workgroup asks for, which caps the workgroups

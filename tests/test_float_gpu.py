@@ -362,3 +362,27 @@ def test_float_exception_record_pad_bytes_are_zero_in_a_dirty_buffer(ctx, of32):
     ctx.synchronize()
     for a, b, what in zip(dcol.to_host(), want, ("rowgroup states", "descriptors", "packed stream", "exception stream")):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), what
+
+
+@pytest.mark.parametrize("name", ["mixed_1pct", "mixed_30pct", "rd_latlon", "drifting_k", "adversarial", "one_vector"])
+def test_unordered_float_encode_writes_the_same_records_somewhere_else(ctx, of32, name):
+    """ALPGPU_OPT_ENCODE_UNORDERED on a float column: every vector's descriptor fields, packed words and exception record are the oracle's; the records
+    tile the two streams without gaps or overlaps, a tile's eight vectors adjacent and in order; the decode gives the input back"""
+    from alp_amd import capi
+    import test_encode_gpu
+    col_np = COLUMNS[name]()
+    want = of32.encode_column(col_np)
+    try:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
+        dcol, x = gpu_encode(ctx, col_np)
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
+    rg, vec, packed, exc = dcol.to_host()
+    got = layout.expand(rg, vec, packed, exc, 4)
+    assert_parts_equal(got, want, name)
+    assert np.array_equal(got["packed_left"], want["packed_left"])
+    pb, eb, ov = ctx.column_totals(dcol)
+    test_encode_gpu._assert_records_tile_the_streams(vec, pb, eb, value_bytes=4)
+    out = ctx.decode(dcol)
+    ctx.synchronize()
+    assert torch.equal(out.view(torch.int32), x.view(torch.int32))

@@ -87,5 +87,38 @@ case $step in
 	unset ALPGPU_LIB
 	grep -v "^==\|amdgpu.ids" "$out/resid.txt"
 	;;
+7)  # the pruned rowgroup search: parity first (every test that looks at rowgroup states), then search alone and encode, against the build without it
+	run 400 pytest.txt python -m pytest tests/test_encode_gpu.py tests/test_reference_gpu.py tests/test_fuzz_gpu.py tests/test_async_init_gpu.py tests/test_dropin_gpu.py tests/test_recovery_gpu.py -x -q
+	tail -4 "$out/pytest.txt"
+	for lib in init_noprune "" init_noprune ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		for kind in mixed rd mixed_exc0 mixed_exc10; do run 60 init.txt python tools/time_init.py $kind 1048576; done
+		run 200 encode.txt python tools/r05_time_encode.py
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/init.txt"
+	grep -v "^==\|amdgpu.ids" "$out/encode.txt"
+	;;
+8)  # the pruned search (now a -D build) with its race fixed: parity, then what it buys where its incumbent is good (a column of one kind of rowgroup)
+	export ALPGPU_LIB=$PWD/build/variants/libalpgpu_init_prune.so
+	run 400 pytest.txt python -m pytest tests/test_encode_gpu.py tests/test_reference_gpu.py tests/test_fuzz_gpu.py tests/test_async_init_gpu.py tests/test_dropin_gpu.py tests/test_recovery_gpu.py -x -q
+	tail -4 "$out/pytest.txt"
+	for lib in "" init_prune "" init_prune; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		for kind in uniform2 mixed; do run 60 init.txt python tools/time_init.py $kind 1048576; done
+		run 200 encode.txt python tools/r05_time_encode.py 1048576 uniform2
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/init.txt"
+	grep -v "^==\|amdgpu.ids" "$out/encode.txt"
+	;;
+9)  # the whole GPU suite on the current build; the benchmark column under the residency pads; float encode ordered / unordered
+	run 500 pytest.txt python -m pytest tests -m gpu -x -q
+	tail -4 "$out/pytest.txt"
+	run 200 pads.txt python tools/r05_headline_pads.py
+	grep -v "^==\|amdgpu.ids" "$out/pads.txt"
+	for u in 0 1 0 1; do ALPGPU_ENCODE_UNORDERED=$u run 120 f32enc.txt python tools/time_encode_f32.py; done
+	grep -v "^==\|amdgpu.ids" "$out/f32enc.txt"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac

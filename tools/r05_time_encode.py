@@ -44,7 +44,7 @@ for kind in kinds:
     wb = (pb + eb + 13 * n) // n // 16 * 16
     p = bench.time_launches(lambda: ctx.traffic_probe(x, out, n, wb), 7, 3)[0]
     ps = bench.time_launches(lambda: ctx.traffic_probe_with_search(x, out, n, wb, col), 7, 3)[0]
-    ro = bench.time_launches(lambda: ctx.traffic_probe(x, out, n, 0), 7, 3)[0]
+    ro = bench.time_launches(lambda: ctx.traffic_probe(x, out, n, 0), 7, 3)[0]  # (write_bytes 0: a read-only stream, 8 bytes per vector stored)
     f = lambda t: alg / t / 1e6 / 8000  # noqa: E731
     print(f"{kind}: ordered {' '.join(f'{t:.3f}' for t in ms[0])} ms = {f(min(ms[0])):.3f}-{f(max(ms[0])):.3f} | unordered {' '.join(f'{t:.3f}' for t in ms[1])} ms = {f(min(ms[1])):.3f}-{f(max(ms[1])):.3f} "
           f"(round trip {rt}) | vectors alone: ordered {vs[0][0]:.3f} unordered {vs[1][0]:.3f} | search alone {imed:.3f} | probe ({wb} B written per vector) {p:.3f} ms = {f(p):.3f}, with the search beside {ps:.3f} ms = {f(ps):.3f} "
