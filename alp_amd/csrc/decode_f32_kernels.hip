@@ -160,6 +160,7 @@ __device__ __forceinline__ QuadWords request_quad_f32(const WORDS& words, const 
 // SINK (as in decode_kernels.hip) = kSinkStoreF: the quad is stored.  kSinkSumF: its four values are widened to double
 // (exact) and added to `acc` in index order.  kSinkCountF: `acc` counts the values v with lo <= v <= hi (NaN never does).
 constexpr int kSinkStoreF = 0, kSinkSumF = 1, kSinkCountF = 2;
+__device__ __constant__ const uint32_t kShortcutBoundF[11] = {16777216u, 16777216u, 16777216u, 2147483u, 214748u, 21474u, 2147u, 214u, 21u, 2u, 0u};
 template <bool NT_STORE, int SINK, class LDS>
 __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w, const alpgpu_vector_desc& d, const RdDict& dict, const ExcMaskF& em,
                                                 const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane, double* acc,
@@ -202,9 +203,10 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 		// if every integer base + digit of the vector lies in [-2^24, 2^24] and times 10^f stays inside int32, then (float)(int32)(value * 10^f)
 		// — a quarter-rate 32-bit integer multiply and a conversion — is the correctly rounded product of two exactly representable floats, i.e.
 		// the IEEE product (float)value * 10^f (10^f = 2^f 5^f with 5^10 < 2^24: exact for every f <= 10): same bits, one full-rate multiply.
+		// (the bound from a table — round 5: as a division it was ~25 scalar and vector instructions, and the one-wavefront sink, which runs this
+		//  function four times per vector and is bound by its instruction issue, did it four times)
 		const int64_t lo64 = static_cast<int64_t>(static_cast<int32_t>(base)), hi64 = lo64 + static_cast<int64_t>(bw_mask32(bw));
-		const int64_t lim  = d.f <= 9 ? ((1ll << 31) - 1) / static_cast<int64_t>(fact) : 0; // (fact = 10^f for f <= 9; 10^10 does not fit: literal path)
-		const int64_t bnd  = lim < (1ll << 24) ? lim : (1ll << 24);
+		const int64_t bnd  = static_cast<int64_t>(kShortcutBoundF[d.f]); // min(2^24, (2^31 - 1) / 10^f) for f <= 9; 0 for f = 10 (10^10 does not fit: literal path)
 		const bool    shortcut = bw <= 24 && lo64 >= -bnd && hi64 <= bnd;
 		if (shortcut) {
 			const float fact_f = static_cast<float>(fact);

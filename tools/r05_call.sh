@@ -120,5 +120,17 @@ case $step in
 	for u in 0 1 0 1; do ALPGPU_ENCODE_UNORDERED=$u run 120 f32enc.txt python tools/time_encode_f32.py; done
 	grep -v "^==\|amdgpu.ids" "$out/f32enc.txt"
 	;;
+10) # float: the shortcut bound from a table (the sink ran a division four times per vector): SUM sink and decode, round 4's library beside
+	run 200 pytest.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py -x -q
+	tail -3 "$out/pytest.txt"
+	for lib in r04 "" r04 ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 100 sink.txt python tools/time_sink_f32.py
+		SWEEP_VPW=2 run 100 f32.txt python tools/time_decode_f32.py
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/sink.txt"
+	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
