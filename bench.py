@@ -739,7 +739,7 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
 #       probe_ms (the kernel's loads + stores alone, same launch shape), probe_search_ms (the same with the persistent search beside it: the measured speed of light of
 #       "these bytes + that search"), of_probe_search = probe_search_ms / ms.
 #   ceilings: torch copy_ (read + write) and fill_ (write) of 8 GiB, read_only = the probe with no stores (8 GiB read in the encode's launch shape), as fractions of 8 TB/s.
-#   float_path: enc_ms / enc_frac, dec_frac, sum_ms / sum_frac (k_sink_direct_f32), sum4_ms (staged kernel), bits, rt — per column kind, 1 Mi float vectors.
+#   float_path: enc_ms / enc_frac (ordered, the default), enc_unordered_* (ALPGPU_OPT_ENCODE_UNORDERED), dec_frac, sum_ms / sum_frac (k_sink_direct_f32), sum4_ms (staged kernel), bits, rt — per column kind, 1 Mi float vectors.
 def single_gpu_bench(args, ctx, clock, local_rank, dev):
     n = args.vectors
     col, vec, alg_bytes = build_decode_column(n, local_rank, seed=42)
@@ -892,6 +892,11 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
             xf[sp] = specials[torch.randint(0, 4, (int(sp.sum()),), device=dev, generator=g)]
             del xd, sc, m, sp
         fcol = capi.DeviceColumn(n, local_rank, dtype="f32")
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)  # tiles reserve their bytes with one atomic add instead of the ordered look-back
+        uemed, _ = time_launches(lambda: ctx.encode(xf, fcol), 3, 1)
+        ctx.decode(fcol, outf)
+        urt = bool(torch.equal(outf.view(torch.int32), xf.view(torch.int32)))
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
         emed, _ = time_launches(lambda: ctx.encode(xf, fcol), 3, 1)
         pb, eb, ov = ctx.column_totals(fcol)
         dmed, _ = time_launches(lambda: ctx.decode(fcol, outf), 7, 10)
@@ -903,7 +908,8 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
         ctx.set_option(capi.OPT_CONSUMER_PIPELINED, 0)
         del fsums
         f_alg = n * (4096 + 13) + pb + eb
-        fl[kind] = {"enc_ms": round(emed, 3), "enc_frac": frac(f_alg, emed), "bits": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
+        fl[kind] = {"enc_ms": round(emed, 3), "enc_frac": frac(f_alg, emed), "enc_unordered_ms": round(uemed, 3), "enc_unordered_frac": frac(f_alg, uemed), "enc_unordered_rt": urt,
+                    "bits": round((pb + eb + 32 * n) * 8 / (n * VEC), 2),
                     "dec_frac": frac(f_alg, dmed), "sum_ms": round(smed, 3), "sum_frac": frac(f_alg - n * 4096 + n * 8, smed), "sum4_ms": round(s4, 3), "rt": rt}
         del xf, fcol
     extras["float_path"] = fl

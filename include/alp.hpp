@@ -1,4 +1,7 @@
 // include/alp.hpp — source-compatible drop-in for the reference's umbrella header (cwida/ALP include/alp.hpp:4-13).
+// READ THIS FIRST: the per-vector functions below are CORRECT but SLOW — one PCIe round trip per 1024 values, 4-10 k vectors/s (33-80 MB/s), about a
+// hundred times slower than the reference's CPU loop.  Replacing the include path and the link line gives parity, not speed; speed is
+// alp::gpu::rowgroup<PT> / alp::gpu::column<PT> (alp/batch.hpp: 30-40 GB/s host to host) or the C ABI on device-resident columns (TB/s).  INTEGRATION.md §1.
 //
 // Same namespaces, types and static functions as the reference's vector API, but every function forwards to the
 // MI355X kernels in libalpgpu.so through the C ABI (include/alpgpu.h): there is no CPU implementation behind this

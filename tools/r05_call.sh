@@ -132,5 +132,15 @@ case $step in
 	grep -v "^==\|amdgpu.ids" "$out/sink.txt"
 	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
 	;;
+11) # the bench line as the driver runs it (does it fit the 8 KB tail? every key there?), then with a 2-rank shared-GPU run of the N > 1 path
+	run 900 bench.txt python bench.py --steps 20 --warmup 5
+	grep "^{" "$out/bench.txt" | tail -1 > "$out/bench.json"
+	wc -c "$out/bench.json"
+	cat "$out/bench.json"
+	;;
+12) # the round's profile of the library as built: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh), every command under its own guard there
+	timeout 1500 bash tools/profile_round.sh r05 > "$out/profile_round.txt" 2>&1
+	echo "rc $?"; tail -5 "$out/profile_round.txt"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
