@@ -142,5 +142,22 @@ case $step in
 	timeout 1500 bash tools/profile_round.sh r05 > "$out/profile_round.txt" 2>&1
 	echo "rc $?"; tail -5 "$out/profile_round.txt"
 	;;
+13) run 200 pairs.txt python tools/r05_pairs_on_mixed.py
+	grep -v "^==\|amdgpu.ids" "$out/pairs.txt"
+	;;
+14) # hopeless rounds of the (e,f) search end at their checkpoint: parity, then the search alone and the encodes against the build without it
+	run 400 pytest.txt python -m pytest tests/test_encode_gpu.py tests/test_float_gpu.py tests/test_reference_gpu.py tests/test_fuzz_gpu.py tests/test_async_init_gpu.py tests/test_dropin_gpu.py tests/test_recovery_gpu.py tests/test_sharding_gpu.py -x -q
+	tail -4 "$out/pytest.txt"
+	for lib in init_noearly "" init_noearly ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		for kind in mixed rd; do run 60 init.txt python tools/time_init.py $kind 1048576; run 60 init.txt python tools/time_init.py $kind 1048576 f32; done
+		run 200 encode.txt python tools/r05_time_encode.py
+		run 120 f32enc.txt python tools/time_encode_f32.py
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/init.txt"
+	grep -v "^==\|amdgpu.ids" "$out/encode.txt" | cut -c1-330
+	grep -v "^==\|amdgpu.ids" "$out/f32enc.txt"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
