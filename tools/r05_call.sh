@@ -159,5 +159,13 @@ case $step in
 	grep -v "^==\|amdgpu.ids" "$out/encode.txt" | cut -c1-330
 	grep -v "^==\|amdgpu.ids" "$out/f32enc.txt"
 	;;
+15) # the unordered mode with one reservation per VECTOR (no tile barrier): parity, then timings
+	run 400 pytest.txt python -m pytest tests/test_encode_gpu.py tests/test_float_gpu.py tests/test_recovery_gpu.py tests/test_async_init_gpu.py -x -q
+	tail -4 "$out/pytest.txt"
+	run 200 encode.txt python tools/r05_time_encode.py
+	for u in 0 1; do ALPGPU_ENCODE_UNORDERED=$u run 120 f32enc.txt python tools/time_encode_f32.py; done
+	grep -v "^==\|amdgpu.ids" "$out/encode.txt" | cut -c1-330
+	grep -v "^==\|amdgpu.ids" "$out/f32enc.txt"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
