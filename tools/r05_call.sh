@@ -167,5 +167,10 @@ case $step in
 	grep -v "^==\|amdgpu.ids" "$out/encode.txt" | cut -c1-330
 	grep -v "^==\|amdgpu.ids" "$out/f32enc.txt"
 	;;
+16) run 300 pytest.txt python -m pytest tests/test_encode_gpu.py tests/test_recovery_gpu.py tests/test_async_init_gpu.py -x -q
+	tail -3 "$out/pytest.txt"
+	run 200 encode.txt python tools/r05_time_encode.py
+	grep -v "^==\|amdgpu.ids" "$out/encode.txt" | cut -c1-330
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
