@@ -49,16 +49,34 @@ __device__ __forceinline__ ExcMaskF load_exception_mask_f32(const LDS& L, int la
 	return m;
 }
 
+// the value of the exception of that rank: staged (LDS) or, past the stage, from HBM.  all_staged (wave-uniform: the vector's count fits the stage)
+// keeps the common case to the LDS read alone.  Until round 5 this read "LDS if rank < kStaged else HBM": the compiler selected between the two
+// ADDRESSES and issued ONE FLAT load per exception (v_cndmask on pointers, src_shared_base) — slower than either, and it waits for every counter
+// (decode_kernels.hip: fetch_exception had been cured of the same in round 3; found again in the float sink's ISA, profiles/r05_float_sink.txt).
 template <int VAL_BYTES, class LDS>
-__device__ __forceinline__ uint32_t fetch_exception_f32(const LDS& L, const uint8_t* __restrict__ rec, int rank) {
+__device__ __forceinline__ uint32_t fetch_exception_f32(const LDS& L, const uint8_t* __restrict__ rec, int rank, bool all_staged) {
 	constexpr int kStaged = 4 * kExcStageF / VAL_BYTES;
+	const int     at      = rank < kStaged ? rank : kStaged - 1;
+	uint32_t      v;
 	if constexpr (VAL_BYTES == 4) {
-		if (rank < kStaged) { return reinterpret_cast<const uint32_t*>(L.excv)[rank]; }
-		return reinterpret_cast<const uint32_t*>(rec)[rank];
+		v = reinterpret_cast<const uint32_t*>(L.excv)[at];
 	} else {
-		if (rank < kStaged) { return reinterpret_cast<const uint16_t*>(L.excv)[rank]; }
-		return reinterpret_cast<const uint16_t*>(rec)[rank];
+		v = reinterpret_cast<const uint16_t*>(L.excv)[at];
 	}
+	asm volatile("" : "+v"(v)); // keeps the two loads two loads
+	if (!all_staged) {
+		if (rank >= kStaged) {
+			if constexpr (VAL_BYTES == 4) {
+				v = reinterpret_cast<const uint32_t*>(rec)[rank];
+			} else {
+				v = reinterpret_cast<const uint16_t*>(rec)[rank];
+			}
+#ifdef ALPGPU_F32_EXC_WAIT_IN_BRANCH // A/B (round 5): waited for HERE instead of at the join in front of the quad's store — measured 4 % SLOWER on columns whose vectors carry more exceptions than the stage holds (every such fetch then waits on its own)
+			asm volatile("" : "+v"(v));
+#endif
+		}
+	}
+	return v;
 }
 
 template <bool NT_STORE>
@@ -171,6 +189,7 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 	const int row  = tid >> 3;
 	uint32_t  hits = 0;
 	int       rank = 0;
+	const bool all_staged = cnt <= (d.scheme == ALPGPU_SCHEME_ALP ? kExcStageF : 2 * kExcStageF); // wave-uniform: every exception value of the vector is in the LDS stage
 	if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
 		const int wi = 8 * wave + (lane >> 3);
 		uint32_t  word;
@@ -194,6 +213,12 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 	u32x4          q;
 #pragma unroll
 	for (int c = 0; c < 4; ++c) { q[c] = __builtin_amdgcn_alignbit(w.w1[c], w.w0[c], s) & msk; }
+#if defined(ALPGPU_SINKF_STOP_AT) && ALPGPU_SINKF_STOP_AT == 4 // measurement builds (profiles/r05_float_sink.txt): the quad ends behind its unpack
+	if constexpr (SINK != kSinkStoreF) {
+		*acc += static_cast<double>(q[0] ^ q[1] ^ q[2] ^ q[3] ^ hits);
+		return;
+	}
+#endif
 	u32x4          out;
 	if (d.scheme == ALPGPU_SCHEME_ALP) {
 		const uint32_t base = static_cast<uint32_t>(d.base);
@@ -216,11 +241,17 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 #pragma unroll
 			for (int c = 0; c < 4; ++c) { out[c] = __float_as_uint(decode_value_f32(static_cast<int32_t>(q[c] + base), fact, frac)); }
 		}
-		if (hits) {
+#if defined(ALPGPU_SINKF_STOP_AT) && ALPGPU_SINKF_STOP_AT == 5 // ... behind the conversion
+		if constexpr (SINK != kSinkStoreF) {
+			*acc += static_cast<double>(out[0] ^ out[1] ^ out[2] ^ out[3] ^ hits);
+			return;
+		}
+#endif
+		if (hits) { // (a branch-free form — every lane reads the staged value it WOULD take, then selects — was measured in round 5: no difference, 64 VGPRs; profiles/r05_float_sink.txt)
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
 				if (hits & (1u << c)) {
-					out[c] = fetch_exception_f32<4>(L, rec, rank);
+					out[c] = fetch_exception_f32<4>(L, rec, rank, all_staged);
 					++rank;
 				}
 			}
@@ -241,12 +272,18 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 			const uint32_t idx = ((f0 >> ls) | (f1 << (16 - ls))) & lmsk;
 			uint32_t       l   = static_cast<uint32_t>((idx < 4 ? dlo >> (16 * idx) : dhi >> (16 * (idx & 3))) & 0xFFFFull);
 			if (hits & (1u << c)) {
-				l = fetch_exception_f32<2>(L, rec, rank);
+				l = fetch_exception_f32<2>(L, rec, rank, all_staged);
 				++rank;
 			}
 			out[c] = (l << rbw) | q[c];
 		}
 	}
+#if defined(ALPGPU_SINKF_STOP_AT) && ALPGPU_SINKF_STOP_AT == 6 // ... behind the exceptions, in front of the widening adds
+	if constexpr (SINK != kSinkStoreF) {
+		*acc += static_cast<double>(out[0] ^ out[1] ^ out[2] ^ out[3]);
+		return;
+	}
+#endif
 	if constexpr (SINK == kSinkSumF) {
 #pragma unroll
 		for (int c = 0; c < 4; ++c) { *acc += static_cast<double>(__uint_as_float(out[c])); }
@@ -430,6 +467,10 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	const bool               is_alp = d.scheme == ALPGPU_SCHEME_ALP;
 	const int                cnt    = d.exc_cnt;
 	ExcMaskF                 em {0u, 0};
+#if defined(ALPGPU_SINKF_STOP_AT) && ALPGPU_SINKF_STOP_AT == 1 // measurement builds: every wavefront ends behind stage n with one dependent store
+	if (lane == 0) { out[v] = static_cast<double>(d.bw + cnt) + static_cast<double>(dict.lo ^ dict.hi); }
+	return;
+#endif
 #if ALPGPU_SINK_STAGE_F32 > 0
 	// Round 4: a narrow ALP vector's words whole into the wavefront's LDS by LDS-DMA (1 KiB per instruction, no registers): ONE round trip for all
 	// of them instead of eight 16-byte buffer loads per lane — what took the double sink from 0.85 to 0.73 ms (profiles/r03_consumers.txt) and what
@@ -473,6 +514,11 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	constexpr int      kRsrcFlags = 0x00020000; // gfx9 raw buffer, 32-bit data format
 	const BufferWordsF words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d.bw, kRsrcFlags),
 	                          __builtin_amdgcn_make_buffer_rsrc(first + 128u * d.bw, 0, is_alp ? 0 : 128 * d.lbw, kRsrcFlags)};
+#if defined(ALPGPU_SINKF_STOP_AT) && ALPGPU_SINKF_STOP_AT == 2 // ... behind the issue of the loads and the exception mask
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (lane == 0) { out[v] = static_cast<double>(em.excl + static_cast<int>(em.word)); }
+	return;
+#endif
 	QuadWords w[4];
 #if ALPGPU_SINK_STAGE_F32 > 0
 	if (staged) {
@@ -487,6 +533,15 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 #pragma unroll
 		for (int q = 0; q < 4; ++q) { w[q] = request_quad_f32(words, d, 64 * q + lane); }
 	}
+#if defined(ALPGPU_SINKF_STOP_AT) && ALPGPU_SINKF_STOP_AT == 3 // ... behind the arrival of the quads' words
+	{
+		uint32_t x = 0;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { x ^= w[q].w0[0] ^ w[q].w0[1] ^ w[q].w0[2] ^ w[q].w0[3] ^ w[q].w1[0] ^ w[q].w1[1] ^ w[q].w1[2] ^ w[q].w1[3] ^ static_cast<uint32_t>(w[q].l0 ^ w[q].l1); }
+		out[v * 64 % n_vectors] = static_cast<double>(x);
+		return;
+	}
+#endif
 	double part[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int q = 0; q < 4; ++q) { finish_quad_f32<false, SINK>(L, w[q], d, dict, em, rec, nullptr, 64 * q + lane, q, lane, &part[q], lo, hi); }

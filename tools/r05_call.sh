@@ -172,5 +172,51 @@ case $step in
 	run 200 encode.txt python tools/r05_time_encode.py
 	grep -v "^==\|amdgpu.ids" "$out/encode.txt" | cut -c1-330
 	;;
+17) # per-stage instruction budget of k_sink_direct_f32: stop-at-stage builds under the SQ counters, three columns
+	for kind in clean mixed rd; do
+		for lib in sinkf_stop1 sinkf_stop2 sinkf_stop3 sinkf_stop4 sinkf_stop5 sinkf_stop6 ""; do
+			if [ -z "$lib" ]; then unset ALPGPU_LIB; tag=full; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; tag=$lib; fi
+			timeout 120 bash tools/pmc_busy.sh r05_${kind}_$tag python tools/r05_sinkf_counters.py $kind > /dev/null 2>&1
+			echo "$kind $tag: $(grep k_sink_direct_f32 gpurun_out/pmcb_r05_${kind}_$tag.txt | head -1)" | tee -a "$out/sinkf_budget.txt"
+		done
+	done
+	unset ALPGPU_LIB
+	;;
+18) # float exception values: LDS read + rare HBM read instead of one flat load per exception: tests, sink and decode against round 4's library (alternating)
+	run 300 pytest.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_reference_gpu.py -x -q
+	tail -3 "$out/pytest.txt"
+	for lib in r04 "" r04 ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 100 sink.txt python tools/time_sink_f32.py
+		SWEEP_VPW=2 run 100 f32.txt python tools/time_decode_f32.py
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/sink.txt" | cut -c1-120
+	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
+	;;
+19) for lib in f32head "" f32head ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 100 sink.txt python tools/time_sink_f32.py
+		SWEEP_VPW=2 run 100 f32.txt python tools/time_decode_f32.py
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/sink.txt" | cut -c1-120
+	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
+	;;
+20) for kind in clean mixed rd; do run 60 cols.txt python tools/r05_sinkf_counters.py $kind; done
+	grep -v "^==\|amdgpu.ids" "$out/cols.txt"
+	;;
+21) # float: exception values without a branch per value: parity, then sink / decode against the previous form (alternating)
+	run 300 pytest.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_reference_gpu.py tests/test_last_register_gpu.py -x -q
+	tail -3 "$out/pytest.txt"
+	for lib in f32head "" f32head ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 100 sink.txt python tools/time_sink_f32.py
+		for vpw in 2 4; do SWEEP_VPW=$vpw run 100 f32.txt python tools/time_decode_f32.py; done
+	done
+	unset ALPGPU_LIB
+	grep -v "^==\|amdgpu.ids" "$out/sink.txt" | cut -c1-120
+	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
