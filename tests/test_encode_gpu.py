@@ -485,6 +485,15 @@ def test_unordered_encode_writes_the_same_records_somewhere_else(ctx, oracle, na
     out2 = ctx.decode(back)
     ctx.synchronize()
     assert n_values == col_np.size and torch.equal(out2.view(torch.int64), x.view(torch.int64))
+    # the chunked host route uploads a blob's streams in pieces and relies on offsets that ascend with the vector index: it must either refuse
+    # such a blob with its own error or (a column whose records happen to be in order) decode it right — never read outside what it uploaded
+    from alp_amd import capi as _capi
+    host = torch.empty(col_np.size, dtype=torch.float64)
+    try:
+        nv = ctx.decompress_host(torch.from_numpy(blob), host)
+        assert nv == col_np.size and np.array_equal(host.numpy().view(np.uint64), col_np.view(np.uint64))
+    except _capi.AlpGpuError as exc:
+        assert "chunk" in str(exc) or "ascend" in str(exc), str(exc)
 
 
 def test_unordered_encode_of_a_large_column(ctx):
