@@ -218,5 +218,17 @@ case $step in
 	grep -v "^==\|amdgpu.ids" "$out/sink.txt" | cut -c1-120
 	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
 	;;
+final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
+	run 600 pytest.txt python -m pytest tests -m gpu -q
+	tail -4 "$out/pytest.txt"
+	run 120 smoke.txt python __graft_entry__.py smoke
+	tail -1 "$out/smoke.txt"
+	run 900 bench.txt python bench.py --steps 20 --warmup 5
+	grep "^{" "$out/bench.txt" | tail -1 > "$out/bench.json"; wc -c "$out/bench.json"
+	run 900 bench_configs4.txt python bench.py --gpus 1 --column-gb 100 --steps 10 --warmup 3
+	grep "^{" "$out/bench_configs4.txt" | tail -1 > "$out/bench_configs4_n1.json"; wc -c "$out/bench_configs4_n1.json"
+	timeout 1500 bash tools/profile_round.sh r05 > "$out/profile_round.txt" 2>&1
+	echo "profile rc $?"
+	;;
 *)  echo "unknown step $step"; exit 2 ;;
 esac
