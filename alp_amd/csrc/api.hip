@@ -40,6 +40,11 @@ struct alpgpu_ctx {
 	int         decode_pad_kib;    // ALPGPU_OPT_DECODE_RESIDENCY_PAD: KiB of unused dynamic LDS per decode workgroup (-1: chosen from the column's hints)
 	int         decode_patch_max;  // ALPGPU_OPT_DECODE_PATCH_AFTER: ALP vectors with 1..this many exceptions are patched after their stores (0: never; <= 64)
 	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
+	int         read_ahead;        // ALPGPU_OPT_DECODE_READ_AHEAD: the store decode runs with a read-ahead into the Infinity Cache on the second stream (read_ahead_kernels.hip)
+	int         read_ahead_us;     // ... about this many microseconds ahead of the decode kernel
+	int         read_ahead_grid;   // ... by this many four-wavefront workgroups
+	uint64_t*   d_progress;        // ... paced by this word of device memory (64 bytes: [0] the decode's position, tagged; [1] never written)
+	uint64_t    progress_gen;      // ... whose tag changes with every launch
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -142,6 +147,11 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
 	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
 	ctx->encode_unordered = std::getenv("ALPGPU_ENCODE_UNORDERED") ? std::atoi(std::getenv("ALPGPU_ENCODE_UNORDERED")) : 0; // (A/B runs)
+	ctx->read_ahead      = std::getenv("ALPGPU_DECODE_READ_AHEAD") ? std::atoi(std::getenv("ALPGPU_DECODE_READ_AHEAD")) : -1; // -1: by the column (read_ahead_for)
+	ctx->read_ahead_us   = std::getenv("ALPGPU_READ_AHEAD_US") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_US")) : 40;
+	ctx->read_ahead_grid = std::getenv("ALPGPU_READ_AHEAD_GRID") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_GRID")) : 64;
+	ctx->d_progress      = nullptr;
+	ctx->progress_gen    = 0;
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	ctx->ws_stream       = nullptr;
@@ -150,6 +160,14 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 		(void)hipStreamDestroy(ctx->own_stream);
 		delete ctx;
 		return fail(ALPGPU_ERR_HIP, "hipEventCreate failed");
+	}
+	if (hipMalloc(reinterpret_cast<void**>(&ctx->d_progress), 256) != hipSuccess || hipMemset(ctx->d_progress, 0, 256) != hipSuccess) {
+		if (ctx->d_progress) { (void)hipFree(ctx->d_progress); }
+		(void)hipEventDestroy(ctx->ws_event);
+		(void)hipStreamDestroy(ctx->init_stream);
+		(void)hipStreamDestroy(ctx->own_stream);
+		delete ctx;
+		return fail(ALPGPU_ERR_HIP, "hipMalloc of the context's progress word failed");
 	}
 	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { // A/B runs
 		ctx->decode_variant = std::atoi(v);
@@ -174,6 +192,7 @@ void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 	(void)hipStreamDestroy(ctx->init_stream);
 	(void)hipStreamDestroy(ctx->own_stream);
 	if (ctx->workspace) { (void)hipFree(ctx->workspace); }
+	if (ctx->d_progress) { (void)hipFree(ctx->d_progress); }
 	delete ctx;
 }
 
@@ -231,6 +250,14 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_DECODE_PATCH_AFTER:
 		if (value < 0 || value > 64) { return fail(ALPGPU_ERR_INVALID, "decode patch-after: 0 (never) .. 64 exceptions per vector"); }
 		ctx->decode_patch_max = static_cast<int>(value);
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_READ_AHEAD:
+		if (value < -1 || value > 1) { return fail(ALPGPU_ERR_INVALID, "decode read-ahead: -1 (columns of narrow vectors: the default), 0 (off) or 1 (on)"); }
+		ctx->read_ahead = value;
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_READ_AHEAD_US:
+		if (value < 1 || value > 10000) { return fail(ALPGPU_ERR_INVALID, "decode read-ahead lead: 1..10000 microseconds"); }
+		ctx->read_ahead_us = value;
 		return ALPGPU_OK;
 	case ALPGPU_OPT_CONSUMER_PIPELINED:
 		if (value < 0 || value > 3) { return fail(ALPGPU_ERR_INVALID, "consumer kernel: 0 (chosen per column), 1 (persistent LDS-ring kernel), 2 (one wavefront per vector, no stage) or 3 (four wavefronts per vector)"); }
@@ -485,6 +512,19 @@ static bool column_decodes_with_exceptions(const alpgpu_ctx* ctx, const alpgpu_c
 	return true;
 }
 
+// The store decode of this column runs with the read-ahead (read_ahead_kernels.hip).  Asked for (1): any column long enough to be worth a second launch whose
+// sizes are known (the lead is in vectors per microsecond).  Left to the library (-1, the default): columns of NARROW vectors only — up to kReadAheadBits packed
+// bits per value the decode is bound by its two dependent reads under a write-dominated stream (0.68-0.69 of the HBM peak at 2-6 bits, 0.60-0.65 with
+// exceptions) and gains 8-16 % from finding them in the Infinity Cache (0.75-0.80 / 0.68-0.74); at 8 bits it is even, from 12 bits on the second stream of
+// reads costs more than the hits save (benchmark column 0.77 -> 0.73).  tools/r05_read_ahead*.py, profiles/r05_read_ahead.txt.
+constexpr double   kReadAheadBits    = 7.0;
+constexpr uint64_t kReadAheadVectors = 262144; // shorter columns: the cold start and the join of the second stream eat the gain (cold columns: even at 131072 vectors)
+static bool read_ahead_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
+	if (ctx->read_ahead == 0 || col->packed_bytes_hint == 0 || ctx->d_progress == nullptr) { return false; }
+	if (ctx->read_ahead > 0) { return col->n_vectors >= 32768; }
+	return col->n_vectors >= kReadAheadVectors && static_cast<double>(col->packed_bytes_hint) <= kReadAheadBits * 128.0 * static_cast<double>(col->n_vectors);
+}
+
 static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	int variant = ctx->decode_variant;
 	if (ctx->decode_auto) { // pick the launch shape from the host-side size hints, if any
@@ -501,6 +541,9 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const double four_max = with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits; // (0 = never: the four-vector shape lost at every width, it is chosen by tuning runs only)
 		const bool   four     = four_max > 0.0 && bits <= four_max;
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
+		// narrow vectors under the read-ahead: their reads hit the Infinity Cache, and ONE vector per workgroup — the shape that suffers most from the two round
+		// trips (0.53 at 2-6 bits) — becomes the best one (0.75-0.80); with exceptions two per workgroup stay ahead (0.68-0.74 against 0.64-0.68)
+		if (ctx->read_ahead < 0 && read_ahead_for(ctx, col) && !with_exc) { variant = (variant & ~5) | 1; }
 	}
 	// Narrow vectors WITH exceptions: the pair kernel (k_decode_pairs, both vectors' loads in flight together when both are narrow, one after the
 	// other otherwise) is 1-4 % ahead of k_decode_column<2> up to 18 bits (tools/sweep_pairing.py, profiles/r04_decode_floor.txt section 4); without
@@ -515,7 +558,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	// columns.  Two vectors per workgroup: eight / seven / six workgroups by width.  ALPGPU_DECODE_PAD_LDS_KIB overrides (A/B runs; 0 = never cap).
 	const int pad_env = ctx->decode_pad_kib; // ALPGPU_OPT_DECODE_RESIDENCY_PAD / ALPGPU_DECODE_PAD_LDS_KIB: -1 = by the rule below
 	int pad_kib = pad_env >= 0 ? pad_env : 0;
-	if (pad_env < 0 && ctx->decode_auto && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
+	if (pad_env < 0 && ctx->decode_auto && pairing == 0 && col->packed_bytes_hint != 0 && col->n_vectors != 0 && !(ctx->read_ahead < 0 && read_ahead_for(ctx, col))) { // (under the read-ahead no cap helps)
 		const double n        = static_cast<double>(col->n_vectors);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
 		const bool   with_exc = column_decodes_with_exceptions(ctx, col);
@@ -683,7 +726,32 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
 	const int variant = decode_variant_for(ctx, col);
-	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max));
+	// The read-ahead (read_ahead_kernels.hip): a few persistent workgroups on the context's second stream pull the column's streams into the Infinity
+	// Cache a bounded distance ahead of the decode kernel, which tells them where it is.  Started first so that it is ahead from the first workgroup on.
+	const bool ahead = read_ahead_for(ctx, col);
+	uint64_t   tag   = 0;
+	if (ahead) {
+		ctx->progress_gen = (ctx->progress_gen + 1) & 0xFFFFFFull;
+		if (ctx->progress_gen == 0) { ctx->progress_gen = 1; }
+		tag = ctx->progress_gen << 40;
+		// The lead is a TIME (ALPGPU_OPT_DECODE_READ_AHEAD_US): what the read-ahead brings into the Infinity Cache stays there for some tens of
+		// microseconds only (the decode's own stores stream through it), and it has to be there before the decode asks.  In vectors: that time at the rate of
+		// a decode running at the full HBM bandwidth (an upper bound of the true rate: the read-ahead's naps by it never overshoot).
+		const double   n        = static_cast<double>(col->n_vectors);
+		const double   per_vec  = (static_cast<double>(col->packed_bytes_hint) + static_cast<double>(col->exc_bytes_hint)) / n + 32.0;
+		const double   ps_vec   = (8192.0 + per_vec) / 8.0;                                    // picoseconds per vector at 8 TB/s
+		const double   lead     = static_cast<double>(ctx->read_ahead_us) * 1.0e6 / ps_vec * 0.78; // ... vectors per lead time at the decode's usual 0.78 of that
+		const uint32_t lead_max = static_cast<uint32_t>(lead < 4096.0 ? 4096.0 : (lead > 4.0e9 ? 4.0e9 : lead));
+		const uint32_t lead_min = 2048; // about what is resident when a workgroup reports: those vectors' reads are under way
+		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, 8, ctx->d_progress, tag, lead_min, lead_max, static_cast<uint32_t>(ps_vec), ctx->read_ahead_grid) != ALPGPU_OK) {
+			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
+		}
+		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
+	}
+	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), (ahead && !std::getenv("ALPGPU_READ_AHEAD_NO_REPORT")) ? ctx->d_progress : nullptr, tag);
+	if (ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); } // (the read-ahead leaves on its own once its last batch is in reach or the decode never shows up)
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }

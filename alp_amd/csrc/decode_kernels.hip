@@ -653,14 +653,19 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
                                                                   const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                   const uint8_t* __restrict__ packed,
                                                                   const uint8_t* __restrict__ excs, double* __restrict__ out,
-                                                                  uint64_t n_vectors, uint64_t wg_offset, double lo, double hi, uint32_t patch_max) {
+                                                                  uint64_t n_vectors, uint64_t wg_offset, double lo, double hi, uint32_t patch_max,
+                                                                  uint64_t* __restrict__ progress, uint64_t progress_tag) {
 	static_assert(LDS::kStage == kStageBytes || SINK == kSinkStore, "the sinks pass their lane partials through a full stage");
 	__shared__ LDS L[V];
-		const int      tid  = static_cast<int>(threadIdx.x);
+	const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
 	const int      wave = wave_in_wg();
 	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
 	if (v0 >= n_vectors) { return; }
+	// the read-ahead's pace (read_ahead_kernels.hip): workgroups are dispatched in ascending order, every 128th says where the launch is
+	if (SINK == kSinkStore && progress != nullptr && (blockIdx.x & 127u) == 0 && tid == 0) {
+		__hip_atomic_store(progress, progress_tag | v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 
 	alpgpu_vector_desc d[V];
 	uint32_t           pos[V];
@@ -1012,7 +1017,7 @@ int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, 
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max) {
+int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max, uint64_t* progress, uint64_t progress_tag) {
 	(void)n_cus;
 	if (patch_max > 64u) { patch_max = 64u; } // one lane per patched exception (apply_patches)
 	const uint64_t n = col->n_vectors;
@@ -1045,17 +1050,17 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 4 && nt) {
-			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
+			hipLaunchKernelGGL((k_decode_column<4, true, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else if (V == 4) {
-			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
+			hipLaunchKernelGGL((k_decode_column<4, false, kSinkStore, DecodeLdsNarrow>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else if (V == 2 && nt) {
-			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
+			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
+			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else if (nt) {
-			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
+			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max);
+			hipLaunchKernelGGL((k_decode_column<1, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
@@ -1071,9 +1076,9 @@ int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_su
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		if (V == 2) {
-			hipLaunchKernelGGL((k_decode_column<2, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u);
+			hipLaunchKernelGGL((k_decode_column<2, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u, static_cast<uint64_t*>(nullptr), 0ull);
 		} else {
-			hipLaunchKernelGGL((k_decode_column<1, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u);
+			hipLaunchKernelGGL((k_decode_column<1, false, kSinkSum>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u, static_cast<uint64_t*>(nullptr), 0ull);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
@@ -1086,7 +1091,7 @@ int launch_decode_probe(hipStream_t stream, const alpgpu_column* col, double* d_
 	const uint64_t kMaxGrid = 1ull << 30;
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
-		hipLaunchKernelGGL((k_decode_column<2, false, kSinkProbe>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u);
+		hipLaunchKernelGGL((k_decode_column<2, false, kSinkProbe>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_sums, n, off, 0.0, 0.0, 0u, static_cast<uint64_t*>(nullptr), 0ull);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
@@ -1099,7 +1104,7 @@ int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, doub
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(64 * kDecWaves);
 		hipLaunchKernelGGL((k_decode_column<2, false, kSinkCount>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc,
-		                   reinterpret_cast<double*>(d_counts), n, off, lo, hi, 0u);
+		                   reinterpret_cast<double*>(d_counts), n, off, lo, hi, 0u, static_cast<uint64_t*>(nullptr), 0ull);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

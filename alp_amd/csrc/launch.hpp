@@ -13,7 +13,14 @@ constexpr int kStateUnpublished = 0xFF;
 
 // decode_kernels.hip
 // patch_max: ALP vectors with 1..patch_max (<= 64) exceptions are decoded without any per-value lookup and patched after their stores (0: never)
-int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max);
+// progress (nullable): a word of device memory the kernel's workgroups report their position to, tagged (read_ahead_kernels.hip)
+int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max, uint64_t* progress = nullptr,
+                         uint64_t progress_tag = 0);
+// read_ahead_kernels.hip: the column's descriptors, packed words and exception records read into the Infinity Cache a bounded distance ahead of the decode
+// kernel that reports to d_progress with this tag (lead_min / lead_max in vectors; value_bytes 8 or 4; grid workgroups of four wavefronts)
+// ps_per_vector: picoseconds the decode needs per vector AT LEAST (the read-ahead's workgroups sleep by it between looks at the progress word)
+int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
+                      uint32_t ps_per_vector, int grid);
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg);
 int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
 // the same sinks, one wavefront per vector, packed words straight from HBM (no stage, no barrier); count = false: per-vector sums (double), true: counts (u32)

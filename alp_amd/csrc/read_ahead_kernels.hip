@@ -1,0 +1,168 @@
+// read_ahead_kernels.hip — the store decode's READ-AHEAD (round 5): a small persistent kernel on the context's second stream that reads the column's
+// descriptors, packed words and exception records a bounded distance AHEAD of the decode kernel, so that the decode's two dependent reads (descriptor,
+// then the words it points at) are served by the 256 MiB Infinity Cache instead of HBM.
+//
+// Why (tools/r05_mall_warm.py, profiles/r05_read_ahead.txt): a decode workgroup's life is two dependent HBM round trips under a write-dominated stream,
+// then 8 KiB of stores.  With its inputs already in the Infinity Cache the SAME kernel runs at 0.90-0.94 of the HBM peak on 2-12-bit vectors (0.53-0.79
+// cold), with 20 exceptions per vector at 0.88-0.95 (0.53-0.78 cold); a bulk read of the streams in front of the launch gives the same figures as a
+// previous launch does.  The bytes still cross the HBM interface once — as long independent bursts of a kernel nobody waits for.
+//
+// Pacing: the decode kernel's workgroups are dispatched in ascending order; every 128th stores the index of its first vector to one word of context
+// memory (decode_kernels.hip: k_decode_column, `progress`).  The read-ahead's wavefronts take batches of 64 vectors round-robin and keep a batch within
+// [progress + lead_min, progress + lead_max): not so far ahead that the cache has dropped the lines again, not behind the decode.  The word carries
+// the launch's tag in its top bits, so a stale value of an earlier decode reads as "not started".  Best effort by construction: a read-ahead that
+// leaves early or never runs changes nothing but the decode's speed.
+#include "encode_lookback.hpp" // status_load, record_sizes
+#include "launch.hpp"
+
+#include <cstdlib>
+
+namespace alpgpu {
+
+#ifndef ALPGPU_AHEAD_WAVES
+#define ALPGPU_AHEAD_WAVES 8
+#endif
+constexpr int      kAheadWaves  = ALPGPU_AHEAD_WAVES; // wavefronts per read-ahead workgroup (few, fat workgroups: one lane of each polls)
+constexpr int      kAheadUnroll = 16;       // 16-byte loads in flight per lane and round (16 KiB per wavefront)
+constexpr uint64_t kAheadVecMask = (1ull << 40) - 1ull;
+constexpr uint64_t kAheadPatience = 5000000; // 10 ns ticks (50 ms) without news from the decode before a workgroup gives up
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+	for (int s = 1; s < 64; s <<= 1) {
+		const uint64_t o = __shfl_xor(v, s);
+		v                = o < v ? o : v;
+	}
+	return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+	for (int s = 1; s < 64; s <<= 1) {
+		const uint64_t o = __shfl_xor(v, s);
+		v                = o > v ? o : v;
+	}
+	return v;
+}
+__device__ __forceinline__ uint64_t wave_add_u64(uint64_t v) {
+#pragma unroll
+	for (int s = 1; s < 64; s <<= 1) { v += __shfl_xor(v, s); }
+	return v;
+}
+
+// the bytes [begin, end) of a stream, 16 per lane and load, kAheadUnroll loads in flight; returns something that depends on every word
+__device__ __forceinline__ uint32_t touch_span(const uint8_t* __restrict__ stream, uint64_t begin, uint64_t end, int lane) {
+	const uint64_t b = begin & ~15ull, e = end & ~15ull;
+	const uint4*   p = reinterpret_cast<const uint4*>(stream + b);
+	const uint64_t n = (e - b) >> 4;
+	uint32_t       x = 0;
+	for (uint64_t i = static_cast<uint64_t>(lane); i < n; i += 64ull * kAheadUnroll) {
+		uint4 r[kAheadUnroll];
+#pragma unroll
+		for (int k = 0; k < kAheadUnroll; ++k) {
+			const uint64_t j = i + 64ull * k;
+			r[k]             = j < n ? p[j] : uint4 {0u, 0u, 0u, 0u};
+		}
+#pragma unroll
+		for (int k = 0; k < kAheadUnroll; ++k) { x ^= r[k].x ^ r[k].w; }
+	}
+	return x;
+}
+
+// mode (experiments, ALPGPU_READ_AHEAD_MODE): bit 0 = pace only, read nothing; bit 1 = read without pacing; bit 2 = sleep ~1.5 ms and leave
+template <int VALUE_BYTES>
+__global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_vector_desc* __restrict__ descs, const uint8_t* __restrict__ packed,
+                                                                const uint8_t* __restrict__ excs, uint64_t n_vectors, const uint64_t* __restrict__ progress,
+                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t* __restrict__ hole, uint32_t mode) {
+	// One workgroup = kAheadWaves consecutive batches of 64 vectors per round; ONE lane of the workgroup reads the progress word, and while the round is
+	// out of reach it does so every ~7 us only: the word lives on one memory channel, and every poll of every waiting wavefront is a trip to it.
+	__shared__ uint64_t s_seen;
+	__shared__ uint32_t s_go;
+	const int      lane  = lane_id();
+	const int      wave  = wave_in_wg();
+	if (mode & 4u) { // experiment: resident for ~1.5 ms, touching nothing
+		for (int k = 0; k < 440; ++k) { __builtin_amdgcn_s_sleep(127); }
+		return;
+	}
+	const uint64_t round = static_cast<uint64_t>(gridDim.x) * kAheadWaves * 64;
+	uint32_t       x     = 0;
+	uint64_t       seen  = 0; // the decode's position as last read: first vector of a workgroup that has been dispatched
+	for (uint64_t wg_first = static_cast<uint64_t>(blockIdx.x) * kAheadWaves * 64; wg_first < n_vectors; wg_first += round) {
+		if (!(mode & 2u)) {
+			if (threadIdx.x == 0) {
+				// Sleep until the decode is lead_max vectors short of this round, by the clock: the decode advances at most one vector per ps_per_vector
+				// (the host's estimate at the full HBM rate, so the sleep never overshoots), 0.9 of the way per nap, one poll per nap.
+				uint32_t go      = 1;
+				uint64_t changed = wall_clock64();
+				for (;;) {
+					const uint64_t w = status_load((mode & 8u) ? progress + 16 : progress); // (bit 3, experiment: a word nobody writes)
+					if ((w & ~kAheadVecMask) == tag && (w & kAheadVecMask) > seen) { seen = w & kAheadVecMask, changed = wall_clock64(); }
+					if (wg_first < seen + lead_max) { break; }                          // in reach
+					if (wall_clock64() - changed > kAheadPatience) { go = 0; break; } // the decode is not coming (its launch failed?): leave
+					const uint64_t togo  = wg_first - (seen + lead_max) + 1;                       // vectors
+					uint64_t       ticks = (togo * ps_per_vector / 10000ull) * 9ull / 10ull;        // 10 ns ticks of wall_clock64()
+					ticks                = ticks < 100ull ? 100ull : (ticks > 20000ull ? 20000ull : ticks); // 1 us .. 200 us
+					const uint64_t until = wall_clock64() + ticks;
+					while (wall_clock64() < until) { __builtin_amdgcn_s_sleep(32); }
+				}
+				s_seen = seen, s_go = go;
+			}
+			__syncthreads();
+			seen                = s_seen;
+			const uint32_t go   = s_go;
+			__syncthreads();
+			if (!go) { break; }
+			if (wg_first + kAheadWaves * 64 <= seen + lead_min) { continue; } // the decode is already there
+		}
+		const uint64_t first = wg_first + static_cast<uint64_t>(wave) * 64;
+		if (first >= n_vectors || (mode & 1u)) { continue; }
+		const uint64_t     v = first + lane;
+		alpgpu_vector_desc d = descs[v < n_vectors ? v : n_vectors - 1];
+		uint64_t           pb, eb;
+		record_sizes<VALUE_BYTES>(d, pb, eb);
+		if (v >= n_vectors) { pb = eb = 0; }
+		x ^= static_cast<uint32_t>(d.base);
+		// a column written in vector order: the batch's records are one span of each stream.  Otherwise (ALPGPU_OPT_ENCODE_UNORDERED; a blob stitched by hand)
+		// record by record.
+		const uint64_t p_lo = wave_min_u64(pb ? d.packed_off : ~0ull), p_hi = wave_max_u64(pb ? d.packed_off + pb : 0ull), p_sum = wave_add_u64(pb);
+		const uint64_t e_lo = wave_min_u64(eb ? d.exc_off : ~0ull), e_hi = wave_max_u64(eb ? d.exc_off + eb : 0ull), e_sum = wave_add_u64(eb);
+		if (p_sum != 0) {
+			if (p_hi - p_lo <= 2 * p_sum) {
+				x ^= touch_span(packed, p_lo, p_hi, lane);
+			} else {
+				for (int j = 0; j < 64; ++j) {
+					const uint64_t o = __shfl(d.packed_off, j), s = __shfl(pb, j);
+					if (s) { x ^= touch_span(packed, o, o + s, lane); }
+				}
+			}
+		}
+		if (e_sum != 0) {
+			if (e_hi - e_lo <= 2 * e_sum + 4096) {
+				x ^= touch_span(excs, e_lo, e_hi, lane);
+			} else {
+				for (int j = 0; j < 64; ++j) {
+					const uint64_t o = __shfl(d.exc_off, j), s = __shfl(eb, j);
+					if (s) { x ^= touch_span(excs, o, o + s, lane); }
+				}
+			}
+		}
+	}
+	if (x == 0x9E3779B9u && n_vectors == ~0ull) { *hole = x; } // (never: what keeps the loads)
+}
+
+// lead_min / lead_max in vectors; value_bytes 8 (double column) or 4 (float column)
+int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
+                      uint32_t ps_per_vector, int grid) {
+	if (col->n_vectors == 0 || grid <= 0) { return ALPGPU_OK; }
+	static const uint32_t mode = std::getenv("ALPGPU_READ_AHEAD_MODE") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_MODE"))) : 0u;
+	uint32_t* hole = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(d_progress) + 1);
+	if (value_bytes == 8) {
+		hipLaunchKernelGGL((k_read_ahead<8>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
+		                   d_progress, tag, lead_min, lead_max, ps_per_vector, hole, mode);
+	} else {
+		hipLaunchKernelGGL((k_read_ahead<4>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
+		                   d_progress, tag, lead_min, lead_max, ps_per_vector, hole, mode);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+} // namespace alpgpu

@@ -217,6 +217,14 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * resident per CU (160 KiB / (its own 9.6 or 19.3 KiB + this)); -1 (default) = chosen from the column's size hints (what a CU wants
  * is an amount of bytes in flight).  Never changes results. */
 #define ALPGPU_OPT_DECODE_RESIDENCY_PAD 11
+/* ALPGPU_OPT_DECODE_READ_AHEAD (double store decode; round 5): alpgpu_decode_f64 starts a READ-AHEAD beside the decode kernel — a few persistent workgroups
+ * on the context's second stream that pull descriptors, packed words and exception records into the Infinity Cache about ALPGPU_OPT_DECODE_READ_AHEAD_US
+ * (default 40) microseconds ahead of the decode kernel, which tells them where it is; the decode's two dependent reads then hit the cache.
+ *   -1 (default)  columns of >= 262144 vectors of at most 7 packed bits per value on average whose size hints are set (+8-16 % there; wider columns lose);
+ *    0            never;   1  every column of >= 32768 vectors whose size hints are set (measurements).
+ * Same output bytes.  The two kernels are joined on the context's stream: work enqueued behind alpgpu_decode_f64 waits for both. */
+#define ALPGPU_OPT_DECODE_READ_AHEAD 12
+#define ALPGPU_OPT_DECODE_READ_AHEAD_US 13
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */

@@ -259,3 +259,121 @@ def test_shortcut_arithmetic_at_every_width(ctx, oracle, exceptions):
             assert bad.size == 0, (vpw, [rows[i] for i in bad[:5]])
     finally:
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+
+
+@pytest.mark.parametrize("lead_us", [1, 40])
+def test_read_ahead_does_not_change_a_byte(ctx, oracle, lead_us):
+    """ALPGPU_OPT_DECODE_READ_AHEAD: the decode kernel reports its position, a second kernel on the context's second stream reads the column's streams
+    ahead of it (read_ahead_kernels.hip).  A column long enough to take the option (>= 32768 vectors; widths 0..53 by rowgroup, every other rowgroup with
+    exceptions), every launch shape, a lead so short that the read-ahead waits for the decode all the time and the default one; four launches in a row
+    (the tag in the progress word changes per launch); against the plain decode bit for bit, and a sample of that against the oracle"""
+    import torch
+    from alp_amd import capi
+    rng = np.random.default_rng(5)
+    n = 40000
+    rgs = n // 100
+    bw_rg = rng.integers(0, 54, rgs)
+    bw = np.repeat(bw_rg, 100).astype(np.uint8)
+    c = np.repeat(np.where(np.arange(rgs) % 2 == 0, 0, 17), 100).astype(np.uint16)
+    enc = dict(scheme=np.full(n, 2, np.uint8), e=np.full(n, 14, np.uint8), f=np.full(n, 12, np.uint8), bw=bw,
+               lbw=np.zeros(n, np.uint8), base=rng.integers(-1000, 1000, n), exc_cnt=c,
+               packed=np.zeros((n, 1024), np.int64), packed_left=np.zeros((n, 1024), np.uint16),
+               exc=np.zeros((n, 1024), np.float64), pos=np.zeros((n, 1024), np.uint16), dict=np.zeros((rgs, 8), np.uint16),
+               dict_size=np.zeros(rgs, np.uint8), k=np.ones(rgs, np.uint8), combos=np.zeros((rgs, 10), np.int32))
+    for r in range(rgs):
+        w = 16 * int(bw_rg[r])
+        if w:
+            enc["packed"][100 * r: 100 * r + 100, :w] = rng.integers(-2**63, 2**63 - 1, (100, w), dtype=np.int64)
+    pos = np.sort(np.argsort(rng.random((n, 1024)), axis=1)[:, :17], axis=1)
+    enc["pos"][:, :17] = pos.astype(np.uint16)
+    enc["exc"][:, :17] = rng.integers(0, 2**64, (n, 17), dtype=np.uint64).view(np.float64)
+    rg, vec, packed, exc = layout.compact(enc)
+    col = capi.DeviceColumn.from_host(rg, vec, packed, exc)
+    try:
+        ref = ctx.decode(col).clone()
+        ctx.synchronize()
+        sample = {k: (a[:300] if a.shape[0] == n else a[:3]) for k, a in enc.items()}
+        assert np.array_equal(ref[:300 * 1024].cpu().numpy().view(np.uint64), oracle.decode_column(sample).view(np.uint64))
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 1)
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD_US, lead_us)
+        for vpw in (0, 1, 2, 0):
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+            out = torch.zeros_like(ref)
+            ctx.decode(col, out)
+            ctx.synchronize()
+            assert torch.equal(out.view(torch.int64), ref.view(torch.int64)), vpw
+    finally:
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD_US, 40)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+
+
+def test_read_ahead_over_a_column_encoded_out_of_order(ctx):
+    """records that are not in vector order (ALPGPU_OPT_ENCODE_UNORDERED): the read-ahead reads them record by record where a batch is not one span"""
+    import torch
+    from alp_amd import capi
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    n = 36000
+    x = torch.round(torch.rand(n * 1024, dtype=torch.float64, device="cuda:0", generator=g) * 1e4, decimals=2)
+    x[::97] = torch.rand(x[::97].shape, dtype=torch.float64, device="cuda:0", generator=g)  # exceptions
+    try:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
+        col = ctx.encode(x)
+        ctx.column_totals(col)
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 1)
+        out = ctx.decode(col)
+        ctx.synchronize()
+        assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
+
+
+@pytest.mark.parametrize("exc", [0, 20])
+def test_long_columns_of_narrow_vectors_take_the_read_ahead_by_themselves(ctx, oracle, exc):
+    """the default (ALPGPU_OPT_DECODE_READ_AHEAD = -1): a column of >= 262144 vectors of <= 7 bits runs with the read-ahead and the launch shape that goes
+    with it (one vector per workgroup without exceptions, two with); a wider or shorter one does not.  Same bytes as with the option off, and a sample of
+    them against the oracle's falp + patch"""
+    import torch
+    import bench
+    from alp_amd import capi
+    n = 270000
+    col, vec, _ = bench.build_decode_column(n, 0, seed=3, bw_of_rowgroup=3, exc_per_vec=exc)
+    wide, _, _ = bench.build_decode_column(n, 0, seed=3, bw_of_rowgroup=20, exc_per_vec=exc)
+    short, _, _ = bench.build_decode_column(140000, 0, seed=3, bw_of_rowgroup=3, exc_per_vec=exc)
+    try:
+        assert ctx.decode_vectors_per_wg(col) == (2 if exc else 1)
+        assert ctx.decode_vectors_per_wg(short) == 2 and ctx.decode_vectors_per_wg(wide) == (2 if exc else 1)  # (20 bits: one per workgroup from 17.5 bits on without exceptions)
+        got = ctx.decode(col).clone()
+        again = ctx.decode(col).clone()  # (the progress word's tag changes per launch)
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 0)
+        assert ctx.decode_vectors_per_wg(col) == 2
+        ref = ctx.decode(col)
+        ctx.synchronize()
+        assert torch.equal(got.view(torch.int64), ref.view(torch.int64)) and torch.equal(again.view(torch.int64), ref.view(torch.int64))
+        # the oracle on the first and the last 200 vectors
+        for lo in (0, n - 200):
+            idx = np.arange(lo, lo + 200)
+            sub = {k: vec[k][idx].copy() for k in ("bw", "e", "f", "base", "exc_cnt", "lbw")}
+            sub["scheme"] = vec["scheme"][idx].astype(np.uint8)
+            packed = np.zeros((200, 1024), np.uint64)
+            p8 = packed.view(np.uint8).reshape(200, 8192)
+            rec = (10 * exc + 7) // 8 * 8
+            sub["exc"] = np.zeros((200, 1024), np.float64)
+            sub["pos"] = np.zeros((200, 1024), np.uint16)
+            for i, v in enumerate(idx):
+                o = int(vec["packed_off"][v])
+                p8[i, : 128 * 3] = col.packed[o:o + 128 * 3].cpu().numpy()
+                if exc:
+                    r = col.exc[int(vec["exc_off"][v]): int(vec["exc_off"][v]) + rec].cpu().numpy()
+                    sub["exc"][i, :exc] = r[: 8 * exc].view(np.float64)
+                    sub["pos"][i, :exc] = r[8 * exc: 10 * exc].view(np.uint16)
+            sub["packed"] = packed
+            sub["packed_left"] = np.zeros((200, 1024), np.uint16)
+            sub["dict"] = np.zeros((3, 8), np.uint16)
+            sub["dict_size"] = np.zeros(3, np.uint8)
+            want = oracle.decode_column(sub)
+            assert np.array_equal(ref.view(-1, 1024)[lo:lo + 200].cpu().numpy().view(np.uint64).reshape(-1), want.view(np.uint64).reshape(-1))
+    finally:
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)

@@ -218,6 +218,94 @@ case $step in
 	grep -v "^==\|amdgpu.ids" "$out/sink.txt" | cut -c1-120
 	grep -v "^==\|amdgpu.ids" "$out/f32.txt"
 	;;
+22) # Infinity Cache: decode with its inputs resident / flushed / pre-read; segmented decode of a 1 Mi-vector column with the next segments pre-read
+	PARTS=1 run 400 mall.txt python tools/r05_mall_warm.py
+	PARTS=2 run 500 mall.txt python tools/r05_mall_warm.py
+	grep -v "^==\|amdgpu.ids" "$out/mall.txt"
+	;;
+23) # the read-ahead kernel beside the decode: parity, then shapes x pads x windows per width; two more grids on a few widths
+	run 300 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q -k "read_ahead or tuning or synthetic"
+	tail -3 "$out/pytest.txt"
+	run 600 ra.txt python tools/r05_read_ahead.py
+	for g in 32 256; do
+		ALPGPU_READ_AHEAD_GRID=$g WIDTHS=4,16,36,mix EXCS=0 WINDOWS=96 run 200 ra.txt python tools/r05_read_ahead.py
+	done
+	grep -v "^==\|amdgpu.ids" "$out/ra.txt"
+	;;
+24) # read-ahead, one poll per workgroup and ~7 us: what the pacing alone costs (mode 1), what unpaced reads do (mode 2), grids
+	run 200 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q -k "read_ahead"
+	tail -3 "$out/pytest.txt"
+	for g in 128 32; do for m in 0 1 2; do
+		echo "== grid $g mode $m" >>"$out/ra.txt"
+		ALPGPU_READ_AHEAD_GRID=$g ALPGPU_READ_AHEAD_MODE=$m WIDTHS=2,4,16,36,mix EXCS=0 PADS=0,14 WINDOWS=96,32 run 200 ra.txt python tools/r05_read_ahead.py
+	done; done
+	grep -v "amdgpu.ids\|== rc\|== python" "$out/ra.txt"
+	;;
+25) # what a nearly idle kernel on the second stream costs the decode: pace-only (mode 1) and sleep-only (mode 4) by grid and stream priority
+	for cfg in "1 8 high" "1 32 high" "1 128 high" "4 8 high" "4 32 high" "4 128 high" "4 128 normal" "4 128 low" "1 128 low" "0 32 low"; do
+		set -- $cfg
+		ALPGPU_READ_AHEAD_MODE=$1 ALPGPU_READ_AHEAD_GRID=$2 ALPGPU_INIT_STREAM_PRIO=$3 run 100 beside.txt python tools/r05_beside.py
+	done
+	grep "^mode" "$out/beside.txt"
+	;;
+26) # the pacing's cost taken apart (grid 128): polls of a word nobody writes; no reports from the decode; naps of 27 / 110 us; reports but no polls
+	for cfg in "1 0" "9 0" "1 1" "2049 0" "8193 0" "9 1"; do
+		set -- $cfg
+		if [ "$2" = 1 ]; then export ALPGPU_READ_AHEAD_NO_REPORT=1; else unset ALPGPU_READ_AHEAD_NO_REPORT; fi
+		echo "== mode $1 no_report $2" >>"$out/beside.txt"
+		ALPGPU_READ_AHEAD_MODE=$1 ALPGPU_READ_AHEAD_GRID=128 run 100 beside.txt python tools/r05_beside.py
+	done
+	grep "^mode\|^== mode" "$out/beside.txt"
+	;;
+27) # read-ahead by fat workgroups (8 / 16 wavefronts), naps of 14 / 27 us between polls: net effect per width, with the pace-only reference
+	for cfg in "1024 32 -" "2048 32 -" "1025 32 -" "1024 16 -" "1024 16 ra16" "2048 8 ra16"; do
+		set -- $cfg
+		if [ "$3" = - ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$3.so; fi
+		echo "== mode $1 grid $2 lib $3" >>"$out/ra.txt"
+		ALPGPU_READ_AHEAD_MODE=$1 ALPGPU_READ_AHEAD_GRID=$2 WIDTHS=2,4,16,36,mix EXCS=0,20 PADS=0,14 WINDOWS=96 run 200 ra.txt python tools/r05_read_ahead.py
+	done
+	unset ALPGPU_LIB
+	grep -v "amdgpu.ids\|== rc\|== python" "$out/ra.txt"
+	;;
+28) # read-ahead on narrow vectors, every width up to 12 bits: grids 32 / 64 of eight wavefronts, naps of 14 us
+	for g in 32 64; do
+		echo "== grid $g" >>"$out/ra.txt"
+		ALPGPU_READ_AHEAD_MODE=1024 ALPGPU_READ_AHEAD_GRID=$g WIDTHS=1,2,3,4,5,6,8,10,12 EXCS=0,20 PADS=0,3 WINDOWS=96,32 run 400 ra.txt python tools/r05_read_ahead.py
+	done
+	grep -v "amdgpu.ids\|== rc\|== python" "$out/ra.txt"
+	;;
+29) # the read-ahead's window per width and shape (grid 64 and 32 of eight wavefronts)
+	for g in 64 32; do
+		ALPGPU_READ_AHEAD_MODE=1024 ALPGPU_READ_AHEAD_GRID=$g run 500 win.txt python tools/r05_read_ahead_windows.py
+	done
+	grep -v "amdgpu.ids\|== rc\|== python" "$out/win.txt"
+	;;
+30) # the read-ahead paced by the clock: parity, then the lead (microseconds) per width and shape, grids 64 / 32 / 16 of eight wavefronts
+	run 200 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q -k "read_ahead"
+	tail -3 "$out/pytest.txt"
+	for g in 64 32 16; do
+		ALPGPU_READ_AHEAD_GRID=$g run 500 win.txt python tools/r05_read_ahead_windows.py
+	done
+	grep -v "amdgpu.ids\|== rc\|== python" "$out/win.txt"
+	;;
+31) # narrow columns under the read-ahead: residency pad x lead
+	for g in 64 128; do
+		ALPGPU_READ_AHEAD_GRID=$g run 500 pads.txt python tools/r05_read_ahead_pads.py
+	done
+	grep -v "amdgpu.ids\|== rc\|== python" "$out/pads.txt"
+	;;
+32) # the read-ahead chosen by the library: decode tests, where it starts to pay by column length, the bench line
+	run 400 pytest.txt python -m pytest tests/test_decode_gpu.py tests/test_sharding_gpu.py tests/test_dropin_gpu.py -x -q
+	tail -3 "$out/pytest.txt"
+	run 300 short.txt python tools/r05_read_ahead_short.py
+	grep -v "amdgpu.ids\|^==" "$out/short.txt"
+	run 400 bench.json python bench.py --steps 20 --warmup 5
+	tail -c 6000 "$out/bench.json"
+	;;
+33) # by column length, cold (2 GiB read between launches)
+	COLD=1 run 400 short.txt python tools/r05_read_ahead_short.py
+	grep -v "amdgpu.ids\|^==" "$out/short.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
