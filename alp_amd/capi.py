@@ -75,6 +75,7 @@ OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US = 12, 13
 ENCODE_KERNEL_LEAN, ENCODE_KERNEL_CLASSIC = 0, 1
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
+_sig("alpgpu_decode_reads_ahead", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
 try:
     _sig("alpgpu_debug_traffic_probe_with_search", _int, _vp, _vp, _vp, _u64, C.c_uint32, C.POINTER(CColumn))
@@ -271,6 +272,10 @@ class Context:
     def decode_vectors_per_wg(self, col: "DeviceColumn") -> int:
         """the launch shape decode() would use for this column now (vectors per decode workgroup)"""
         return int(lib.alpgpu_decode_vectors_per_wg(self.h, C.byref(col.c), 1 if col.dtype == "f32" else 0))
+
+    def decode_reads_ahead(self, col: "DeviceColumn") -> bool:
+        """decode() of this column would start the read-ahead beside the decode kernel (OPT_DECODE_READ_AHEAD)"""
+        return int(lib.alpgpu_decode_reads_ahead(self.h, C.byref(col.c), 1 if col.dtype == "f32" else 0)) == 1
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(128)

@@ -42,7 +42,8 @@ struct alpgpu_ctx {
 	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
 	int         read_ahead;        // ALPGPU_OPT_DECODE_READ_AHEAD: the store decode runs with a read-ahead into the Infinity Cache on the second stream (read_ahead_kernels.hip)
 	int         read_ahead_us;     // ... about this many microseconds ahead of the decode kernel
-	int         read_ahead_grid;   // ... by this many four-wavefront workgroups
+	int         read_ahead_grid;   // ... by this many eight-wavefront workgroups
+	int         read_ahead_bits;   // ... records of vectors of at most this many packed bits per value (the descriptors of all)
 	uint64_t*   d_progress;        // ... paced by this word of device memory (64 bytes: [0] the decode's position, tagged; [1] never written)
 	uint64_t    progress_gen;      // ... whose tag changes with every launch
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
@@ -150,6 +151,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->read_ahead      = std::getenv("ALPGPU_DECODE_READ_AHEAD") ? std::atoi(std::getenv("ALPGPU_DECODE_READ_AHEAD")) : -1; // -1: by the column (read_ahead_for)
 	ctx->read_ahead_us   = std::getenv("ALPGPU_READ_AHEAD_US") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_US")) : 40;
 	ctx->read_ahead_grid = std::getenv("ALPGPU_READ_AHEAD_GRID") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_GRID")) : 64;
+	ctx->read_ahead_bits = std::getenv("ALPGPU_READ_AHEAD_BITS") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_BITS")) : 128;
 	ctx->d_progress      = nullptr;
 	ctx->progress_gen    = 0;
 	ctx->workspace       = nullptr;
@@ -594,6 +596,12 @@ int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int 
 	return (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
 }
 
+// ... and whether it would start the read-ahead beside the decode kernel (ALPGPU_OPT_DECODE_READ_AHEAD): 1 / 0; negative on bad arguments
+int alpgpu_decode_reads_ahead(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32) {
+	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
+	return (!is_f32 && read_ahead_for(ctx, col)) ? 1 : 0;
+}
+
 // measurement aid: what alpgpu_decode_sum_f64 costs with its unpack arithmetic left out (decode_kernels.hip: kSinkProbe)
 int alpgpu_debug_decode_probe_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
 	ALPGPU_CHECK_CTX(ctx);
@@ -745,7 +753,7 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 		const uint32_t lead_min = 2048; // about what is resident when a workgroup reports: those vectors' reads are under way
 		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
 		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
-		if (alpgpu::launch_read_ahead(ctx->init_stream, col, 8, ctx->d_progress, tag, lead_min, lead_max, static_cast<uint32_t>(ps_vec), ctx->read_ahead_grid) != ALPGPU_OK) {
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, 8, ctx->d_progress, tag, lead_min, lead_max, static_cast<uint32_t>(ps_vec), static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
 			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
 		}
 		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));

@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t touch_span(const uint8_t* __restrict__ strea
 template <int VALUE_BYTES>
 __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_vector_desc* __restrict__ descs, const uint8_t* __restrict__ packed,
                                                                 const uint8_t* __restrict__ excs, uint64_t n_vectors, const uint64_t* __restrict__ progress,
-                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t* __restrict__ hole, uint32_t mode) {
+                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t max_bits, uint32_t* __restrict__ hole, uint32_t mode) {
 	// One workgroup = kAheadWaves consecutive batches of 64 vectors per round; ONE lane of the workgroup reads the progress word, and while the round is
 	// out of reach it does so every ~7 us only: the word lives on one memory channel, and every poll of every waiting wavefront is a trip to it.
 	__shared__ uint64_t s_seen;
@@ -119,7 +119,9 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 		alpgpu_vector_desc d = descs[v < n_vectors ? v : n_vectors - 1];
 		uint64_t           pb, eb;
 		record_sizes<VALUE_BYTES>(d, pb, eb);
-		if (v >= n_vectors) { pb = eb = 0; }
+		// max_bits: only vectors of at most this many packed bits per value are worth it (a column that mixes widths: the narrow vectors' two dependent reads are what
+		// the decode waits for; the wide ones' bytes would only cross the fabric twice).  The descriptors themselves — the first of the two reads — are read for all.
+		if (v >= n_vectors || pb > 128ull * max_bits) { pb = eb = 0; }
 		x ^= static_cast<uint32_t>(d.base);
 		// a column written in vector order: the batch's records are one span of each stream.  Otherwise (ALPGPU_OPT_ENCODE_UNORDERED; a blob stitched by hand)
 		// record by record.
@@ -151,16 +153,16 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 
 // lead_min / lead_max in vectors; value_bytes 8 (double column) or 4 (float column)
 int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
-                      uint32_t ps_per_vector, int grid) {
+                      uint32_t ps_per_vector, uint32_t max_bits, int grid) {
 	if (col->n_vectors == 0 || grid <= 0) { return ALPGPU_OK; }
 	static const uint32_t mode = std::getenv("ALPGPU_READ_AHEAD_MODE") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_MODE"))) : 0u;
 	uint32_t* hole = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(d_progress) + 1);
 	if (value_bytes == 8) {
 		hipLaunchKernelGGL((k_read_ahead<8>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_progress, tag, lead_min, lead_max, ps_per_vector, hole, mode);
+		                   d_progress, tag, lead_min, lead_max, ps_per_vector, max_bits, hole, mode);
 	} else {
 		hipLaunchKernelGGL((k_read_ahead<4>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_progress, tag, lead_min, lead_max, ps_per_vector, hole, mode);
+		                   d_progress, tag, lead_min, lead_max, ps_per_vector, max_bits, hole, mode);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

@@ -731,7 +731,8 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
 # ---- N = 1: configs[1] headline + extras -----------------------------------------------------------------------------------
 # What the extras' short keys mean (the line has to fit the 8 KB the driver keeps; this is the legend; every `frac` is algorithmic bytes / time / 8 TB/s):
 #   decode_sweep_by_bit_width[_2pct_exceptions]: one 1 Mi-vector column per bit width 1..53 (0 / 20 exceptions per vector): frac[i] and vpw[i] (vectors per decode
-#       workgroup the launch rule chose) for width i + 1; summary = min / argmin / p10 / mean / max of frac.
+#       workgroup the launch rule chose) for width i + 1; summary = min / argmin / p10 / mean / max of frac; widths 1..read_ahead_upto ran with the read-ahead
+#       kernel beside the decode (ALPGPU_OPT_DECODE_READ_AHEAD, the library's choice), no_read_ahead = the same columns with the option off.
 #   decode_tuning: [frac at 1 vector per workgroup, at 2, auto, auto's choice] per case;  decode_bimodal: first half 6 bits + 20 exceptions, second half 44 bits.
 #   decode_sum: per-vector SUM fused into the decode (k_sink_direct) — ms and frac; column_sum / count_range / ring (persistent LDS-ring kernel) / four_wave (staged kernel) fracs.
 #   encode_<column>: ms / frac / GBps of alpgpu_encode_f64 (search beside the encode), front_ms (search in front), init_ms + vectors_ms (the two halves alone), bits (compressed
@@ -766,17 +767,24 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     # EVERY width 1..53 (BASELINE.json configs[1] "bit-width sweep 1-53"), without exceptions and with 20 per vector (2 %); the summary prints
     # the minimum, the 10th percentile and the mean, so that the headline (the mean of a column that mixes the widths) cannot hide a floor
     def sweep_of(exc_per_vec):
-        fr, vpw = [], []
+        fr, vpw, ahead, plain = [], [], 0, []
         for bw in range(1, 54):
             c, _, ab = build_decode_column(n, local_rank, seed=7, bw_of_rowgroup=bw, exc_per_vec=exc_per_vec)
             med, _ = time_launches(lambda: ctx.decode(c, out), 7, 6)
             fr.append(round(ab / med / 1e6 / HBM_PEAK_GBPS, 3))
             vpw.append(ctx.decode_vectors_per_wg(c))
+            if ctx.decode_reads_ahead(c):  # the library runs this width with the read-ahead: the same column with the option off, same run
+                ahead = bw
+                ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 0)
+                med, _ = time_launches(lambda: ctx.decode(c, out), 7, 6)
+                plain.append(round(ab / med / 1e6 / HBM_PEAK_GBPS, 3))
+                ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
             del c
         a = np.array(fr)
         summary = {"min": round(float(a.min()), 4), "argmin_bit_width": int(a.argmin()) + 1, "p10": round(float(np.percentile(a, 10)), 4),
-                   "mean": round(float(a.mean()), 4), "max": round(float(a.max()), 4), "widths": 53, "exceptions_per_vector": exc_per_vec}
-        return {"frac": fr, "vpw": vpw, "summary": summary}
+                   "mean": round(float(a.mean()), 4), "max": round(float(a.max()), 4), "widths": 53, "exceptions_per_vector": exc_per_vec,
+                   "read_ahead_upto": ahead}
+        return {"frac": fr, "vpw": vpw, "no_read_ahead": plain, "summary": summary}
     for key, exc_ in (("decode_sweep_by_bit_width", 0), ("decode_sweep_by_bit_width_2pct_exceptions", 20)):
         extras[key] = sweep_of(exc_)
         summaries[key] = extras[key]["summary"]

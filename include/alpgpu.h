@@ -229,6 +229,8 @@ int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
 int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
+/* ... and whether that decode would run with the read-ahead beside it (ALPGPU_OPT_DECODE_READ_AHEAD): 1 / 0; negative on bad arguments */
+int         alpgpu_decode_reads_ahead(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
 /* ---- host-resident columns -----------------------------------------------------------------------------------------------
  * The reference's callers (publication/source_code/bench_compression_ratio/alp.cpp:198-229) hold the column and what they
  * compress it into in host memory.  These entry points take it from there: n_values values at h_in (the last vector may be

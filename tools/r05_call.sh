@@ -306,6 +306,12 @@ case $step in
 	COLD=1 run 400 short.txt python tools/r05_read_ahead_short.py
 	grep -v "amdgpu.ids\|^==" "$out/short.txt"
 	;;
+34) # columns that are not narrow: descriptors of all vectors + records of the narrow ones only, by grid
+	for g in 16 32 64; do for b in 0 7 12 128; do
+		ALPGPU_READ_AHEAD_GRID=$g ALPGPU_READ_AHEAD_BITS=$b run 100 mix.txt python tools/r05_read_ahead_mix.py
+	done; done
+	grep "^grid" "$out/mix.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
