@@ -46,6 +46,7 @@ struct alpgpu_ctx {
 	int         read_ahead_bits;   // ... records of vectors of at most this many packed bits per value (the descriptors of all)
 	uint64_t*   d_progress;        // ... paced by this word of device memory (64 bytes: [0] the decode's position, tagged; [1] never written)
 	uint64_t    progress_gen;      // ... whose tag changes with every launch
+	uint32_t    wall_tick_ps;      // picoseconds per tick of the device's wall_clock64() (the read-ahead's naps)
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -154,6 +155,12 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->read_ahead_bits = std::getenv("ALPGPU_READ_AHEAD_BITS") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_BITS")) : 128;
 	ctx->d_progress      = nullptr;
 	ctx->progress_gen    = 0;
+	{
+		int khz = 0;
+		if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { khz = 100000; } // 100 MHz: gfx9's s_memrealtime
+		ctx->wall_tick_ps = static_cast<uint32_t>(1000000000ll / khz);
+		if (ctx->wall_tick_ps == 0) { ctx->wall_tick_ps = 1; }
+	}
 	ctx->workspace       = nullptr;
 	ctx->workspace_bytes = 0;
 	ctx->ws_stream       = nullptr;
@@ -753,7 +760,7 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 		const uint32_t lead_min = 2048; // about what is resident when a workgroup reports: those vectors' reads are under way
 		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
 		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
-		if (alpgpu::launch_read_ahead(ctx->init_stream, col, 8, ctx->d_progress, tag, lead_min, lead_max, static_cast<uint32_t>(ps_vec), static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, 8, ctx->d_progress, tag, lead_min, lead_max, static_cast<uint32_t>(ps_vec), ctx->wall_tick_ps, static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
 			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
 		}
 		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));

@@ -18,9 +18,10 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
                          uint64_t progress_tag = 0);
 // read_ahead_kernels.hip: the column's descriptors, packed words and exception records read into the Infinity Cache a bounded distance ahead of the decode
 // kernel that reports to d_progress with this tag (lead_min / lead_max in vectors; value_bytes 8 or 4; grid workgroups of four wavefronts)
-// ps_per_vector: picoseconds the decode needs per vector AT LEAST (the read-ahead's workgroups sleep by it between looks at the progress word)
+// ps_per_vector: picoseconds the decode needs per vector AT LEAST (the read-ahead's workgroups sleep by it between looks at the progress word);
+// ps_per_tick: of wall_clock64() on this device (hipDeviceAttributeWallClockRate)
 int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
-                      uint32_t ps_per_vector, uint32_t max_bits, int grid); // max_bits: records of wider vectors are left alone (their descriptors are read)
+                      uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid); // max_bits: records of wider vectors are left alone (their descriptors are read)
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg);
 int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
 // the same sinks, one wavefront per vector, packed words straight from HBM (no stage, no barrier); count = false: per-vector sums (double), true: counts (u32)

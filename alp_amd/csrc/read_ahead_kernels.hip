@@ -25,7 +25,7 @@ namespace alpgpu {
 constexpr int      kAheadWaves  = ALPGPU_AHEAD_WAVES; // wavefronts per read-ahead workgroup (few, fat workgroups: one lane of each polls)
 constexpr int      kAheadUnroll = 16;       // 16-byte loads in flight per lane and round (16 KiB per wavefront)
 constexpr uint64_t kAheadVecMask = (1ull << 40) - 1ull;
-constexpr uint64_t kAheadPatience = 5000000; // 10 ns ticks (50 ms) without news from the decode before a workgroup gives up
+constexpr uint64_t kAheadPatiencePs = 50000000000ull; // 50 ms without news from the decode before a workgroup gives up
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t touch_span(const uint8_t* __restrict__ strea
 template <int VALUE_BYTES>
 __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_vector_desc* __restrict__ descs, const uint8_t* __restrict__ packed,
                                                                 const uint8_t* __restrict__ excs, uint64_t n_vectors, const uint64_t* __restrict__ progress,
-                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t max_bits, uint32_t* __restrict__ hole, uint32_t mode) {
+                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, uint32_t* __restrict__ hole, uint32_t mode) {
 	// One workgroup = kAheadWaves consecutive batches of 64 vectors per round; ONE lane of the workgroup reads the progress word, and while the round is
 	// out of reach it does so every ~7 us only: the word lives on one memory channel, and every poll of every waiting wavefront is a trip to it.
 	__shared__ uint64_t s_seen;
@@ -97,10 +97,11 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 					const uint64_t w = status_load((mode & 8u) ? progress + 16 : progress); // (bit 3, experiment: a word nobody writes)
 					if ((w & ~kAheadVecMask) == tag && (w & kAheadVecMask) > seen) { seen = w & kAheadVecMask, changed = wall_clock64(); }
 					if (wg_first < seen + lead_max) { break; }                          // in reach
-					if (wall_clock64() - changed > kAheadPatience) { go = 0; break; } // the decode is not coming (its launch failed?): leave
+					if (wall_clock64() - changed > kAheadPatiencePs / ps_per_tick) { go = 0; break; } // the decode is not coming (its launch failed?): leave
 					const uint64_t togo  = wg_first - (seen + lead_max) + 1;                       // vectors
-					uint64_t       ticks = (togo * ps_per_vector / 10000ull) * 9ull / 10ull;        // 10 ns ticks of wall_clock64()
-					ticks                = ticks < 100ull ? 100ull : (ticks > 20000ull ? 20000ull : ticks); // 1 us .. 200 us
+					uint64_t       ticks = (togo * ps_per_vector / ps_per_tick) * 9ull / 10ull;        // ticks of wall_clock64() (100 MHz on MI355X; the host asks the runtime)
+					const uint64_t t_min = 1000000ull / ps_per_tick, t_max = 200000000ull / ps_per_tick; // 1 us .. 200 us
+					ticks                = ticks < t_min ? t_min : (ticks > t_max ? t_max : ticks);
 					const uint64_t until = wall_clock64() + ticks;
 					while (wall_clock64() < until) { __builtin_amdgcn_s_sleep(32); }
 				}
@@ -153,16 +154,16 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 
 // lead_min / lead_max in vectors; value_bytes 8 (double column) or 4 (float column)
 int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
-                      uint32_t ps_per_vector, uint32_t max_bits, int grid) {
+                      uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid) {
 	if (col->n_vectors == 0 || grid <= 0) { return ALPGPU_OK; }
 	static const uint32_t mode = std::getenv("ALPGPU_READ_AHEAD_MODE") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_MODE"))) : 0u;
 	uint32_t* hole = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(d_progress) + 1);
 	if (value_bytes == 8) {
 		hipLaunchKernelGGL((k_read_ahead<8>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_progress, tag, lead_min, lead_max, ps_per_vector, max_bits, hole, mode);
+		                   d_progress, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, hole, mode);
 	} else {
 		hipLaunchKernelGGL((k_read_ahead<4>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_progress, tag, lead_min, lead_max, ps_per_vector, max_bits, hole, mode);
+		                   d_progress, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, hole, mode);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

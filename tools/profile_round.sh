@@ -9,6 +9,7 @@
 #   narrow: python tools/time_one.py 8:1048576:2                         (k_decode_column<2, true>: the two-vectors-per-workgroup decode of a narrow column)
 #   sinkf: python tools/prof_sink_direct_f32.py 1048576                  (k_sink_direct_f32 and the staged float SUM sink)
 #   shapes: python tools/prof_decode_shapes.py 1048576                   (the auto rule's other decode launches: k_decode_pairs, two vectors x six workgroups per CU, one x six)
+#   ahead: python tools/prof_read_ahead.py 1048576                       (k_read_ahead beside k_decode_column<1> / <2> on 3- and 4-bit columns; kernel stats only mean something without --pmc)
 # (enc / encrd also decode what they encoded: the ALP_RD column's k_decode_column row; encf runs the float search in front of the float encode)
 # raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_* (run the summary LOCALLY on the
 # merged directory, and remove a stale local gpurun_out/<tag>_prof first: rocprofv3 names its files after process ids, a second run
@@ -37,6 +38,7 @@ run cons python $ROOT/tools/prof_consumers.py 0 1048576
 run narrow python $ROOT/tools/time_one.py 8:1048576:2
 run sinkf python $ROOT/tools/prof_sink_direct_f32.py 1048576
 run shapes python $ROOT/tools/prof_decode_shapes.py 1048576
+run ahead python $ROOT/tools/prof_read_ahead.py 1048576
 cd $ROOT
 if [ -f $OUT/dec_stats.log ]; then grep -h '"metric"' $OUT/dec_stats.log | tail -1 > $OUT/bench_under_rocprof.json; fi
 python tools/summarize_round.py $TAG $OUT
