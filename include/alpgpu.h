@@ -191,7 +191,7 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 #define ALPGPU_OPT_ENCODE_KERNEL 7
 #define ALPGPU_ENCODE_KERNEL_LEAN 0
 #define ALPGPU_ENCODE_KERNEL_CLASSIC 1
-/* ALPGPU_OPT_DECODE_PAIRING (double store decode only; 0 = chosen by the library, the default: form 1 for columns of narrow vectors with exceptions): workgroups that own two consecutive vectors and choose how to
+/* ALPGPU_OPT_DECODE_PAIRING (double store decode only; 0 = the library's choice, the default — since round 5 never this kernel): workgroups that own two consecutive vectors and choose how to
  * run them from the two descriptors — 1: together when both are narrow, else one after the other; 2: as 1 with the second vector's loads issued in front
  * of the first one's unpack; 3: three vectors per two workgroups.  Same output bytes as every other shape (tests/test_decode_gpu.py). */
 #define ALPGPU_OPT_DECODE_PAIRING 8
