@@ -312,6 +312,9 @@ case $step in
 	done; done
 	grep "^grid" "$out/mix.txt"
 	;;
+35) run 300 stride.txt python tools/r05_stride.py
+	grep -v "amdgpu.ids\|^==" "$out/stride.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"

@@ -8,6 +8,7 @@ Part 1  small columns (N1 vectors, everything a launch reads fits the cache): pe
         pre   = flush, then a bulk read of the column's streams, then the timed launch.
 Part 2  1 Mi-vector columns decoded in segments of SEG_MB of input each through column views, the next segments' streams read on a side stream while
         a segment is decoded: whole = the library's one launch (auto rule), seg = segments without the reads, seg+pre = with them.
+        (Part 2's seg+pre figures are CPU-bound — dozens of torch ops per segment — and were discarded; k_read_ahead replaced the idea.)
 Fractions of 8 TB/s on algorithmic bytes."""
 import ctypes as C
 import os
