@@ -125,9 +125,16 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	}
 	bool     fresh1 = true, fresh2 = true;
 	if (i != 0) {
+#ifdef ALPGPU_LOOK_REPOLL_MISSING // experiment (round 5, call 36): a word that has arrived is not read again — tile words are written once.  No difference (2.91-2.98 against 2.89-2.97 ms): off
+		uint64_t st = first1;
+		for (;;) {
+			if (!fresh1 && lane < i && (st >> 62) == 0) { st = status_load(status + (tile - 1 - lane)); }
+			fresh1 = false;
+#else
 		for (;;) {
 			const uint64_t st = fresh1 ? first1 : (lane < i ? status_load(status + (tile - 1 - lane)) : kFlagAggregate);
 			fresh1            = false;
+#endif
 			if (ballot64((st >> 62) == 0) == 0) {
 				local = wave_sum_u64(st & ~(3ull << 62));
 				break;
@@ -158,9 +165,24 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 	uint64_t base = 0;
 	if (block != 0 && !stalled) {
 		int64_t look = static_cast<int64_t>(block) - 1; // nearest block not yet accounted for
+#ifdef ALPGPU_LOOK_REPOLL_MISSING
+		uint64_t st      = first2;
+		int64_t  st_look = look; // the window st was read for
+#endif
 		while (look >= 0) {
 			const int64_t  idx        = look - lane;
+#ifdef ALPGPU_LOOK_REPOLL_MISSING
+			if (!fresh2) {
+				if (st_look != look) {
+					st      = idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix;
+					st_look = look;
+				} else if (idx >= 0 && (st >> 62) == 0) {
+					st = status_load(bstatus + idx);
+				}
+			}
+#else
 			const uint64_t st         = fresh2 ? first2 : (idx >= 0 ? status_load(bstatus + idx) : kFlagPrefix);
+#endif
 			fresh2                    = false;
 			const uint64_t fl         = st >> 62;
 			const uint64_t has_prefix = ballot64(fl == 2);

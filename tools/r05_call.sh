@@ -315,6 +315,14 @@ case $step in
 35) run 300 stride.txt python tools/r05_stride.py
 	grep -v "amdgpu.ids\|^==" "$out/stride.txt"
 	;;
+36) # look-back that does not read an arrived word again: default library against the variant, alternating
+	for lib in "" repoll "" repoll; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 120 enc.txt python tools/r05_time_encode.py
+	done
+	unset ALPGPU_LIB
+	grep "^lib\|^mixed\|^rd" "$out/enc.txt" | cut -c1-330
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
