@@ -71,11 +71,12 @@ _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
 OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL, OPT_CONSUMER_PIPELINED, OPT_ENCODE_ASYNC_INIT, OPT_ENCODE_KERNEL, OPT_DECODE_PAIRING = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_DECODE_PATCH_AFTER, OPT_ENCODE_UNORDERED, OPT_DECODE_RESIDENCY_PAD = 9, 10, 11
-OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US = 12, 13
+OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US, OPT_DECODE_SEGMENTS = 12, 13, 14
 ENCODE_KERNEL_LEAN, ENCODE_KERNEL_CLASSIC = 0, 1
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_decode_reads_ahead", _int, _vp, C.POINTER(CColumn), _int)
+_sig("alpgpu_decode_runs", _int, _vp, C.POINTER(CColumn))
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
 try:
     _sig("alpgpu_debug_traffic_probe_with_search", _int, _vp, _vp, _vp, _u64, C.c_uint32, C.POINTER(CColumn))
@@ -272,6 +273,10 @@ class Context:
     def decode_vectors_per_wg(self, col: "DeviceColumn") -> int:
         """the launch shape decode() would use for this column now (vectors per decode workgroup)"""
         return int(lib.alpgpu_decode_vectors_per_wg(self.h, C.byref(col.c), 1 if col.dtype == "f32" else 0))
+
+    def decode_runs(self, col: "DeviceColumn") -> int:
+        """launches decode() of this column would make now: 1, or the runs of regions of different kinds (OPT_DECODE_SEGMENTS; after column_totals / from_blob)"""
+        return int(lib.alpgpu_decode_runs(self.h, C.byref(col.c)))
 
     def decode_reads_ahead(self, col: "DeviceColumn") -> bool:
         """decode() of this column would start the read-ahead beside the decode kernel (OPT_DECODE_READ_AHEAD)"""

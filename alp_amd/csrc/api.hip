@@ -15,6 +15,19 @@
 #include "../../include/alpgpu.h"
 #include "launch.hpp"
 
+// Per-segment sizes of a column (segments of seg_vectors consecutive vectors, a multiple of 400): what a launch rule that sees more than the column's
+// averages needs.  Host-side, in the context, keyed by the descriptor buffer: struct alpgpu_column stays as it is (ABI 3).
+constexpr int kMaxSegments = 32;
+struct SegmentTable {
+	const void* key;         // col->d_vectors (nullptr: empty slot)
+	uint64_t    n_vectors;
+	uint64_t    seg_vectors;
+	uint32_t    n_seg;
+	uint64_t    packed[kMaxSegments];  // bytes of packed records
+	uint64_t    exc_cnt[kMaxSegments]; // exceptions
+	uint64_t    rd_vectors[kMaxSegments]; // vectors of ALP_RD rowgroups
+};
+
 struct alpgpu_ctx {
 	int         device;
 	hipStream_t own_stream;
@@ -44,9 +57,12 @@ struct alpgpu_ctx {
 	int         read_ahead_us;     // ... about this many microseconds ahead of the decode kernel
 	int         read_ahead_grid;   // ... by this many eight-wavefront workgroups
 	int         read_ahead_bits;   // ... records of vectors of at most this many packed bits per value (the descriptors of all)
-	uint64_t*   d_progress;        // ... paced by this word of device memory (64 bytes: [0] the decode's position, tagged; [1] never written)
+	uint64_t*   d_progress;        // ... paced by this word of device memory (2 KiB: [0] the decode's position, tagged; [1] never written; [64..159] alpgpu_column_totals' segment sums)
 	uint64_t    progress_gen;      // ... whose tag changes with every launch
 	uint32_t    wall_tick_ps;      // picoseconds per tick of the device's wall_clock64() (the read-ahead's naps)
+	int         decode_segments;   // ALPGPU_OPT_DECODE_SEGMENTS: a column whose regions differ is decoded region by region, each with its own launch shape (1, default)
+	SegmentTable seg_tables[4];    // ... from the per-segment sizes alpgpu_column_totals / alpgpu_column_from_blob last saw (host-side, keyed by the descriptor buffer)
+	int         seg_next;
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -83,6 +99,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 } // namespace
 
 extern "C" {
+
+static void segment_table_forget(alpgpu_ctx* ctx, const alpgpu_column* col); // (a column that is encoded again has new regions: below, with the decode's launch plan)
 
 int alpgpu_abi_version(void) { return 3; } // 2: alpgpu_column.d_rd_order; 3: alpgpu_column.alp_rd_rowgroups_hint
 
@@ -152,6 +170,9 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->read_ahead      = std::getenv("ALPGPU_DECODE_READ_AHEAD") ? std::atoi(std::getenv("ALPGPU_DECODE_READ_AHEAD")) : -1; // -1: by the column (read_ahead_for)
 	ctx->read_ahead_us   = std::getenv("ALPGPU_READ_AHEAD_US") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_US")) : 40;
 	ctx->read_ahead_grid = std::getenv("ALPGPU_READ_AHEAD_GRID") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_GRID")) : 64;
+	ctx->decode_segments = std::getenv("ALPGPU_DECODE_SEGMENTS") ? std::atoi(std::getenv("ALPGPU_DECODE_SEGMENTS")) : 1;
+	for (auto& t : ctx->seg_tables) { t.key = nullptr; }
+	ctx->seg_next        = 0;
 	ctx->read_ahead_bits = std::getenv("ALPGPU_READ_AHEAD_BITS") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_BITS")) : 128;
 	ctx->d_progress      = nullptr;
 	ctx->progress_gen    = 0;
@@ -170,7 +191,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 		delete ctx;
 		return fail(ALPGPU_ERR_HIP, "hipEventCreate failed");
 	}
-	if (hipMalloc(reinterpret_cast<void**>(&ctx->d_progress), 256) != hipSuccess || hipMemset(ctx->d_progress, 0, 256) != hipSuccess) {
+	if (hipMalloc(reinterpret_cast<void**>(&ctx->d_progress), 2048) != hipSuccess || hipMemset(ctx->d_progress, 0, 2048) != hipSuccess) {
 		if (ctx->d_progress) { (void)hipFree(ctx->d_progress); }
 		(void)hipEventDestroy(ctx->ws_event);
 		(void)hipStreamDestroy(ctx->init_stream);
@@ -267,6 +288,10 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_DECODE_READ_AHEAD_US:
 		if (value < 1 || value > 10000) { return fail(ALPGPU_ERR_INVALID, "decode read-ahead lead: 1..10000 microseconds"); }
 		ctx->read_ahead_us = value;
+		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_SEGMENTS:
+		if (value < 0 || value > 1) { return fail(ALPGPU_ERR_INVALID, "decode by segments: 0 (off) or 1 (on)"); }
+		ctx->decode_segments = value;
 		return ALPGPU_OK;
 	case ALPGPU_OPT_CONSUMER_PIPELINED:
 		if (value < 0 || value > 3) { return fail(ALPGPU_ERR_INVALID, "consumer kernel: 0 (chosen per column), 1 (persistent LDS-ring kernel), 2 (one wavefront per vector, no stage) or 3 (four wavefronts per vector)"); }
@@ -445,7 +470,10 @@ static int encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
 	return workspace_used(ctx);
 }
-int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) { return encode_vectors_f64(ctx, d_in, n_vectors, col, false); }
+int alpgpu_encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	segment_table_forget(ctx, col);
+	return encode_vectors_f64(ctx, d_in, n_vectors, col, false);
+}
 
 // Rowgroup search + vector encode.
 // Short columns (and ALPGPU_OPT_ENCODE_ASYNC_INIT = 0, and the two-pass form): one after the other on the context's stream.
@@ -502,6 +530,7 @@ static int encode_with_side_search(alpgpu_ctx* ctx, const T* d_in, uint64_t n_ve
 } // extern "C++"
 
 int alpgpu_encode_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	segment_table_forget(ctx, col);
 	const uint64_t n_rg = (n_vectors + 99) / 100;
 	if (!ctx || !ctx->async_init || ctx->encode_two_pass || n_rg < kAsyncMinRowgroups) {
 		if (int rc = alpgpu_rowgroup_init_f64(ctx, d_in, n_vectors, col)) { return rc; }
@@ -592,6 +621,100 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		}
 	}
 	return (variant & 7) | (pairing << 3) | (pad_kib << 8);
+}
+
+// ---- a launch rule that sees more than the column's averages (round 5) -------------------------------------------------------------------------
+// alpgpu_column_totals and alpgpu_column_from_blob record, per segment of the column, what they record for the whole: packed bytes, exceptions, ALP_RD
+// vectors.  alpgpu_decode_f64 of that column (same context, same descriptor buffer) merges adjacent segments of the same KIND — by packed width: up to the
+// read-ahead's 7 bits / up to the two-vectors-per-workgroup limit / below 38 bits / beyond; with or without exceptions — into runs and decodes run by run,
+// each through the rule above with the run's own sizes: a column whose first half is 6-bit vectors with exceptions and whose second half is 44-bit vectors
+// (bench.py: decode_bimodal) gets two vectors per workgroup + the read-ahead for the first and one per workgroup, six workgroups per CU, for the second,
+// instead of the shape of their average.  One kind, or more than kMaxRuns runs (a column that changes every few thousand vectors is served by its average): the
+// whole column in one launch, as before.  ALPGPU_OPT_DECODE_SEGMENTS = 0: never.  Launch shapes only: the bytes cannot differ.
+constexpr uint64_t kSegmentMinVectors = 32800; // a multiple of 400: runs begin on rowgroup boundaries and on even vectors
+constexpr int      kMaxRuns           = 8;
+struct DecodeRun {
+	uint64_t v0, n, packed, exc_bytes, rd_vectors;
+};
+
+static uint64_t segment_vectors_for(uint64_t n_vectors) {
+	uint64_t sv = (n_vectors + kMaxSegments - 1) / kMaxSegments;
+	sv          = (sv + 399) / 400 * 400;
+	return sv < kSegmentMinVectors ? kSegmentMinVectors : sv;
+}
+
+static SegmentTable* segment_table_of(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	for (auto& t : ctx->seg_tables) {
+		if (t.key != nullptr && t.key == col->d_vectors && t.n_vectors == col->n_vectors) { return &t; }
+	}
+	return nullptr;
+}
+static void segment_table_forget(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	if (!ctx || !col) { return; }
+	for (auto& t : ctx->seg_tables) {
+		if (t.key == col->d_vectors) { t.key = nullptr; }
+	}
+}
+static SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	segment_table_forget(ctx, col);
+	SegmentTable* t = nullptr;
+	for (auto& c : ctx->seg_tables) {
+		if (c.key == nullptr) { t = &c; break; }
+	}
+	if (!t) {
+		t             = &ctx->seg_tables[ctx->seg_next];
+		ctx->seg_next = (ctx->seg_next + 1) % 4;
+	}
+	t->key         = col->d_vectors;
+	t->n_vectors   = col->n_vectors;
+	t->seg_vectors = segment_vectors_for(col->n_vectors);
+	t->n_seg       = static_cast<uint32_t>((col->n_vectors + t->seg_vectors - 1) / t->seg_vectors);
+	return t;
+}
+
+// the kind of a stretch of vectors, from its sums (see above)
+static int stretch_kind(const alpgpu_ctx* ctx, uint64_t n, uint64_t packed, uint64_t exc_bytes) {
+	alpgpu_column v {};
+	v.n_vectors = n, v.packed_bytes_hint = packed ? packed : 1, v.exc_bytes_hint = exc_bytes;
+	const bool   with_exc = column_decodes_with_exceptions(ctx, &v);
+	const double bits     = static_cast<double>(packed) / (128.0 * static_cast<double>(n));
+	const int    band     = bits <= kReadAheadBits ? 0 : (bits <= (with_exc ? 22.0 : 17.5) ? 1 : (bits < 38.0 ? 2 : 3));
+	return 2 * band + (with_exc ? 1 : 0);
+}
+
+// runs[0 .. return) cover the column; 0 = no plan (decode the column whole)
+static int plan_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col, DecodeRun* runs) {
+	if (!ctx->decode_segments || !ctx->decode_auto || ctx->decode_pad_kib >= 0 || ctx->decode_pairing != 0) { return 0; } // (a forced shape is a forced shape)
+	const SegmentTable* t = segment_table_of(ctx, col);
+	if (!t || t->n_seg < 2) { return 0; }
+	int n_runs = 0, kind = -1;
+	for (uint32_t s = 0; s < t->n_seg; ++s) {
+		const uint64_t v0 = s * t->seg_vectors;
+		const uint64_t n  = v0 + t->seg_vectors < t->n_vectors ? t->seg_vectors : t->n_vectors - v0;
+		const uint64_t eb = 10ull * t->exc_cnt[s]; // (ALP: 8-byte value + 2-byte position; ALP_RD records are smaller and their vectors wide anyway)
+		const int      k  = stretch_kind(ctx, n, t->packed[s], eb);
+		if (k != kind) {
+			if (n_runs == kMaxRuns) { return 0; }
+			runs[n_runs++] = DecodeRun {v0, 0, 0, 0, 0};
+			kind           = k;
+		}
+		DecodeRun& r = runs[n_runs - 1];
+		r.n += n, r.packed += t->packed[s], r.exc_bytes += eb, r.rd_vectors += t->rd_vectors[s];
+	}
+	return n_runs >= 2 ? n_runs : 0;
+}
+
+// the view of a run: descriptors hold absolute stream offsets, so a stretch of whole rowgroups decodes on its own
+static alpgpu_column run_view(const alpgpu_column* col, const DecodeRun& r) {
+	alpgpu_column v   = *col;
+	v.n_vectors       = r.n;
+	v.n_rowgroups     = (r.n + 99) / 100;
+	v.d_vectors       = col->d_vectors + r.v0;
+	v.d_rowgroups     = col->d_rowgroups + r.v0 / 100;
+	v.packed_bytes_hint = r.packed ? r.packed : 1;
+	v.exc_bytes_hint    = r.exc_bytes;
+	v.alp_rd_rowgroups_hint = 1 + r.rd_vectors / 100;
+	return v;
 }
 
 // what alpgpu_decode_f64 / _f32 would launch for this column right now (option + size hints): vectors per decode workgroup
@@ -735,11 +858,8 @@ int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, dou
 	return ALPGPU_OK;
 }
 
-int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
-	ALPGPU_CHECK_CTX(ctx);
-	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
-	if (col->n_vectors == 0) { return ALPGPU_OK; }
-	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+// one launch of the store decode over a column or a run of it (+ the read-ahead beside it where the rule wants one)
+static int decode_one_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
 	const int variant = decode_variant_for(ctx, col);
 	// The read-ahead (read_ahead_kernels.hip): a few persistent workgroups on the context's second stream pull the column's streams into the Infinity
 	// Cache a bounded distance ahead of the decode kernel, which tells them where it is.  Started first so that it is ahead from the first workgroup on.
@@ -769,6 +889,29 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 	if (ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); } // (the read-ahead leaves on its own once its last batch is in reach or the decode never shows up)
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
+}
+
+int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
+	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	DecodeRun runs[kMaxRuns];
+	const int n_runs = plan_decode_runs(ctx, col, runs);
+	if (n_runs == 0) { return decode_one_f64(ctx, col, d_out); }
+	for (int i = 0; i < n_runs; ++i) { // regions of different kinds, each with its own launch shape (plan_decode_runs)
+		const alpgpu_column view = run_view(col, runs[i]);
+		if (const int rc = decode_one_f64(ctx, &view, d_out + runs[i].v0 * 1024)) { return rc; }
+	}
+	return ALPGPU_OK;
+}
+
+// how many launches alpgpu_decode_f64 would make for this column now: 1, or the number of runs of plan_decode_runs; negative on bad arguments
+int alpgpu_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
+	DecodeRun runs[kMaxRuns];
+	const int n_runs = plan_decode_runs(ctx, col, runs);
+	return n_runs == 0 ? 1 : n_runs;
 }
 
 // ---- vector primitives on batches ---------------------------------------------------------------------------
@@ -1031,6 +1174,21 @@ static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 		for (uint64_t r = 0; r < h.n_rowgroups; ++r) { n_rd += rgs_h[r].scheme == ALPGPU_SCHEME_ALP_RD ? 1 : 0; }
 		col->alp_rd_rowgroups_hint = 1 + n_rd;
 	}
+	segment_table_forget(ctx, col);
+	if (h.n_vectors >= 2 * kSegmentMinVectors) { // the decode's launch plan (plan_decode_runs): the same sums alpgpu_column_totals takes on the device
+		SegmentTable* seg = segment_table_new(ctx, col);
+		for (uint32_t i = 0; i < seg->n_seg; ++i) {
+			uint64_t       pk = 0, ec = 0, rd = 0;
+			const uint64_t v1 = (i + 1) * seg->seg_vectors < h.n_vectors ? (i + 1) * seg->seg_vectors : h.n_vectors;
+			for (uint64_t v = i * seg->seg_vectors; v < v1; ++v) {
+				const bool is_rd = vds[v].scheme == ALPGPU_SCHEME_ALP_RD;
+				pk += 128ull * (vds[v].bw + (is_rd ? vds[v].lbw : 0));
+				ec += vds[v].exc_cnt;
+				rd += is_rd ? 1 : 0;
+			}
+			seg->packed[i] = pk, seg->exc_cnt[i] = ec, seg->rd_vectors[i] = rd;
+		}
+	}
 	if (n_values) { *n_values = h.n_values; }
 	return ALPGPU_OK;
 }
@@ -1070,8 +1228,21 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_b
 	if (col->d_totals) {
 		const bool count_rd = col->d_rowgroups != nullptr && col->n_rowgroups != 0;
 		if (count_rd && alpgpu::launch_count_rd_rowgroups(ctx->stream, col, col->d_totals + 7) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "rowgroup count launch failed", hipGetLastError()); }
+		// per-segment sums for the decode's launch plan (plan_decode_runs): columns long enough to have two segments
+		SegmentTable* seg = nullptr;
+		uint64_t      seg_sums[3 * kMaxSegments];
+		segment_table_forget(ctx, col);
+		if (col->d_vectors && ctx->d_progress && col->n_vectors >= 2 * kSegmentMinVectors) {
+			seg = segment_table_new(ctx, col);
+			if (alpgpu::launch_segment_sums(ctx->stream, col, seg->seg_vectors, seg->n_seg, ctx->d_progress + 64) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "segment sums launch failed", hipGetLastError()); }
+			ALPGPU_HIP(hipMemcpyAsync(seg_sums, ctx->d_progress + 64, 24ull * seg->n_seg, hipMemcpyDeviceToHost, ctx->stream));
+		}
 		ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
 		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+		if (seg) {
+			for (uint32_t i = 0; i < seg->n_seg; ++i) { seg->packed[i] = seg_sums[3 * i], seg->exc_cnt[i] = seg_sums[3 * i + 1], seg->rd_vectors[i] = seg_sums[3 * i + 2]; }
+			if (t[2] || t[3]) { seg->key = nullptr; } // an overflowed or unrecovered column: no plans
+		}
 		col->alp_rd_rowgroups_hint = count_rd ? 1 + t[7] : (col->n_vectors == 0 ? 1 : 0);
 	} else if (col->n_vectors != 0) {
 		return fail(ALPGPU_ERR_INVALID, "column without d_totals");
@@ -1144,12 +1315,16 @@ static int encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vec
 	if (rc != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "encode launch failed", hipGetLastError()); }
 	return workspace_used(ctx);
 }
-int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) { return encode_vectors_f32(ctx, d_in, n_vectors, col, false); }
+int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	segment_table_forget(ctx, col);
+	return encode_vectors_f32(ctx, d_in, n_vectors, col, false);
+}
 
 // Float columns keep the search in front unless ALPGPU_OPT_ENCODE_ASYNC_INIT = 2: the float single pass needs 77 VGPRs, THREE of its
 // tiles fit a CU, and the persistent search's wavefront takes one of them away for as long as it lives — 3.53 against 3.38 ms per 1 Mi
 // vectors (profiles/r03_async_init.txt); beside the double kernel's two tiles it fits in what they leave.
 int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col) {
+	segment_table_forget(ctx, col);
 	const uint64_t n_rg = (n_vectors + 99) / 100;
 	if (!ctx || ctx->async_init < 2 || ctx->encode_two_pass || n_rg < kAsyncMinRowgroups) {
 		if (int rc = alpgpu_rowgroup_init_f32(ctx, d_in, n_vectors, col)) { return rc; }

@@ -51,6 +51,33 @@ int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
+// Per-segment sums over the descriptors (alpgpu_column_totals -> the context's segment table, api.hip): bytes of packed records, exceptions, vectors of ALP_RD rowgroups
+// of every segment of seg_vectors consecutive vectors.  One workgroup per segment; out[3 s .. 3 s + 2].
+__global__ __launch_bounds__(256) void k_segment_sums(const alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors, uint64_t seg_vectors, uint64_t* __restrict__ out) {
+	__shared__ unsigned long long s_sum[3];
+	if (threadIdx.x < 3) { s_sum[threadIdx.x] = 0ull; }
+	__syncthreads();
+	const uint64_t v0 = static_cast<uint64_t>(blockIdx.x) * seg_vectors;
+	const uint64_t v1 = v0 + seg_vectors < n_vectors ? v0 + seg_vectors : n_vectors;
+	unsigned long long p = 0, e = 0, r = 0;
+	for (uint64_t v = v0 + threadIdx.x; v < v1; v += 256) {
+		const alpgpu_vector_desc d  = descs[v];
+		const bool               rd = d.scheme == ALPGPU_SCHEME_ALP_RD;
+		p += 128ull * (d.bw + (rd ? d.lbw : 0));
+		e += d.exc_cnt;
+		r += rd ? 1ull : 0ull;
+	}
+	atomicAdd(&s_sum[0], p);
+	atomicAdd(&s_sum[1], e);
+	atomicAdd(&s_sum[2], r);
+	__syncthreads();
+	if (threadIdx.x < 3) { out[3 * blockIdx.x + threadIdx.x] = s_sum[threadIdx.x]; }
+}
+int launch_segment_sums(hipStream_t stream, const alpgpu_column* col, uint64_t seg_vectors, uint32_t n_seg, uint64_t* d_out) {
+	hipLaunchKernelGGL(k_segment_sums, dim3(n_seg), dim3(256), 0, stream, col->d_vectors, col->n_vectors, seg_vectors, d_out);
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
 int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_t value_bytes, unsigned long long* d_first_bad) {
 	const uint64_t n = col->n_vectors;
 	hipLaunchKernelGGL(k_validate_column, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, col->d_vectors, col->d_rowgroups, col->d_exc, n,

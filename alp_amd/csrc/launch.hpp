@@ -38,6 +38,8 @@ int launch_tree_sum(hipStream_t stream, const double* d_in, uint64_t n, double* 
 // guard_kernels.hip
 int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_t value_bytes, unsigned long long* d_first_bad);
 int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint64_t* d_count);
+// d_out[3 s .. 3 s + 2] = {packed bytes, exceptions, ALP_RD vectors} of segment s (seg_vectors consecutive vectors each)
+int launch_segment_sums(hipStream_t stream, const alpgpu_column* col, uint64_t seg_vectors, uint32_t n_seg, uint64_t* d_out);
 
 // init_kernels.hip
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first = 0,

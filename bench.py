@@ -733,7 +733,8 @@ def sharded_column_bench(args, ctx, clock, world, rank, local_rank, dev):
 #   decode_sweep_by_bit_width[_2pct_exceptions]: one 1 Mi-vector column per bit width 1..53 (0 / 20 exceptions per vector): frac[i] and vpw[i] (vectors per decode
 #       workgroup the launch rule chose) for width i + 1; summary = min / argmin / p10 / mean / max of frac; widths 1..read_ahead_upto ran with the read-ahead
 #       kernel beside the decode (ALPGPU_OPT_DECODE_READ_AHEAD, the library's choice), no_read_ahead = the same columns with the option off.
-#   decode_tuning: [frac at 1 vector per workgroup, at 2, auto, auto's choice] per case;  decode_bimodal: first half 6 bits + 20 exceptions, second half 44 bits.
+#   decode_tuning: [frac at 1 vector per workgroup, at 2, auto, auto's choice] per case;  decode_bimodal: first half 6 bits + 20 exceptions, second half 44 bits: one / two
+#       vectors per workgroup, the rule on the column's averages (`average`), and `auto` = after alpgpu_column_totals, region by region in `runs` launches (ALPGPU_OPT_DECODE_SEGMENTS).
 #   decode_sum: per-vector SUM fused into the decode (k_sink_direct) — ms and frac; column_sum / count_range / ring (persistent LDS-ring kernel) / four_wave (staged kernel) fracs.
 #   encode_<column>: ms / frac / GBps of alpgpu_encode_f64 (search beside the encode), front_ms (search in front), init_ms + vectors_ms (the two halves alone), bits (compressed
 #       bits per value), dec_frac / dec_vpw (decode of that column), rt (GPU round trip bit-exact), unordered_ms / unordered_frac (ALPGPU_OPT_ENCODE_UNORDERED),
@@ -809,8 +810,11 @@ def single_gpu_bench(args, ctx, clock, local_rank, dev):
     for vpw in (1, 2, 0):
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
         med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
-        bim["auto" if vpw == 0 else f"vpw{vpw}"] = frac(ab, med)
-    bim["auto_vpw"] = ctx.decode_vectors_per_wg(c)
+        bim["average" if vpw == 0 else f"vpw{vpw}"] = frac(ab, med)  # (a hand-built column: no alpgpu_column_totals yet, the rule sees the two byte hints only)
+    bim["average_vpw"] = ctx.decode_vectors_per_wg(c)
+    ctx.column_totals(c)  # what a caller does after an encode: the context now knows the column's segments (ALPGPU_OPT_DECODE_SEGMENTS)
+    med, _ = time_launches(lambda: ctx.decode(c, out), 7, 10)
+    bim["auto"], bim["runs"] = frac(ab, med), ctx.decode_runs(c)
     extras["decode_bimodal"] = bim
     del c
     # decode fused into a SUM consumer: the 8 KiB per vector of decoded doubles never reach HBM

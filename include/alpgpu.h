@@ -225,12 +225,19 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * Same output bytes.  The two kernels are joined on the context's stream: work enqueued behind alpgpu_decode_f64 waits for both. */
 #define ALPGPU_OPT_DECODE_READ_AHEAD 12
 #define ALPGPU_OPT_DECODE_READ_AHEAD_US 13
+/* ALPGPU_OPT_DECODE_SEGMENTS (double store decode; round 5; default 1): alpgpu_column_totals and alpgpu_column_from_blob remember, in the context, the sizes of up to 32
+ * segments of the column; alpgpu_decode_f64 of that column through the same context merges adjacent segments of the same kind (by packed width and exceptions) into at most 8 runs
+ * and decodes run by run, each with the launch shape (and read-ahead) its own sizes call for — a column whose regions differ is no longer decoded in the shape of its average.
+ * Columns of one kind, columns without the call, forced launch shapes: one launch, as before.  0 = never.  alpgpu_decode_runs tells.  Same bytes. */
+#define ALPGPU_OPT_DECODE_SEGMENTS 14
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
 int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
 /* ... and whether that decode would run with the read-ahead beside it (ALPGPU_OPT_DECODE_READ_AHEAD): 1 / 0; negative on bad arguments */
 int         alpgpu_decode_reads_ahead(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
+/* ... and in how many launches alpgpu_decode_f64 would decode it (ALPGPU_OPT_DECODE_SEGMENTS): 1, or the number of runs; negative on bad arguments */
+int         alpgpu_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col);
 /* ---- host-resident columns -----------------------------------------------------------------------------------------------
  * The reference's callers (publication/source_code/bench_compression_ratio/alp.cpp:198-229) hold the column and what they
  * compress it into in host memory.  These entry points take it from there: n_values values at h_in (the last vector may be

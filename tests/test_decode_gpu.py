@@ -377,3 +377,73 @@ def test_long_columns_of_narrow_vectors_take_the_read_ahead_by_themselves(ctx, o
             assert np.array_equal(ref.view(-1, 1024)[lo:lo + 200].cpu().numpy().view(np.uint64).reshape(-1), want.view(np.uint64).reshape(-1))
     finally:
         ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
+
+
+def test_a_column_whose_regions_differ_is_decoded_region_by_region(ctx, oracle):
+    """ALPGPU_OPT_DECODE_SEGMENTS: after alpgpu_column_totals the context knows the column's segments; a column of three kinds of regions (3-bit vectors with 20
+    exceptions, 44-bit vectors, 12-bit vectors; the middle one short) is decoded in three launches with three shapes, a uniform one in one; every launch plan
+    writes the same bytes (the option off, shapes forced, the blob route through alpgpu_column_from_blob on a second context), and a re-encode forgets the plan"""
+    import torch
+    import bench
+    from alp_amd import capi
+    n = 300000
+    idx = np.arange(n)
+    a, b = 140000, 200000  # (not multiples of the plan's segments — 32 800 vectors here: the segments decide where runs begin)
+    bw = np.where(idx < a, 3, np.where(idx < b, 44, 12))
+    exc = np.where(idx < a, 20, 0)
+    col, vec, _ = bench.build_decode_column(n, 0, seed=5, bw_of_rowgroup=bw, exc_per_vec=exc)
+    uni, _, _ = bench.build_decode_column(n, 0, seed=5, bw_of_rowgroup=12, exc_per_vec=0)
+    try:
+        assert ctx.decode_runs(col) == 1  # nobody has looked at the column yet
+        ref = ctx.decode(col).clone()
+        ctx.synchronize()
+        ctx.column_totals(col)
+        ctx.column_totals(uni)
+        assert ctx.decode_runs(uni) == 1
+        runs = ctx.decode_runs(col)
+        assert 3 <= runs <= 5, runs  # three kinds; the segments that straddle a border may form runs of their own
+        for _ in range(2):
+            out = torch.zeros_like(ref)
+            ctx.decode(col, out)
+            ctx.synchronize()
+            assert torch.equal(out.view(torch.int64), ref.view(torch.int64))
+        ctx.set_option(capi.OPT_DECODE_SEGMENTS, 0)
+        assert ctx.decode_runs(col) == 1
+        ctx.set_option(capi.OPT_DECODE_SEGMENTS, 1)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 2)  # a forced shape is a forced shape
+        assert ctx.decode_runs(col) == 1
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+        # the oracle on vectors around both borders
+        for lo in (a - 100, b - 100):
+            sel = np.arange(lo, lo + 200)
+            sub = {k: vec[k][sel].copy() for k in ("bw", "e", "f", "base", "exc_cnt", "lbw")}
+            sub["scheme"] = vec["scheme"][sel].astype(np.uint8)
+            packed = np.zeros((200, 1024), np.uint64)
+            p8 = packed.view(np.uint8).reshape(200, 8192)
+            sub["exc"] = np.zeros((200, 1024), np.float64)
+            sub["pos"] = np.zeros((200, 1024), np.uint16)
+            rec = (10 * 20 + 7) // 8 * 8
+            for i, v in enumerate(sel):
+                o, w = int(vec["packed_off"][v]), int(vec["bw"][v])
+                p8[i, : 128 * w] = col.packed[o:o + 128 * w].cpu().numpy()
+                if vec["exc_cnt"][v]:
+                    r = col.exc[int(vec["exc_off"][v]): int(vec["exc_off"][v]) + rec].cpu().numpy()
+                    sub["exc"][i, :20] = r[:160].view(np.float64)
+                    sub["pos"][i, :20] = r[160:200].view(np.uint16)
+            sub["packed"] = packed
+            sub["packed_left"] = np.zeros((200, 1024), np.uint16)
+            sub["dict"] = np.zeros((3, 8), np.uint16)
+            sub["dict_size"] = np.zeros(3, np.uint8)
+            want = oracle.decode_column(sub)
+            assert np.array_equal(ref.view(-1, 1024)[lo:lo + 200].cpu().numpy().view(np.uint64).reshape(-1), want.view(np.uint64).reshape(-1))
+        # the blob route: a second context learns the segments from the blob's descriptors
+        blob = ctx.to_blob(col, n * 1024)
+        other = capi.Context(0)
+        col2, n_values = other.from_blob(blob)
+        assert n_values == n * 1024 and other.decode_runs(col2) == runs
+        out2 = other.decode(col2)
+        other.synchronize()
+        assert torch.equal(out2.view(torch.int64), ref.view(torch.int64))
+    finally:
+        ctx.set_option(capi.OPT_DECODE_SEGMENTS, 1)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)

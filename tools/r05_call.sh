@@ -323,6 +323,15 @@ case $step in
 	unset ALPGPU_LIB
 	grep "^lib\|^mixed\|^rd" "$out/enc.txt" | cut -c1-330
 	;;
+37) # decode by segments: the decode tests, the bimodal column and friends through the plan
+	run 400 pytest.txt python -m pytest tests/test_decode_gpu.py tests/test_container_gpu.py tests/test_host_pipeline_gpu.py -x -q
+	tail -5 "$out/pytest.txt"
+	run 300 seg.txt python tools/r05_segments.py
+	grep -v "amdgpu.ids\|^==" "$out/seg.txt"
+	;;
+38) run 300 seg.txt python tools/r05_segments.py
+	grep -v "amdgpu.ids\|^==" "$out/seg.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
