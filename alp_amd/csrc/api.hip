@@ -885,7 +885,7 @@ static int decode_one_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_o
 		}
 		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
 	}
-	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), (ahead && !std::getenv("ALPGPU_READ_AHEAD_NO_REPORT")) ? ctx->d_progress : nullptr, tag);
+	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), ahead ? ctx->d_progress : nullptr, tag);
 	if (ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); } // (the read-ahead leaves on its own once its last batch is in reach or the decode never shows up)
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;

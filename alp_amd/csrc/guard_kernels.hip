@@ -52,13 +52,18 @@ int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint
 }
 
 // Per-segment sums over the descriptors (alpgpu_column_totals -> the context's segment table, api.hip): bytes of packed records, exceptions, vectors of ALP_RD rowgroups
-// of every segment of seg_vectors consecutive vectors.  One workgroup per segment; out[3 s .. 3 s + 2].
-__global__ __launch_bounds__(256) void k_segment_sums(const alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors, uint64_t seg_vectors, uint64_t* __restrict__ out) {
+// of every segment of seg_vectors consecutive vectors.  kSegmentSplit workgroups per segment, each over its share, added into out[3 s .. 3 s + 2] (zeroed by the launcher).
+constexpr unsigned kSegmentSplit = 16;
+__global__ __launch_bounds__(256) void k_segment_sums(const alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors, uint64_t seg_vectors, unsigned long long* __restrict__ out) {
 	__shared__ unsigned long long s_sum[3];
 	if (threadIdx.x < 3) { s_sum[threadIdx.x] = 0ull; }
 	__syncthreads();
-	const uint64_t v0 = static_cast<uint64_t>(blockIdx.x) * seg_vectors;
-	const uint64_t v1 = v0 + seg_vectors < n_vectors ? v0 + seg_vectors : n_vectors;
+	const uint64_t seg   = blockIdx.x / kSegmentSplit, part = blockIdx.x % kSegmentSplit;
+	const uint64_t share = (seg_vectors + kSegmentSplit - 1) / kSegmentSplit;
+	const uint64_t s0    = seg * seg_vectors;
+	const uint64_t s1    = s0 + seg_vectors < n_vectors ? s0 + seg_vectors : n_vectors;
+	const uint64_t v0    = s0 + part * share;
+	const uint64_t v1    = v0 + share < s1 ? v0 + share : s1;
 	unsigned long long p = 0, e = 0, r = 0;
 	for (uint64_t v = v0 + threadIdx.x; v < v1; v += 256) {
 		const alpgpu_vector_desc d  = descs[v];
@@ -71,10 +76,11 @@ __global__ __launch_bounds__(256) void k_segment_sums(const alpgpu_vector_desc* 
 	atomicAdd(&s_sum[1], e);
 	atomicAdd(&s_sum[2], r);
 	__syncthreads();
-	if (threadIdx.x < 3) { out[3 * blockIdx.x + threadIdx.x] = s_sum[threadIdx.x]; }
+	if (threadIdx.x < 3 && s_sum[threadIdx.x] != 0ull) { atomicAdd(&out[3 * seg + threadIdx.x], s_sum[threadIdx.x]); }
 }
 int launch_segment_sums(hipStream_t stream, const alpgpu_column* col, uint64_t seg_vectors, uint32_t n_seg, uint64_t* d_out) {
-	hipLaunchKernelGGL(k_segment_sums, dim3(n_seg), dim3(256), 0, stream, col->d_vectors, col->n_vectors, seg_vectors, d_out);
+	if (hipMemsetAsync(d_out, 0, 24ull * n_seg, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
+	hipLaunchKernelGGL(k_segment_sums, dim3(n_seg * kSegmentSplit), dim3(256), 0, stream, col->d_vectors, col->n_vectors, seg_vectors, reinterpret_cast<unsigned long long*>(d_out));
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

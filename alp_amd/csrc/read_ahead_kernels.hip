@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 				uint32_t go      = 1;
 				uint64_t changed = wall_clock64();
 				for (;;) {
-					const uint64_t w = status_load((mode & 8u) ? progress + 16 : progress); // (bit 3, experiment: a word nobody writes)
+					const uint64_t w = status_load(progress);
 					if ((w & ~kAheadVecMask) == tag && (w & kAheadVecMask) > seen) { seen = w & kAheadVecMask, changed = wall_clock64(); }
 					if (wg_first < seen + lead_max) { break; }                          // in reach
 					if (wall_clock64() - changed > kAheadPatiencePs / ps_per_tick) { go = 0; break; } // the decode is not coming (its launch failed?): leave

@@ -248,7 +248,8 @@ case $step in
 	done
 	grep "^mode" "$out/beside.txt"
 	;;
-26) # the pacing's cost taken apart (grid 128): polls of a word nobody writes; no reports from the decode; naps of 27 / 110 us; reports but no polls
+26) # (history: mode bit 3 and ALPGPU_READ_AHEAD_NO_REPORT were removed from the library after this call — both arms only made the read-ahead wait out its patience)
+    # the pacing's cost taken apart (grid 128): polls of a word nobody writes; no reports from the decode; naps of 27 / 110 us; reports but no polls
 	for cfg in "1 0" "9 0" "1 1" "2049 0" "8193 0" "9 1"; do
 		set -- $cfg
 		if [ "$2" = 1 ]; then export ALPGPU_READ_AHEAD_NO_REPORT=1; else unset ALPGPU_READ_AHEAD_NO_REPORT; fi
