@@ -333,6 +333,11 @@ case $step in
 38) run 300 seg.txt python tools/r05_segments.py
 	grep -v "amdgpu.ids\|^==" "$out/seg.txt"
 	;;
+39) # the whole GPU suite three times in a row (flakiness of the round's new tests), then smoke
+	for i in 1 2 3; do run 600 pytest.txt python -m pytest tests -m gpu -q -x; tail -2 "$out/pytest.txt"; done
+	run 120 smoke.txt python __graft_entry__.py smoke
+	tail -1 "$out/smoke.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
