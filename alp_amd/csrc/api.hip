@@ -20,7 +20,9 @@
 constexpr int kMaxSegments = 32;
 struct SegmentTable {
 	const void* key;         // col->d_vectors (nullptr: empty slot)
-	uint64_t    n_vectors;
+	const void* d_packed;    // ... and the rest of what a column must share with the one the sums were taken from: a caching allocator hands the same
+	uint64_t    n_vectors;   //     descriptor buffer to the next column of the same length, whose stream sizes then differ
+	uint64_t    packed_bytes, exc_bytes;
 	uint64_t    seg_vectors;
 	uint32_t    n_seg;
 	uint64_t    packed[kMaxSegments];  // bytes of packed records
@@ -645,7 +647,10 @@ static uint64_t segment_vectors_for(uint64_t n_vectors) {
 
 static SegmentTable* segment_table_of(alpgpu_ctx* ctx, const alpgpu_column* col) {
 	for (auto& t : ctx->seg_tables) {
-		if (t.key != nullptr && t.key == col->d_vectors && t.n_vectors == col->n_vectors) { return &t; }
+		if (t.key != nullptr && t.key == col->d_vectors && t.d_packed == col->d_packed && t.n_vectors == col->n_vectors && t.packed_bytes == col->packed_bytes_hint &&
+		    t.exc_bytes == col->exc_bytes_hint) {
+			return &t;
+		}
 	}
 	return nullptr;
 }
@@ -655,7 +660,8 @@ static void segment_table_forget(alpgpu_ctx* ctx, const alpgpu_column* col) {
 		if (t.key == col->d_vectors) { t.key = nullptr; }
 	}
 }
-static SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col) {
+// (packed_bytes / exc_bytes: the stream sizes the caller is about to write into the column's hints)
+static SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t packed_bytes, uint64_t exc_bytes) {
 	segment_table_forget(ctx, col);
 	SegmentTable* t = nullptr;
 	for (auto& c : ctx->seg_tables) {
@@ -666,7 +672,9 @@ static SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col
 		ctx->seg_next = (ctx->seg_next + 1) % 4;
 	}
 	t->key         = col->d_vectors;
+	t->d_packed    = col->d_packed;
 	t->n_vectors   = col->n_vectors;
+	t->packed_bytes = packed_bytes, t->exc_bytes = exc_bytes;
 	t->seg_vectors = segment_vectors_for(col->n_vectors);
 	t->n_seg       = static_cast<uint32_t>((col->n_vectors + t->seg_vectors - 1) / t->seg_vectors);
 	return t;
@@ -1176,7 +1184,7 @@ static int column_from_blob(alpgpu_ctx* ctx, const void* h_blob, uint64_t size, 
 	}
 	segment_table_forget(ctx, col);
 	if (h.n_vectors >= 2 * kSegmentMinVectors) { // the decode's launch plan (plan_decode_runs): the same sums alpgpu_column_totals takes on the device
-		SegmentTable* seg = segment_table_new(ctx, col);
+		SegmentTable* seg = segment_table_new(ctx, col, h.packed_bytes, h.exc_bytes);
 		for (uint32_t i = 0; i < seg->n_seg; ++i) {
 			uint64_t       pk = 0, ec = 0, rd = 0;
 			const uint64_t v1 = (i + 1) * seg->seg_vectors < h.n_vectors ? (i + 1) * seg->seg_vectors : h.n_vectors;
@@ -1233,7 +1241,7 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_b
 		uint64_t      seg_sums[3 * kMaxSegments];
 		segment_table_forget(ctx, col);
 		if (col->d_vectors && ctx->d_progress && col->n_vectors >= 2 * kSegmentMinVectors) {
-			seg = segment_table_new(ctx, col);
+			seg = segment_table_new(ctx, col, 0, 0); // (the sizes: below, once they are here)
 			if (alpgpu::launch_segment_sums(ctx->stream, col, seg->seg_vectors, seg->n_seg, ctx->d_progress + 64) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "segment sums launch failed", hipGetLastError()); }
 			ALPGPU_HIP(hipMemcpyAsync(seg_sums, ctx->d_progress + 64, 24ull * seg->n_seg, hipMemcpyDeviceToHost, ctx->stream));
 		}
@@ -1241,6 +1249,7 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_b
 		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
 		if (seg) {
 			for (uint32_t i = 0; i < seg->n_seg; ++i) { seg->packed[i] = seg_sums[3 * i], seg->exc_cnt[i] = seg_sums[3 * i + 1], seg->rd_vectors[i] = seg_sums[3 * i + 2]; }
+			seg->packed_bytes = t[0], seg->exc_bytes = t[1];
 			if (t[2] || t[3]) { seg->key = nullptr; } // an overflowed or unrecovered column: no plans
 		}
 		col->alp_rd_rowgroups_hint = count_rd ? 1 + t[7] : (col->n_vectors == 0 ? 1 : 0);

@@ -410,6 +410,12 @@ def test_a_column_whose_regions_differ_is_decoded_region_by_region(ctx, oracle):
         ctx.set_option(capi.OPT_DECODE_SEGMENTS, 0)
         assert ctx.decode_runs(col) == 1
         ctx.set_option(capi.OPT_DECODE_SEGMENTS, 1)
+        # the plan belongs to THIS column: the next column a caching allocator puts into the same buffers has other stream sizes
+        kept = int(col.c.packed_bytes_hint)
+        col.c.packed_bytes_hint = kept + 128
+        assert ctx.decode_runs(col) == 1
+        col.c.packed_bytes_hint = kept
+        assert ctx.decode_runs(col) == runs
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 2)  # a forced shape is a forced shape
         assert ctx.decode_runs(col) == 1
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)

@@ -338,6 +338,12 @@ case $step in
 	run 120 smoke.txt python __graft_entry__.py smoke
 	tail -1 "$out/smoke.txt"
 	;;
+40) # the plan's key (a caching allocator reuses buffers): decode tests, then the five columns again
+	run 300 pytest.txt python -m pytest tests/test_decode_gpu.py tests/test_container_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	run 300 seg.txt python tools/r05_segments.py
+	grep -v "amdgpu.ids\|^==" "$out/seg.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
