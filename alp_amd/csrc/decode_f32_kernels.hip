@@ -20,7 +20,10 @@ namespace alpgpu {
 
 constexpr int kDecThreadsF  = 256;
 constexpr int kStageBytesF  = 4480; // >= 31*128 (RD right) + 3*128 (RD left) + 128 pad, and >= 32*128 + 128 (ALP bw 32)
-constexpr int kExcStageF    = 128;
+#ifndef ALPGPU_EXC_STAGE_F
+#define ALPGPU_EXC_STAGE_F 256 // (round 5, late: 128 -> 256.  bench.py's decimal float column carries 94 exceptions per vector on average, 39 % of its vectors more than 128: decode 0.72-0.73 -> 0.75-0.76; the others unchanged)
+#endif
+constexpr int kExcStageF    = ALPGPU_EXC_STAGE_F; // exception values (4 bytes; ALP_RD: twice as many 2-byte ones) staged in LDS per vector
 
 struct __attribute__((aligned(16))) DecodeLdsF32 {
 	static constexpr bool kPrefixInLds = false; // exception lookup by ds_bpermute
@@ -179,7 +182,10 @@ __device__ __forceinline__ QuadWords request_quad_f32(const WORDS& words, const 
 // (exact) and added to `acc` in index order.  kSinkCountF: `acc` counts the values v with lo <= v <= hi (NaN never does).
 constexpr int kSinkStoreF = 0, kSinkSumF = 1, kSinkCountF = 2;
 __device__ __constant__ const uint32_t kShortcutBoundF[11] = {16777216u, 16777216u, 16777216u, 2147483u, 214748u, 21474u, 2147u, 214u, 21u, 2u, 0u};
-template <bool NT_STORE, int SINK, class LDS>
+// HBM_EXC = false: the caller knows (wave-uniform) that every exception value of the vector is in the LDS stage — this instance has no load from HBM in it, so
+// the compiler puts no s_waitcnt vmcnt(0) in front of the quad's store (stores count in vmcnt on gfx9: with the rare load in the code, every store of a
+// wavefront waited for the one before it — decode_kernels.hip cured the double kernel of this in round 5, the float kernel followed late in the round).
+template <bool NT_STORE, int SINK, class LDS, bool HBM_EXC = true>
 __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w, const alpgpu_vector_desc& d, const RdDict& dict, const ExcMaskF& em,
                                                 const uint8_t* __restrict__ rec, float* __restrict__ dst, int tid, int wave, int lane, double* acc,
                                                 float range_lo, float range_hi) {
@@ -189,7 +195,7 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 	const int row  = tid >> 3;
 	uint32_t  hits = 0;
 	int       rank = 0;
-	const bool all_staged = cnt <= (d.scheme == ALPGPU_SCHEME_ALP ? kExcStageF : 2 * kExcStageF); // wave-uniform: every exception value of the vector is in the LDS stage
+	const bool all_staged = !HBM_EXC || cnt <= (d.scheme == ALPGPU_SCHEME_ALP ? kExcStageF : 2 * kExcStageF); // wave-uniform: every exception value of the vector is in the LDS stage
 	if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
 		const int wi = 8 * wave + (lane >> 3);
 		uint32_t  word;
@@ -295,6 +301,12 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 		}
 	} else {
 		store_quad<NT_STORE>(dst + 4 * tid, out);
+		// (the two instances' stores must stay two stores: merged into one behind the join of their callers' branch, the wait for the rare load is back in front of it)
+		if constexpr (HBM_EXC) {
+			asm volatile("; quad stored (exception values beyond the stage possible)" ::: "memory");
+		} else {
+			asm volatile("; quad stored (exception values all staged)" ::: "memory");
+		}
 	}
 }
 
@@ -306,7 +318,11 @@ __device__ __forceinline__ void decode_staged_vector_f32(const DecodeLdsF32& L, 
 	ExcMaskF em {0u, 0};
 	if (d.exc_cnt > 0) { em = load_exception_mask_f32(L, lane); }
 	const QuadWords w = request_quad_f32(StagedWordsF {L.stage}, d, tid);
-	finish_quad_f32<NT_STORE, SINK>(L, w, d, dict, em, rec, dst, tid, wave, lane, acc, range_lo, range_hi);
+	if (SINK == kSinkStoreF && d.exc_cnt <= (d.scheme == ALPGPU_SCHEME_ALP ? kExcStageF : 2 * kExcStageF)) { // workgroup-uniform
+		finish_quad_f32<NT_STORE, SINK, DecodeLdsF32, false>(L, w, d, dict, em, rec, dst, tid, wave, lane, acc, range_lo, range_hi);
+	} else {
+		finish_quad_f32<NT_STORE, SINK, DecodeLdsF32, true>(L, w, d, dict, em, rec, dst, tid, wave, lane, acc, range_lo, range_hi);
+	}
 }
 
 // SINK != kSinkStoreF: `out` is the per-vector result array instead (double sums / uint32 counts)

@@ -344,6 +344,26 @@ case $step in
 	run 300 seg.txt python tools/r05_segments.py
 	grep -v "amdgpu.ids\|^==" "$out/seg.txt"
 	;;
+41) # float store decode without the store waits (a staged-exceptions instance of the quad): parity, then A/B against the build before, alternating
+	run 300 pytest.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	for lib in f32old "" f32old ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 120 f32.txt python tools/r05_time_float_decode.py
+	done
+	unset ALPGPU_LIB
+	grep -v "amdgpu.ids\|^==" "$out/f32.txt"
+	;;
+42) # float: 256 exception values staged per vector instead of 128: parity of the variant, then A/B alternating (decode and SUM)
+	ALPGPU_LIB=$PWD/build/variants/libalpgpu_f32stage256.so run 300 pytest.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	for lib in "" f32stage256 "" f32stage256; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 120 f32.txt python tools/r05_time_float_decode.py
+	done
+	unset ALPGPU_LIB
+	grep -v "amdgpu.ids\|^==" "$out/f32.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
