@@ -326,18 +326,33 @@ __device__ __forceinline__ void lean_pack_rd(uint64_t* image, const VecIn& x, in
 	wave_lds_sync();
 }
 
-// the image's first n_units 16-byte units -> out[0 .. n_units): 1 KiB contiguous per instruction
+// the image's first n_units 16-byte units -> out[0 .. n_units): 1 KiB contiguous per instruction.
+// All units are read into registers of their OWN before the first store (round 5, late): read and stored one by one, the compiler reuses one register quad, and the
+// LDS read that overwrites it waits — s_waitcnt vmcnt(0), stores count in vmcnt on gfx9 — until the store before has taken its data: every store of a wavefront waited
+// for the acknowledgement of the one before it (the "store acknowledgement" third of a wavefront's waits in profiles/r04_encode_levers.txt).
 __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_units, ull2v* __restrict__ out, int lane) {
-	const ull2v* img2 = reinterpret_cast<const ull2v*>(image);
+	const ull2v*  img2 = reinterpret_cast<const ull2v*>(image);
+	constexpr int kT   = kLeanImageBytes / 1024;
+#ifdef ALPGPU_LEAN_STORES_ONE_BY_ONE // (A/B: the form until late in round 5)
 #pragma unroll
-	for (int t = 0; t < kLeanImageBytes / 1024; ++t) {
+	for (int t = 0; t < kT; ++t) {
+		const int u = lane + 64 * t;
+		if (64 * t < n_units && u < n_units) { __builtin_nontemporal_store(img2[u], out + u); }
+	}
+#else
+	ull2v r[kT];
+#pragma unroll
+	for (int t = 0; t < kT; ++t) { r[t] = img2[lane + 64 * t]; } // (inside the image whatever n_units is)
+#pragma unroll
+	for (int t = 0; t < kT; ++t) {
 		const int u = lane + 64 * t;
 #ifdef ALPGPU_LEAN_PLAIN_STORES // (A/B: until late in round 4 the lean kernel wrote its packed words with plain stores)
-		if (64 * t < n_units && u < n_units) { out[u] = img2[u]; }
+		if (64 * t < n_units && u < n_units) { out[u] = r[t]; }
 #else
-		if (64 * t < n_units && u < n_units) { __builtin_nontemporal_store(img2[u], out + u); } // written once, read by nobody on this device soon
+		if (64 * t < n_units && u < n_units) { __builtin_nontemporal_store(r[t], out + u); } // written once, read by nobody on this device soon
 #endif
 	}
+#endif
 }
 
 // The five arguments needed only behind the wait are read from the kernarg segment where they are used (alp_device.hpp: late_kernel_arg):
@@ -627,10 +642,24 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 			const uint64_t* img64 = reinterpret_cast<const uint64_t*>(img);
 			uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
 			const int       n_w   = static_cast<int>(my_e >> 3);
-#ifdef ALPGPU_LEAN_PLAIN_STORES
+#if defined(ALPGPU_LEAN_PLAIN_STORES)
 			for (int w = lane; w < n_w; w += 64) { rec64[w] = img64[w]; }
-#else
+#elif defined(ALPGPU_LEAN_STORES_ONE_BY_ONE)
 			for (int w = lane; w < n_w; w += 64) { __builtin_nontemporal_store(img64[w], rec64 + w); }
+#else
+			for (int w0 = 0; w0 < n_w; w0 += 256) { // four words per lane and round in registers of their own (lean_store_image: no store waits for the one before it)
+				uint64_t q[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int w = w0 + 64 * k + lane;
+					q[k]        = w < n_w ? img64[w] : 0ull;
+				}
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int w = w0 + 64 * k + lane;
+					if (w < n_w) { __builtin_nontemporal_store(q[k], rec64 + w); }
+				}
+			}
 #endif
 		} else { // a record larger than its staging room (rare): the vector is read again and the record written from it (as the two-pass form's pack kernel does)
 			const VecIn xr   = load_vector(in, v, lane);

@@ -364,6 +364,16 @@ case $step in
 	unset ALPGPU_LIB
 	grep -v "amdgpu.ids\|^==" "$out/f32.txt"
 	;;
+43) # the lean encode's stores from registers of their own (no store waits for the one before it): parity, then A/B against the one-by-one form, alternating
+	run 400 pytest.txt python -m pytest tests/test_encode_gpu.py tests/test_recovery_gpu.py tests/test_async_init_gpu.py tests/test_reference_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	for lib in onebyone "" onebyone ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 120 enc.txt python tools/r05_time_encode.py
+	done
+	unset ALPGPU_LIB
+	grep "^lib\|^mixed\|^rd" "$out/enc.txt" | cut -c1-330
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
