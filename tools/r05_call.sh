@@ -374,6 +374,19 @@ case $step in
 	unset ALPGPU_LIB
 	grep "^lib\|^mixed\|^rd" "$out/enc.txt" | cut -c1-330
 	;;
+44) run 200 sum.txt python tools/r05_sum_exc.py
+	grep -v "amdgpu.ids\|^==" "$out/sum.txt"
+	;;
+45) # double SUM sink: the exception lookup pinned behind the pair's values (fewer spills): parity, then A/B alternating
+	run 300 pytest.txt python -m pytest tests/test_decode_sum_gpu.py tests/test_last_register_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	for lib in nopin "" nopin ""; do
+		if [ -z "$lib" ]; then unset ALPGPU_LIB; else export ALPGPU_LIB=$PWD/build/variants/libalpgpu_$lib.so; fi
+		run 120 sum.txt python tools/r05_sum_exc.py
+	done
+	unset ALPGPU_LIB
+	grep -v "amdgpu.ids\|^==" "$out/sum.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
