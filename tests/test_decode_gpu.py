@@ -317,11 +317,19 @@ def test_read_ahead_over_a_column_encoded_out_of_order(ctx):
     n = 36000
     x = torch.round(torch.rand(n * 1024, dtype=torch.float64, device="cuda:0", generator=g) * 1e4, decimals=2)
     x[::97] = torch.rand(x[::97].shape, dtype=torch.float64, device="cuda:0", generator=g)  # exceptions
+    x[n // 2 * 1024:] = torch.rand(n * 1024 - n // 2 * 1024, dtype=torch.float64, device="cuda:0", generator=g)  # the second half: full-precision values -> ALP_RD rowgroups (right + left words, 2-byte exception values)
     try:
         ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
         col = ctx.encode(x)
         ctx.column_totals(col)
         ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 1)
+        out = ctx.decode(col)
+        ctx.synchronize()
+        assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)  # ... and the same column in vector order (ALP and ALP_RD records in one span per batch)
+        col = ctx.encode(x)
+        ctx.column_totals(col)
+        assert ctx.decode_reads_ahead(col)
         out = ctx.decode(col)
         ctx.synchronize()
         assert torch.equal(out.view(torch.int64), x.view(torch.int64))

@@ -387,6 +387,9 @@ case $step in
 	unset ALPGPU_LIB
 	grep -v "amdgpu.ids\|^==" "$out/sum.txt"
 	;;
+46) run 300 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
