@@ -56,7 +56,7 @@ struct alpgpu_ctx {
 	int         decode_patch_max;  // ALPGPU_OPT_DECODE_PATCH_AFTER: ALP vectors with 1..this many exceptions are patched after their stores (0: never; <= 64)
 	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
 	int         read_ahead;        // ALPGPU_OPT_DECODE_READ_AHEAD: the store decode runs with a read-ahead into the Infinity Cache on the second stream (read_ahead_kernels.hip)
-	int         read_ahead_us;     // ... about this many microseconds ahead of the decode kernel
+	int         read_ahead_us;     // ... this many microseconds ahead of the decode kernel (0: 10 + 5.5 us per packed bit of the vectors)
 	int         read_ahead_grid;   // ... by this many eight-wavefront workgroups
 	int         read_ahead_bits;   // ... records of vectors of at most this many packed bits per value (the descriptors of all)
 	uint64_t*   d_progress;        // ... paced by this word of device memory (2 KiB: [0] the decode's position, tagged; [1] never written; [64..159] alpgpu_column_totals' segment sums)
@@ -170,7 +170,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
 	ctx->encode_unordered = std::getenv("ALPGPU_ENCODE_UNORDERED") ? std::atoi(std::getenv("ALPGPU_ENCODE_UNORDERED")) : 0; // (A/B runs)
 	ctx->read_ahead      = std::getenv("ALPGPU_DECODE_READ_AHEAD") ? std::atoi(std::getenv("ALPGPU_DECODE_READ_AHEAD")) : -1; // -1: by the column (read_ahead_for)
-	ctx->read_ahead_us   = std::getenv("ALPGPU_READ_AHEAD_US") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_US")) : 40;
+	ctx->read_ahead_us   = std::getenv("ALPGPU_READ_AHEAD_US") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_US")) : 0; // 0: by the vectors' width (alpgpu_decode_f64)
 	ctx->read_ahead_grid = std::getenv("ALPGPU_READ_AHEAD_GRID") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_GRID")) : 64;
 	ctx->decode_segments = std::getenv("ALPGPU_DECODE_SEGMENTS") ? std::atoi(std::getenv("ALPGPU_DECODE_SEGMENTS")) : 1;
 	for (auto& t : ctx->seg_tables) { t.key = nullptr; }
@@ -288,7 +288,7 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		ctx->read_ahead = value;
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_READ_AHEAD_US:
-		if (value < 1 || value > 10000) { return fail(ALPGPU_ERR_INVALID, "decode read-ahead lead: 1..10000 microseconds"); }
+		if (value < 0 || value > 10000) { return fail(ALPGPU_ERR_INVALID, "decode read-ahead lead: 0 (by the vectors' width) or 1..10000 microseconds"); }
 		ctx->read_ahead_us = value;
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_SEGMENTS:
@@ -883,7 +883,12 @@ static int decode_one_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_o
 		const double   n        = static_cast<double>(col->n_vectors);
 		const double   per_vec  = (static_cast<double>(col->packed_bytes_hint) + static_cast<double>(col->exc_bytes_hint)) / n + 32.0;
 		const double   ps_vec   = (8192.0 + per_vec) / 8.0;                                    // picoseconds per vector at 8 TB/s
-		const double   lead     = static_cast<double>(ctx->read_ahead_us) * 1.0e6 / ps_vec * 0.78; // ... vectors per lead time at the decode's usual 0.78 of that
+		// ... how long: by the vectors' width unless set (the wider the vectors, the longer a read-ahead workgroup's round takes: best leads measured per width
+		// 15 / 20 / 30 / 30 / 35 / 40 / 50 us at 1 .. 7 bits, with and without exceptions; too short falls off a cliff, too long decays slowly: call 47)
+		const double   bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
+		const double   lead_by_width = 10.0 + 5.5 * bits;
+		const double   lead_us  = ctx->read_ahead_us > 0 ? static_cast<double>(ctx->read_ahead_us) : (lead_by_width > 80.0 ? 80.0 : lead_by_width);
+		const double   lead     = lead_us * 1.0e6 / ps_vec * 0.78; // ... vectors per lead time at the decode's usual 0.78 of the full rate
 		const uint32_t lead_max = static_cast<uint32_t>(lead < 4096.0 ? 4096.0 : (lead > 4.0e9 ? 4.0e9 : lead));
 		const uint32_t lead_min = 2048; // about what is resident when a workgroup reports: those vectors' reads are under way
 		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));

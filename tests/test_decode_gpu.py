@@ -304,7 +304,7 @@ def test_read_ahead_does_not_change_a_byte(ctx, oracle, lead_us):
             assert torch.equal(out.view(torch.int64), ref.view(torch.int64)), vpw
     finally:
         ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
-        ctx.set_option(capi.OPT_DECODE_READ_AHEAD_US, 40)
+        ctx.set_option(capi.OPT_DECODE_READ_AHEAD_US, 0)
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
 
 

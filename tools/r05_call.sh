@@ -390,6 +390,20 @@ case $step in
 46) run 300 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q
 	tail -2 "$out/pytest.txt"
 	;;
+47) # the read-ahead's lead per width, finer, twice
+	for i in 1 2; do
+		WIDTHS=1,2,3,4,5,6,7 EXCS=0,20 WINDOWS=15,20,30,40,50,60,80 run 400 win.txt python tools/r05_read_ahead_windows.py
+	done
+	grep -v "amdgpu.ids\|^==" "$out/win.txt"
+	;;
+48) # the lead by width (option 13 = 0, the default) against 40 us fixed, decode tests first
+	run 300 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	for i in 1 2; do
+		WIDTHS=1,2,3,4,5,6,7 EXCS=0,20 WINDOWS=0,40 run 300 win.txt python tools/r05_read_ahead_windows.py
+	done
+	grep -v "amdgpu.ids\|^==" "$out/win.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
