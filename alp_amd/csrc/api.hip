@@ -56,7 +56,7 @@ struct alpgpu_ctx {
 	int         decode_patch_max;  // ALPGPU_OPT_DECODE_PATCH_AFTER: ALP vectors with 1..this many exceptions are patched after their stores (0: never; <= 64)
 	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
 	int         read_ahead;        // ALPGPU_OPT_DECODE_READ_AHEAD: the store decode runs with a read-ahead into the Infinity Cache on the second stream (read_ahead_kernels.hip)
-	int         read_ahead_us;     // ... this many microseconds ahead of the decode kernel (0: 10 + 5.5 us per packed bit of the vectors)
+	int         read_ahead_us;     // ... this many microseconds ahead of the decode kernel (0: 12 + 6.5 us per packed bit of the vectors, at most 60)
 	int         read_ahead_grid;   // ... by this many eight-wavefront workgroups
 	int         read_ahead_bits;   // ... records of vectors of at most this many packed bits per value (the descriptors of all)
 	uint64_t*   d_progress;        // ... paced by this word of device memory (2 KiB: [0] the decode's position, tagged; [1] never written; [64..159] alpgpu_column_totals' segment sums)
@@ -553,16 +553,20 @@ static bool column_decodes_with_exceptions(const alpgpu_ctx* ctx, const alpgpu_c
 }
 
 // The store decode of this column runs with the read-ahead (read_ahead_kernels.hip).  Asked for (1): any column long enough to be worth a second launch whose
-// sizes are known (the lead is in vectors per microsecond).  Left to the library (-1, the default): columns of NARROW vectors only — up to kReadAheadBits packed
-// bits per value the decode is bound by its two dependent reads under a write-dominated stream (0.68-0.69 of the HBM peak at 2-6 bits, 0.60-0.65 with
-// exceptions) and gains 8-16 % from finding them in the Infinity Cache (0.75-0.80 / 0.68-0.74); at 8 bits it is even, from 12 bits on the second stream of
-// reads costs more than the hits save (benchmark column 0.77 -> 0.73).  tools/r05_read_ahead*.py, profiles/r05_read_ahead.txt.
-constexpr double   kReadAheadBits    = 7.0;
+// sizes are known (the lead is in vectors per microsecond).  Left to the library (-1, the default): columns of NARROW vectors only — there the decode is bound
+// by its two dependent reads under a write-dominated stream (0.68-0.72 of the HBM peak at 2-6 bits, 0.60-0.69 with exceptions) and gains from finding them in
+// the Infinity Cache: +3-14 % up to 6 bits (one vector per workgroup), with exceptions +5-24 % up to 7 bits (two per workgroup).  At 7 bits without exceptions
+// it is even across six closing runs (-1 %), and an extension to 11 / 9 bits that single-column A/B runs suggested (+2-7 %, call 49) lost 3-6 % in the bench line of
+// another box (call 50): the limits are where the gain is robust.  Beyond, the second stream of reads costs more than the hits save (benchmark column 0.77 -> 0.73).
+// The lead that goes with a width: alpgpu_decode_f64.  tools/r05_read_ahead*.py, profiles/r05_read_ahead.txt.
+constexpr double   kReadAheadBits    = 6.5; // without exceptions
+constexpr double   kReadAheadBitsExc = 7.5; // with exceptions
 constexpr uint64_t kReadAheadVectors = 262144; // shorter columns: the cold start and the join of the second stream eat the gain (cold columns: even at 131072 vectors)
 static bool read_ahead_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	if (ctx->read_ahead == 0 || col->packed_bytes_hint == 0 || ctx->d_progress == nullptr) { return false; }
 	if (ctx->read_ahead > 0) { return col->n_vectors >= 32768; }
-	return col->n_vectors >= kReadAheadVectors && static_cast<double>(col->packed_bytes_hint) <= kReadAheadBits * 128.0 * static_cast<double>(col->n_vectors);
+	const double limit = column_decodes_with_exceptions(ctx, col) ? kReadAheadBitsExc : kReadAheadBits;
+	return col->n_vectors >= kReadAheadVectors && static_cast<double>(col->packed_bytes_hint) <= limit * 128.0 * static_cast<double>(col->n_vectors);
 }
 
 static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
@@ -686,7 +690,7 @@ static int stretch_kind(const alpgpu_ctx* ctx, uint64_t n, uint64_t packed, uint
 	v.n_vectors = n, v.packed_bytes_hint = packed ? packed : 1, v.exc_bytes_hint = exc_bytes;
 	const bool   with_exc = column_decodes_with_exceptions(ctx, &v);
 	const double bits     = static_cast<double>(packed) / (128.0 * static_cast<double>(n));
-	const int    band     = bits <= kReadAheadBits ? 0 : (bits <= (with_exc ? 22.0 : 17.5) ? 1 : (bits < 38.0 ? 2 : 3));
+	const int    band     = bits <= (with_exc ? kReadAheadBitsExc : kReadAheadBits) ? 0 : (bits <= (with_exc ? 22.0 : 17.5) ? 1 : (bits < 38.0 ? 2 : 3));
 	return 2 * band + (with_exc ? 1 : 0);
 }
 
@@ -883,11 +887,12 @@ static int decode_one_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_o
 		const double   n        = static_cast<double>(col->n_vectors);
 		const double   per_vec  = (static_cast<double>(col->packed_bytes_hint) + static_cast<double>(col->exc_bytes_hint)) / n + 32.0;
 		const double   ps_vec   = (8192.0 + per_vec) / 8.0;                                    // picoseconds per vector at 8 TB/s
-		// ... how long: by the vectors' width unless set (the wider the vectors, the longer a read-ahead workgroup's round takes: best leads measured per width
-		// 15 / 20 / 30 / 30 / 35 / 40 / 50 us at 1 .. 7 bits, with and without exceptions; too short falls off a cliff, too long decays slowly: call 47)
+		// ... how long: by the vectors' width unless set — the wider the vectors, the longer a read-ahead workgroup's round takes.  Best leads measured per width
+		// (calls 47, 49): 15 / 20 / 30 / 30 / 35 / 40 / 50 us at 1 .. 7 bits, 50-70 us at 8-11, with and without exceptions; too short falls off a cliff whose place
+		// moves a little from box to box, too long decays slowly: a little above the optimum, 12 + 6.5 us per bit, at most 60.
 		const double   bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
-		const double   lead_by_width = 10.0 + 5.5 * bits;
-		const double   lead_us  = ctx->read_ahead_us > 0 ? static_cast<double>(ctx->read_ahead_us) : (lead_by_width > 80.0 ? 80.0 : lead_by_width);
+		const double   lead_by_width = 12.0 + 6.5 * bits;
+		const double   lead_us  = ctx->read_ahead_us > 0 ? static_cast<double>(ctx->read_ahead_us) : (lead_by_width > 60.0 ? 60.0 : lead_by_width);
 		const double   lead     = lead_us * 1.0e6 / ps_vec * 0.78; // ... vectors per lead time at the decode's usual 0.78 of the full rate
 		const uint32_t lead_max = static_cast<uint32_t>(lead < 4096.0 ? 4096.0 : (lead > 4.0e9 ? 4.0e9 : lead));
 		const uint32_t lead_min = 2048; // about what is resident when a workgroup reports: those vectors' reads are under way

@@ -219,8 +219,8 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 #define ALPGPU_OPT_DECODE_RESIDENCY_PAD 11
 /* ALPGPU_OPT_DECODE_READ_AHEAD (double store decode; round 5): alpgpu_decode_f64 starts a READ-AHEAD beside the decode kernel — a few persistent workgroups
  * on the context's second stream that pull descriptors, packed words and exception records into the Infinity Cache ALPGPU_OPT_DECODE_READ_AHEAD_US
- * microseconds (default 0 = by the vectors' width: 15 us at 1 bit .. 50 us at 7) ahead of the decode kernel, which tells them where it is; the decode's two dependent reads then hit the cache.
- *   -1 (default)  columns of >= 262144 vectors of at most 7 packed bits per value on average whose size hints are set (+8-16 % there; wider columns lose);
+ * microseconds (default 0 = by the vectors' width: 18 us at 1 bit .. 60 us from 8 bits on) ahead of the decode kernel, which tells them where it is; the decode's two dependent reads then hit the cache.
+ *   -1 (default)  columns of >= 262144 vectors of at most 6 packed bits per value on average (7 when they have exceptions) whose size hints are set (+3-24 % there; wider columns lose);
  *    0            never;   1  every column of >= 32768 vectors whose size hints are set (measurements).
  * Same output bytes.  The two kernels are joined on the context's stream: work enqueued behind alpgpu_decode_f64 waits for both. */
 #define ALPGPU_OPT_DECODE_READ_AHEAD 12

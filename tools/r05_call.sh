@@ -404,6 +404,29 @@ case $step in
 	done
 	grep -v "amdgpu.ids\|^==" "$out/win.txt"
 	;;
+49) # beyond 7 bits: the read-ahead (lead by width, and fixed leads) on 8-12-bit vectors, with and without exceptions, twice
+	for i in 1 2; do
+		WIDTHS=7,8,9,10,11,12 EXCS=0,20 WINDOWS=0,50,70,90 run 400 win.txt python tools/r05_read_ahead_windows.py
+	done
+	grep -v "amdgpu.ids\|^==" "$out/win.txt"
+	;;
+50) # the rule extended to 11 bits (9 with exceptions), leads 12 + 6.5 us per bit up to 60: decode tests, then the bench line
+	run 300 pytest.txt python -m pytest tests/test_decode_gpu.py -x -q
+	tail -2 "$out/pytest.txt"
+	run 400 bench.json python bench.py --steps 20 --warmup 5
+	python - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/r05/50/bench.json") if l.startswith("{")][-1])
+x = d["extras"]
+print(d["value"], d["roofline"]["frac"])
+for k in x:
+    if "sweep" in k:
+        print(k, x[k]["summary"])
+        print("  on ", x[k]["frac"][:12])
+        print("  off", x[k]["no_read_ahead"])
+print(x["decode_bimodal"])
+PY
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
