@@ -427,6 +427,15 @@ for k in x:
 print(x["decode_bimodal"])
 PY
 	;;
+51) # fewer search workgroups than CUs beside the encode (ALP columns): 64 / 96 / 128 / 192 against 256
+	export ALPGPU_LIB=$PWD/build/variants/libalpgpu_initbase.so
+	for b in 256 64 96 128 192 256; do
+		echo "== base $b" >>"$out/enc.txt"
+		ALPGPU_INIT_BASE=$b run 100 enc.txt python tools/r05_time_encode.py 1048576 mixed
+	done
+	unset ALPGPU_LIB
+	grep "^== base\|^mixed" "$out/enc.txt" | cut -c1-200
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
