@@ -436,6 +436,9 @@ PY
 	unset ALPGPU_LIB
 	grep "^== base\|^mixed" "$out/enc.txt" | cut -c1-200
 	;;
+52) run 200 hit.txt python tools/r05_hit_rate.py
+	grep -v "amdgpu.ids\|^==" "$out/hit.txt"
+	;;
 final) # the closing run on the library as committed: whole GPU suite, smoke, the bench line, the configs[4] line at N = 1, the profile
 	run 600 pytest.txt python -m pytest tests -m gpu -q
 	tail -4 "$out/pytest.txt"
