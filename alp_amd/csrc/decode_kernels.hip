@@ -1043,7 +1043,7 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 	// Unused dynamic LDS that caps the workgroups resident per CU (variant bits 8.. = KiB).  Wide vectors want FEWER
 	// streams in flight per CU than the eight the wavefront slots allow: a column of 40-53-bit vectors decodes at 0.81 of the HBM peak with six
 	// workgroups per CU and at 0.75 with eight, 34-38 bits like seven; up to 33 bits eight are best (tools/sweep_residency.py,
-	// profiles/r04_decode_floor.txt section 6).  decode_variant_for (api.hip) sets it from the column's size hints.
+	// profiles/r04_decode_floor.txt section 6).  decode_variant_for (api_decode.hip) sets it from the column's size hints.
 	const unsigned pad_lds  = static_cast<unsigned>((variant >> 8) & 0xFF) * 1024u;
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30; // a grid dimension holds < 2^31 workgroups -> chunk very long columns

@@ -2,7 +2,7 @@
 //
 // The decode kernels follow the descriptors as they find them, like the reference's decoder follows the bit width, exception count and
 // positions its caller hands it (include/alp/decoder.hpp:141-149 writes out[pos[i]] unchecked; src/falp.cpp reads 16*bw words).  Columns
-// from alpgpu_encode_* are well-formed by construction and blobs are validated on the host (api.hip: validate_blob_vectors); this kernel
+// from alpgpu_encode_* are well-formed by construction and blobs are validated on the host (api_container.hip: validate_blob_vectors); this kernel
 // is the same set of checks for descriptors that reached HBM some other way.  One thread per vector.
 #include "alp_device.hpp"
 #include "launch.hpp"
@@ -51,7 +51,7 @@ int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-// Per-segment sums over the descriptors (alpgpu_column_totals -> the context's segment table, api.hip): bytes of packed records, exceptions, vectors of ALP_RD rowgroups
+// Per-segment sums over the descriptors (alpgpu_column_totals -> the context's segment table, api_decode.hip): bytes of packed records, exceptions, vectors of ALP_RD rowgroups
 // of every segment of seg_vectors consecutive vectors.  kSegmentSplit workgroups per segment, each over its share, added into out[3 s .. 3 s + 2] (zeroed by the launcher).
 constexpr unsigned kSegmentSplit = 16;
 __global__ __launch_bounds__(256) void k_segment_sums(const alpgpu_vector_desc* __restrict__ descs, uint64_t n_vectors, uint64_t seg_vectors, unsigned long long* __restrict__ out) {

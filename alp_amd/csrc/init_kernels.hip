@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * W, (init_waves_per_simd<ASYNC, W, P::kBits>())
 	uint32_t walkers = gridDim.x;
 	if constexpr (ASYNC) {
 		if (adaptive_base != 0 && adaptive_base < gridDim.x) { // (kernel argument: uniform)
-			const bool     rd    = rgs[4 * lane].scheme == ALPGPU_SCHEME_ALP_RD; // 64 of the head's 256 rowgroups (api.hip: kAsyncHeadRowgroups)
+			const bool     rd    = rgs[4 * lane].scheme == ALPGPU_SCHEME_ALP_RD; // 64 of the head's 256 rowgroups (api_encode.hip: kAsyncHeadRowgroups)
 			const bool     heavy = __builtin_popcountll(ballot64(rd)) >= 32;
 			walkers              = heavy ? gridDim.x : adaptive_base;
 			if (blockIdx.x >= walkers) { return; }

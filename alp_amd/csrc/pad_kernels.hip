@@ -1,7 +1,7 @@
 // pad_kernels.hip — tail padding: incomplete last vectors are padded with the tail vector's first value
 // (PRIMITIVES.md:141-144, first strategy; the reference's drivers simply drop the tail,
 // publication/source_code/bench_compression_ratio/alp.cpp:195).  The serialized form of a compressed column — the HBM layout of
-// include/alpgpu.h laid end to end behind a 64-byte header whose n_values says where the data ends — is host code: api.hip,
+// include/alpgpu.h laid end to end behind a 64-byte header whose n_values says where the data ends — is host code: api_container.hip,
 // alpgpu_column_to_blob / alpgpu_column_from_blob.
 #include <hip/hip_runtime.h>
 

@@ -65,7 +65,7 @@ def test_committed_profiles_are_quoted_only_for_the_built_library():
 def test_every_entry_point_makes_its_contexts_device_current(capsys):
     """hipSetDevice is per host thread: a process that drives the GPUs of a node from several threads (alpgpu_compress_host_multi_*, or a caller's
     own threads) must get the context's device on whatever thread it calls from — tools/audit_set_device.py walks include/alpgpu.h's entry points
-    in alp_amd/csrc/api.hip (the in-process multi-GPU path has never met a second physical GPU)"""
+    in alp_amd/csrc/api_*.hip (the in-process multi-GPU path has never met a second physical GPU)"""
     import audit_set_device
     rc = audit_set_device.main()
     out = capsys.readouterr().out

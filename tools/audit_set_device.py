@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """audit_set_device.py: every entry point of the C ABI that is handed a context must make that context's device current ON THE CALLING THREAD
 before it touches the HIP runtime (hipSetDevice is per host thread: a process that drives eight GPUs from eight threads, or from one thread
-in turn, otherwise launches on whatever device the thread used last).  Parses alp_amd/csrc/api.hip: a function "sets the device" if its body
+in turn, otherwise launches on whatever device the thread used last).  Parses alp_amd/csrc/api_*.hip (the translation units behind include/alpgpu.h): a function "sets the device" if its body
 has ALPGPU_CHECK_CTX / hipSetDevice, or if the FIRST thing it does with its context is to hand it to a function that does.  Lists every
 exported alpgpu_* function with a context parameter and how it is covered; exit status 1 if one is not.  (tests/test_build_rules.py runs it.)"""
 import os
@@ -29,7 +29,8 @@ def functions(text):
 
 
 def main():
-    text = open(os.path.join(ROOT, "alp_amd", "csrc", "api.hip")).read()
+    csrc = os.path.join(ROOT, "alp_amd", "csrc")
+    text = "\n".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.startswith("api_") and f.endswith(".hip"))
     text = re.sub(r"//[^\n]*", "", text)
     fns = functions(text)
     direct = {n for n, (_, b) in fns.items() if "ALPGPU_CHECK_CTX(" in b or "hipSetDevice(" in b or "ALPGPU_PRIM(" in b}  # (ALPGPU_PRIM starts with ALPGPU_CHECK_CTX)

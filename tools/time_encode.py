@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""time_encode.py [n_vectors] [kinds...]: alpgpu_encode_f64 (rowgroup search + vector encode) on bench.py's encode columns with the search
-BESIDE the vector encode (ALPGPU_OPT_ENCODE_ASYNC_INIT = 1, the default) and in front of it (0); the two parts on their own; and a
-byte comparison of everything the two routes write.  One process = one library (ALPGPU_LIB selects an A/B build)."""
+"""time_encode.py [n_vectors] [kinds...]: alpgpu_encode_f64 ordered (look-back) against ALPGPU_OPT_ENCODE_UNORDERED (one atomic add per tile), arms
+alternating; the vector encode alone in both forms; the traffic probe alone and with the persistent search beside it; a read-only stream.
+profiles/r0N_encode_levers.txt."""
 import os
 import sys
 
@@ -15,21 +15,38 @@ from alp_amd import capi  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 kinds = sys.argv[2:] or ["mixed", "rd"]
 ctx = capi.Context(0)
-tag = os.path.basename(os.environ.get("ALPGPU_LIB", "libalpgpu.so")) + " kernel=" + os.environ.get("ALPGPU_ENCODE_KERNEL", "0(lean)") + (" wg/cu=" + os.environ["ALPGPU_ASYNC_INIT_WG_PER_CU"] if os.environ.get("ALPGPU_ASYNC_INIT_WG_PER_CU") else "")
+dev = torch.device("cuda:0")
+out = torch.empty(n * 1024, dtype=torch.float64, device=dev)
+print(f"lib {bench.lib_sha16()}  n={n}  env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("ALPGPU_")))
 for kind in kinds:
-    x = bench.synthetic_input(kind, n, torch.device("cuda:0"), seed=42)
-    cols, ms = {}, {}
-    for mode in (0, 1, 0, 1):
-        ctx.set_option(capi.OPT_ENCODE_ASYNC_INIT, mode)
-        col = capi.DeviceColumn(n, 0)
-        ms[mode], _ = bench.time_launches(lambda: ctx.encode(x, col), 7, 3)
-        cols[mode] = col
-    ctx.set_option(capi.OPT_ENCODE_ASYNC_INIT, 1)
-    imed, _ = bench.time_launches(lambda: ctx.rowgroup_init(x, cols[0]), 5, 2)
-    vmed, _ = bench.time_launches(lambda: ctx.encode_vectors(x, cols[0]), 5, 2)
-    pb, eb, ov = ctx.column_totals(cols[1])
-    same = all(torch.equal(a, b) for a, b in ((cols[0].rowgroups, cols[1].rowgroups), (cols[0].vectors, cols[1].vectors), (cols[0].packed[:pb], cols[1].packed[:pb]), (cols[0].exc[:eb], cols[1].exc[:eb])))
+    x = bench.synthetic_input(kind, n, dev, seed=42)
+    col = capi.DeviceColumn(n, 0)
+    ms = {0: [], 1: []}
+    vs = {0: [], 1: []}
+    for rep in range(3):
+        for u in (0, 1):
+            ctx.set_option(capi.OPT_ENCODE_UNORDERED, u)
+            ms[u].append(bench.time_launches(lambda: ctx.encode(x, col), 7, 3)[0])
+    ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
+    ctx.encode(x, col)
+    pb, eb, ov = ctx.column_totals(col)
     alg = bench.encode_alg_bytes(n, pb, eb)
-    print(f"{tag} {kind} n={n}: search beside the encode {ms[1]:.3f} ms = {alg / ms[1] / 1e6 / 8000:.3f} of peak | search in front {ms[0]:.3f} ms = {alg / ms[0] / 1e6 / 8000:.3f} "
-          f"| search alone {imed:.3f} | vectors alone {vmed:.3f} | the two routes wrote the same bytes: {same}", flush=True)
-    del x, cols
+    for u in (0, 1):
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, u)
+        vs[u].append(bench.time_launches(lambda: ctx.encode_vectors(x, col), 5, 2)[0])
+    ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
+    ctx.encode(x, col)
+    ctx.decode(col, out)
+    torch.cuda.synchronize()
+    rt = torch.equal(out.view(torch.int64), x.view(torch.int64))
+    ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
+    imed = bench.time_launches(lambda: ctx.rowgroup_init(x, col), 5, 2)[0]
+    wb = (pb + eb + 13 * n) // n // 16 * 16
+    p = bench.time_launches(lambda: ctx.traffic_probe(x, out, n, wb), 7, 3)[0]
+    ps = bench.time_launches(lambda: ctx.traffic_probe_with_search(x, out, n, wb, col), 7, 3)[0]
+    ro = bench.time_launches(lambda: ctx.traffic_probe(x, out, n, 0), 7, 3)[0]  # (write_bytes 0: a read-only stream, 8 bytes per vector stored)
+    f = lambda t: alg / t / 1e6 / 8000  # noqa: E731
+    print(f"{kind}: ordered {' '.join(f'{t:.3f}' for t in ms[0])} ms = {f(min(ms[0])):.3f}-{f(max(ms[0])):.3f} | unordered {' '.join(f'{t:.3f}' for t in ms[1])} ms = {f(min(ms[1])):.3f}-{f(max(ms[1])):.3f} "
+          f"(round trip {rt}) | vectors alone: ordered {vs[0][0]:.3f} unordered {vs[1][0]:.3f} | search alone {imed:.3f} | probe ({wb} B written per vector) {p:.3f} ms = {f(p):.3f}, with the search beside {ps:.3f} ms = {f(ps):.3f} "
+          f"| read-only 8 KiB per vector {ro:.3f} ms = {n * 8192 / ro / 1e6 / 8000:.3f} of peak", flush=True)
+    del x, col
