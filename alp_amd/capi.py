@@ -71,12 +71,19 @@ _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
 OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL, OPT_CONSUMER_PIPELINED, OPT_ENCODE_ASYNC_INIT, OPT_ENCODE_KERNEL, OPT_DECODE_PAIRING = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_DECODE_PATCH_AFTER, OPT_ENCODE_UNORDERED, OPT_DECODE_RESIDENCY_PAD = 9, 10, 11
-OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US, OPT_DECODE_SEGMENTS = 12, 13, 14
+OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US, OPT_DECODE_SEGMENTS, OPT_DECODE_UNHINTED = 12, 13, 14, 15
 ENCODE_KERNEL_LEAN, ENCODE_KERNEL_CLASSIC = 0, 1
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_decode_reads_ahead", _int, _vp, C.POINTER(CColumn), _int)
 _sig("alpgpu_decode_runs", _int, _vp, C.POINTER(CColumn))
+try:  # (round 6; an A/B library of an earlier round selected with ALPGPU_LIB does not have them)
+    _sig("alpgpu_decode_runs_f32", _int, _vp, C.POINTER(CColumn))
+    _sig("alpgpu_debug_read_ahead_batches", _int, _vp, C.POINTER(_u64))
+    _sig("alpgpu_debug_unhinted_plan", _int, _vp, C.POINTER(_u64 * 6))
+    _sig("alpgpu_debug_forget_column", _int, _vp, C.POINTER(CColumn))
+except AttributeError:
+    pass
 _sig("alpgpu_debug_traffic_probe", _int, _vp, _vp, _vp, _u64, C.c_uint32)
 try:
     _sig("alpgpu_debug_traffic_probe_with_search", _int, _vp, _vp, _vp, _u64, C.c_uint32, C.POINTER(CColumn))
@@ -276,7 +283,24 @@ class Context:
 
     def decode_runs(self, col: "DeviceColumn") -> int:
         """launches decode() of this column would make now: 1, or the runs of regions of different kinds (OPT_DECODE_SEGMENTS; after column_totals / from_blob)"""
-        return int(lib.alpgpu_decode_runs(self.h, C.byref(col.c)))
+        return int((lib.alpgpu_decode_runs_f32 if col.dtype == "f32" else lib.alpgpu_decode_runs)(self.h, C.byref(col.c)))
+
+    def read_ahead_batches(self) -> int:
+        """batches of 64 vectors this context's read-aheads have read since it was created (debug counter; waits for the streams)"""
+        n = _u64()
+        _check(lib.alpgpu_debug_read_ahead_batches(self.h, C.byref(n)), "alpgpu_debug_read_ahead_batches")
+        return n.value
+
+    def forget(self, col: "DeviceColumn"):
+        """what the context remembers about this column (segments, learned sizes) is dropped, as an encode into it would"""
+        _check(lib.alpgpu_debug_forget_column(self.h, C.byref(col.c)), "alpgpu_debug_forget_column")
+
+    def unhinted_plan(self) -> dict:
+        """the device-side plan of this context's last unhinted decode (include/alpgpu.h: alpgpu_debug_unhinted_plan)"""
+        w = (_u64 * 6)()
+        _check(lib.alpgpu_debug_unhinted_plan(self.h, C.byref(w)), "alpgpu_debug_unhinted_plan")
+        return {"shape": int(w[0]), "lead_min": int(w[1] & 0xFFFFFFFF), "lead_max": int(w[1] >> 32), "ps_per_vector": int(w[2] & 0xFFFFFFFF), "max_bits": int(w[2] >> 32),
+                "packed_bytes": int(w[3]), "exceptions": int(w[4]), "rd_vectors": int(w[5])}
 
     def decode_reads_ahead(self, col: "DeviceColumn") -> bool:
         """decode() of this column would start the read-ahead beside the decode kernel (OPT_DECODE_READ_AHEAD)"""

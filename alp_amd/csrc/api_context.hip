@@ -107,7 +107,7 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_pad_kib     = std::getenv("ALPGPU_DECODE_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_PAD_LDS_KIB")) & 0xFF : -1;
 	// the patch arm exists in -DALPGPU_DECODE_PATCH_MODE=1 / 2 builds of decode_kernels.hip only (measured slower than the mask route: profiles/r05_decode_exceptions.txt);
 	// the default build ignores the limit, and the launch rule must not count on an arm that is not there: 0 unless asked for
-	ctx->decode_patch_max   = std::getenv("ALPGPU_DECODE_PATCH_AFTER") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_AFTER")) : 0; // (A/B runs)
+	ctx->decode_patch_max   = (std::getenv("ALPGPU_DECODE_PATCH_AFTER") && alpgpu::decode_patch_arm_compiled()) ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_AFTER")) : 0; // (A/B runs)
 	if (ctx->decode_patch_max < 0 || ctx->decode_patch_max > 64) { ctx->decode_patch_max = 64; }
 	ctx->decode_patch_shape = std::getenv("ALPGPU_DECODE_PATCH_SHAPE") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_SHAPE")) : 1;
 	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
@@ -119,31 +119,34 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_segments = std::getenv("ALPGPU_DECODE_SEGMENTS") ? std::atoi(std::getenv("ALPGPU_DECODE_SEGMENTS")) : 1;
 	for (auto& t : ctx->seg_tables) { t.key = nullptr; }
 	ctx->seg_next        = 0;
-	ctx->read_ahead_bits = std::getenv("ALPGPU_READ_AHEAD_BITS") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_BITS")) : 128;
-	ctx->d_progress      = nullptr;
-	ctx->progress_gen    = 0;
+	ctx->decode_unhinted = std::getenv("ALPGPU_DECODE_UNHINTED") ? std::atoi(std::getenv("ALPGPU_DECODE_UNHINTED")) : 1;
+	for (auto& l : ctx->learn) { l.state = 0, l.key = nullptr, l.ev = nullptr; }
+	ctx->learn_next      = 0;
+	ctx->h_learn         = nullptr;
+	// Where kernels of two streams cannot run side by side the read-ahead can only wait for a decode that starts after it has left (its patience: a few hundred
+	// microseconds per decode, read_ahead_kernels.hip): left to itself (-1) the library then does not start it at all.  What the runtime documents for that:
 	{
-		int khz = 0;
-		if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { khz = 100000; } // 100 MHz: gfx9's s_memrealtime
-		ctx->wall_tick_ps = static_cast<uint32_t>(1000000000ll / khz);
-		if (ctx->wall_tick_ps == 0) { ctx->wall_tick_ps = 1; }
+		const char* ser = std::getenv("AMD_SERIALIZE_KERNEL");
+		const char* blk = std::getenv("HIP_LAUNCH_BLOCKING");
+		const char* q   = std::getenv("GPU_MAX_HW_QUEUES");
+		ctx->streams_serialize = ((ser && std::atoi(ser) != 0) || (blk && std::atoi(blk) != 0) || (q && std::atoi(q) == 1)) ? 1 : 0;
 	}
-	ctx->workspace       = nullptr;
-	ctx->workspace_bytes = 0;
-	ctx->ws_stream       = nullptr;
-	ctx->ws_busy         = 0;
-	if (hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) {
-		(void)hipStreamDestroy(ctx->own_stream);
-		delete ctx;
-		return fail(ALPGPU_ERR_HIP, "hipEventCreate failed");
-	}
-	if (hipMalloc(reinterpret_cast<void**>(&ctx->d_progress), 2048) != hipSuccess || hipMemset(ctx->d_progress, 0, 2048) != hipSuccess) {
-		if (ctx->d_progress) { (void)hipFree(ctx->d_progress); }
-		(void)hipEventDestroy(ctx->ws_event);
-		(void)hipStreamDestroy(ctx->init_stream);
-		(void)hipStreamDestroy(ctx->own_stream);
-		delete ctx;
-		return fail(ALPGPU_ERR_HIP, "hipMalloc of the context's progress word failed");
+	// what unhinted decodes learn about their columns (api_decode.hip): page-locked words + one event per slot; without them such columns simply stay unhinted
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_learn), sizeof(uint64_t) * kLearnSlots * 3 * kMaxSegments, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->h_learn = nullptr;
+	} else {
+		for (auto& l : ctx->learn) {
+			if (hipEventCreateWithFlags(&l.ev, hipEventDisableTiming) != hipSuccess) {
+				(void)hipGetLastError();
+				for (auto& m : ctx->learn) {
+					if (m.ev) { (void)hipEventDestroy(m.ev); m.ev = nullptr; }
+				}
+				(void)hipHostFree(ctx->h_learn);
+				ctx->h_learn = nullptr;
+				break;
+			}
+		}
 	}
 	if (const char* v = std::getenv("ALPGPU_DECODE_VARIANT")) { // A/B runs
 		ctx->decode_variant = std::atoi(v);
@@ -169,6 +172,13 @@ void alpgpu_ctx_destroy(alpgpu_ctx* ctx) {
 	(void)hipStreamDestroy(ctx->own_stream);
 	if (ctx->workspace) { (void)hipFree(ctx->workspace); }
 	if (ctx->d_progress) { (void)hipFree(ctx->d_progress); }
+	for (auto& l : ctx->learn) {
+		if (l.ev) {
+			if (l.state == 1) { (void)hipEventSynchronize(l.ev); }
+			(void)hipEventDestroy(l.ev);
+		}
+	}
+	if (ctx->h_learn) { (void)hipHostFree(ctx->h_learn); }
 	delete ctx;
 }
 
@@ -223,8 +233,14 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	case ALPGPU_OPT_ENCODE_UNORDERED:
 		ctx->encode_unordered = value ? 1 : 0;
 		return ALPGPU_OK;
+	case ALPGPU_OPT_DECODE_UNHINTED:
+		if (value < 0 || value > 1) { return fail(ALPGPU_ERR_INVALID, "unhinted decode: 0 (one vector per workgroup, as before round 6) or 1 (sizes summed and the shape chosen on the device)"); }
+		ctx->decode_unhinted = static_cast<int>(value);
+		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_PATCH_AFTER:
 		if (value < 0 || value > 64) { return fail(ALPGPU_ERR_INVALID, "decode patch-after: 0 (never) .. 64 exceptions per vector"); }
+		// the arm exists in -DALPGPU_DECODE_PATCH_MODE=1 / 2 builds only: without it the launch rule must not count on it
+		if (value != 0 && !alpgpu::decode_patch_arm_compiled()) { return fail(ALPGPU_ERR_INVALID, "decode patch-after: this build of libalpgpu has no patch arm (-DALPGPU_DECODE_PATCH_MODE=1 or 2)"); }
 		ctx->decode_patch_max = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_READ_AHEAD:

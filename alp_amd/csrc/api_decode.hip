@@ -1,6 +1,11 @@
 // api_decode.hip — the store decode's LAUNCH POLICY (vectors per workgroup, residency, read-ahead, region by region), the decode entry points, the fused
 // consumers and alpgpu_column_totals (which records what the policy needs) of include/alpgpu.h (see host_ctx.hpp for the map).
+#include "decode_policy.hpp"
 #include "host_ctx.hpp"
+
+using alpgpu::kReadAheadBits;
+using alpgpu::kReadAheadBitsExc;
+using alpgpu::kReadAheadVectors;
 
 extern "C" {
 
@@ -22,14 +27,12 @@ static bool column_decodes_with_exceptions(const alpgpu_ctx* ctx, const alpgpu_c
 // it is even across six closing runs (-1 %), and an extension to 11 / 9 bits that single-column A/B runs suggested (+2-7 %, call 49) lost 3-6 % in the bench line of
 // another box (call 50): the limits are where the gain is robust.  Beyond, the second stream of reads costs more than the hits save (benchmark column 0.77 -> 0.73).
 // The lead that goes with a width: alpgpu_decode_f64.  tools/r05_read_ahead*.py, profiles/r05_read_ahead.txt.
-constexpr double   kReadAheadBits    = 6.5; // without exceptions
-constexpr double   kReadAheadBitsExc = 7.5; // with exceptions
-constexpr uint64_t kReadAheadVectors = 262144; // shorter columns: the cold start and the join of the second stream eat the gain (cold columns: even at 131072 vectors)
-static bool read_ahead_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
+// (float columns, round 6: the same kernel beside k_decode_column_f32, limits of their own — decode_policy.hpp, profiles/r06_float_decode.txt)
+static bool read_ahead_for(const alpgpu_ctx* ctx, const alpgpu_column* col, int value_bytes = 8) {
 	if (ctx->read_ahead == 0 || col->packed_bytes_hint == 0 || ctx->d_progress == nullptr) { return false; }
 	if (ctx->read_ahead > 0) { return col->n_vectors >= 32768; }
-	const double limit = column_decodes_with_exceptions(ctx, col) ? kReadAheadBitsExc : kReadAheadBits;
-	return col->n_vectors >= kReadAheadVectors && static_cast<double>(col->packed_bytes_hint) <= limit * 128.0 * static_cast<double>(col->n_vectors);
+	if (ctx->streams_serialize) { return false; } // (the two kernels cannot run side by side in this process: api_context.hip)
+	return alpgpu::policy_read_ahead_auto(col->n_vectors, static_cast<double>(col->packed_bytes_hint), column_decodes_with_exceptions(ctx, col), value_bytes);
 }
 
 static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
@@ -44,7 +47,7 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		// kNarrowAutoBits bits FOUR vectors share a workgroup over the narrow stage (round 4).
 		const bool   with_exc = column_decodes_with_exceptions(ctx, col);
 		const double bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * (n > 0 ? n : 1.0));
-		const bool   narrow   = bits <= (with_exc ? 22.0 : 17.5); // (17.5: with the residency caps below two vectors per workgroup win through 17 bits; with exceptions through 22: round 5)
+		const bool   narrow   = bits <= (with_exc ? alpgpu::kTwoVectorsBitsExc : alpgpu::kTwoVectorsBits); // (17.5: with the residency caps below two vectors per workgroup win through 17 bits; with exceptions through 22: round 5)
 		const double four_max = with_exc ? ctx->decode_four_bits_exc : ctx->decode_four_bits; // (0 = never: the four-vector shape lost at every width, it is chosen by tuning runs only)
 		const bool   four     = four_max > 0.0 && bits <= four_max;
 		variant               = (variant & ~5) | ((hinted && narrow) ? 0 : 1) | ((hinted && four) ? 4 : 0);
@@ -92,6 +95,18 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	return (variant & 7) | (pairing << 3) | (pad_kib << 8);
 }
 
+// Float columns (round 6): vectors per workgroup — 2 (the bytes in flight of one double vector), FOUR for columns of narrow vectors whose sizes are known, what
+// ALPGPU_OPT_DECODE_VECTORS_PER_WG says otherwise — and the residency pad (ALPGPU_OPT_DECODE_RESIDENCY_PAD, else none).  tools/sweep_f32_decode.py,
+// profiles/r06_float_decode.txt.  Returns vectors per workgroup | pad KiB << 8 (pad 0xFF: the kernel's environment knob, for experiments).
+static int decode_shape_f32(const alpgpu_ctx* ctx, const alpgpu_column* col) {
+	int vpw = ctx->decode_vpw ? ctx->decode_vpw : 2;
+	if (ctx->decode_vpw == 0 && ctx->decode_auto && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
+		const double bits = static_cast<double>(col->packed_bytes_hint) / (128.0 * static_cast<double>(col->n_vectors));
+		if (bits <= (column_decodes_with_exceptions(ctx, col) ? alpgpu::kFourVectorsBitsExcF32 : alpgpu::kFourVectorsBitsF32)) { vpw = 4; }
+	}
+	return vpw | ((ctx->decode_pad_kib >= 0 ? ctx->decode_pad_kib : 0xFF) << 8);
+}
+
 // ---- a launch rule that sees more than the column's averages (round 5) -------------------------------------------------------------------------
 // alpgpu_column_totals and alpgpu_column_from_blob record, per segment of the column, what they record for the whole: packed bytes, exceptions, ALP_RD
 // vectors.  alpgpu_decode_f64 of that column (same context, same descriptor buffer) merges adjacent segments of the same KIND — by packed width: up to the
@@ -105,7 +120,7 @@ struct DecodeRun {
 	uint64_t v0, n, packed, exc_bytes, rd_vectors;
 };
 
-static uint64_t segment_vectors_for(uint64_t n_vectors) {
+uint64_t segment_vectors_for(uint64_t n_vectors) {
 	uint64_t sv = (n_vectors + kMaxSegments - 1) / kMaxSegments;
 	sv          = (sv + 399) / 400 * 400;
 	return sv < kSegmentMinVectors ? kSegmentMinVectors : sv;
@@ -120,15 +135,24 @@ static SegmentTable* segment_table_of(alpgpu_ctx* ctx, const alpgpu_column* col)
 	}
 	return nullptr;
 }
-void segment_table_forget(alpgpu_ctx* ctx, const alpgpu_column* col) {
-	if (!ctx || !col) { return; }
+static void segment_tables_drop(alpgpu_ctx* ctx, const alpgpu_column* col) {
 	for (auto& t : ctx->seg_tables) {
 		if (t.key == col->d_vectors) { t.key = nullptr; }
 	}
 }
+void segment_table_forget(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	if (!ctx || !col) { return; }
+	segment_tables_drop(ctx, col);
+	for (auto& l : ctx->learn) { // ... and what an unhinted decode of the old content left behind (decode_unhinted)
+		if (l.state != 0 && l.key == col->d_vectors) {
+			if (l.state == 1) { (void)hipEventSynchronize(l.ev); } // (its copy targets the slot's host words: let it land before the slot is reused)
+			l.state = 0;
+		}
+	}
+}
 // (packed_bytes / exc_bytes: the stream sizes the caller is about to write into the column's hints)
 SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t packed_bytes, uint64_t exc_bytes) {
-	segment_table_forget(ctx, col);
+	segment_tables_drop(ctx, col);
 	SegmentTable* t = nullptr;
 	for (auto& c : ctx->seg_tables) {
 		if (c.key == nullptr) { t = &c; break; }
@@ -146,27 +170,33 @@ SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col, uint6
 	return t;
 }
 
-// the kind of a stretch of vectors, from its sums (see above)
-static int stretch_kind(const alpgpu_ctx* ctx, uint64_t n, uint64_t packed, uint64_t exc_bytes) {
+// the kind of a stretch of vectors, from its sums (see above); float columns: up to the read-ahead's limit / up to the four-vectors limit / beyond
+static int stretch_kind(const alpgpu_ctx* ctx, uint64_t n, uint64_t packed, uint64_t exc_bytes, int value_bytes) {
 	alpgpu_column v {};
 	v.n_vectors = n, v.packed_bytes_hint = packed ? packed : 1, v.exc_bytes_hint = exc_bytes;
 	const bool   with_exc = column_decodes_with_exceptions(ctx, &v);
 	const double bits     = static_cast<double>(packed) / (128.0 * static_cast<double>(n));
-	const int    band     = bits <= (with_exc ? kReadAheadBitsExc : kReadAheadBits) ? 0 : (bits <= (with_exc ? 22.0 : 17.5) ? 1 : (bits < 38.0 ? 2 : 3));
+	int          band;
+	if (value_bytes == 8) {
+		band = bits <= (with_exc ? kReadAheadBitsExc : kReadAheadBits) ? 0 : (bits <= (with_exc ? alpgpu::kTwoVectorsBitsExc : alpgpu::kTwoVectorsBits) ? 1 : (bits < 38.0 ? 2 : 3));
+	} else {
+		band = bits <= (with_exc ? alpgpu::kReadAheadBitsExcF32 : alpgpu::kReadAheadBitsF32) ? 0 : (bits <= (with_exc ? alpgpu::kFourVectorsBitsExcF32 : alpgpu::kFourVectorsBitsF32) ? 1 : 2);
+	}
 	return 2 * band + (with_exc ? 1 : 0);
 }
 
 // runs[0 .. return) cover the column; 0 = no plan (decode the column whole)
-static int plan_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col, DecodeRun* runs) {
+static int plan_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col, DecodeRun* runs, int value_bytes = 8) {
 	if (!ctx->decode_segments || !ctx->decode_auto || ctx->decode_pad_kib >= 0 || ctx->decode_pairing != 0) { return 0; } // (a forced shape is a forced shape)
+	if (value_bytes == 4 && ctx->decode_vpw != 0) { return 0; }
 	const SegmentTable* t = segment_table_of(ctx, col);
 	if (!t || t->n_seg < 2) { return 0; }
 	int n_runs = 0, kind = -1;
 	for (uint32_t s = 0; s < t->n_seg; ++s) {
 		const uint64_t v0 = s * t->seg_vectors;
 		const uint64_t n  = v0 + t->seg_vectors < t->n_vectors ? t->seg_vectors : t->n_vectors - v0;
-		const uint64_t eb = 10ull * t->exc_cnt[s]; // (ALP: 8-byte value + 2-byte position; ALP_RD records are smaller and their vectors wide anyway)
-		const int      k  = stretch_kind(ctx, n, t->packed[s], eb);
+		const uint64_t eb = (value_bytes + 2ull) * t->exc_cnt[s]; // (ALP: the value + a 2-byte position; ALP_RD records are smaller and their vectors wide anyway)
+		const int      k  = stretch_kind(ctx, n, t->packed[s], eb, value_bytes);
 		if (k != kind) {
 			if (n_runs == kMaxRuns) { return 0; }
 			runs[n_runs++] = DecodeRun {v0, 0, 0, 0, 0};
@@ -194,7 +224,7 @@ static alpgpu_column run_view(const alpgpu_column* col, const DecodeRun& r) {
 // what alpgpu_decode_f64 / _f32 would launch for this column right now (option + size hints): vectors per decode workgroup
 int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32) {
 	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
-	if (is_f32) { return ctx->decode_vpw ? ctx->decode_vpw : 2; }
+	if (is_f32) { return decode_shape_f32(ctx, col) & 0xFF; }
 	const int variant = decode_variant_for(ctx, col);
 	if ((variant >> 3) & 3) { return 2; } // (the pair kernel: two vectors per workgroup, run together or one after the other)
 	return (variant & 4) ? 4 : ((variant & 1) ? 1 : 2);
@@ -203,7 +233,7 @@ int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int 
 // ... and whether it would start the read-ahead beside the decode kernel (ALPGPU_OPT_DECODE_READ_AHEAD): 1 / 0; negative on bad arguments
 int alpgpu_decode_reads_ahead(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32) {
 	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
-	return (!is_f32 && read_ahead_for(ctx, col)) ? 1 : 0;
+	return read_ahead_for(ctx, col, is_f32 ? 4 : 8) ? 1 : 0;
 }
 
 // measurement aid: what alpgpu_decode_sum_f64 costs with its unpack arithmetic left out (decode_kernels.hip: kSinkProbe)
@@ -291,57 +321,195 @@ int alpgpu_decode_count_range_f64(alpgpu_ctx* ctx, const alpgpu_column* col, dou
 	return ALPGPU_OK;
 }
 
-// one launch of the store decode over a column or a run of it (+ the read-ahead beside it where the rule wants one)
-static int decode_one_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
-	const int variant = decode_variant_for(ctx, col);
+extern "C++" {
+// the next tag of the context's progress word (its top 24 bits: a stale value of an earlier launch reads as "not started")
+static uint64_t next_progress_tag(alpgpu_ctx* ctx) {
+	ctx->progress_gen = (ctx->progress_gen + 1) & 0xFFFFFFull;
+	if (ctx->progress_gen == 0) { ctx->progress_gen = 1; }
+	return ctx->progress_gen << 40;
+}
+
+// one launch of the store decode over a column or a run of it (+ the read-ahead beside it where the rule wants one); VB = 8 (double) or 4 (float)
+template <int VB>
+static int decode_one(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 	// The read-ahead (read_ahead_kernels.hip): a few persistent workgroups on the context's second stream pull the column's streams into the Infinity
 	// Cache a bounded distance ahead of the decode kernel, which tells them where it is.  Started first so that it is ahead from the first workgroup on.
-	const bool ahead = read_ahead_for(ctx, col);
+	const bool ahead = read_ahead_for(ctx, col, VB);
 	uint64_t   tag   = 0;
 	if (ahead) {
-		ctx->progress_gen = (ctx->progress_gen + 1) & 0xFFFFFFull;
-		if (ctx->progress_gen == 0) { ctx->progress_gen = 1; }
-		tag = ctx->progress_gen << 40;
-		// The lead is a TIME (ALPGPU_OPT_DECODE_READ_AHEAD_US): what the read-ahead brings into the Infinity Cache stays there for some tens of
-		// microseconds only (the decode's own stores stream through it), and it has to be there before the decode asks.  In vectors: that time at the rate of
-		// a decode running at the full HBM bandwidth (an upper bound of the true rate: the read-ahead's naps by it never overshoot).
-		const double   n        = static_cast<double>(col->n_vectors);
-		const double   per_vec  = (static_cast<double>(col->packed_bytes_hint) + static_cast<double>(col->exc_bytes_hint)) / n + 32.0;
-		const double   ps_vec   = (8192.0 + per_vec) / 8.0;                                    // picoseconds per vector at 8 TB/s
-		// ... how long: by the vectors' width unless set — the wider the vectors, the longer a read-ahead workgroup's round takes.  Best leads measured per width
-		// (calls 47, 49): 15 / 20 / 30 / 30 / 35 / 40 / 50 us at 1 .. 7 bits, 50-70 us at 8-11, with and without exceptions; too short falls off a cliff whose place
-		// moves a little from box to box, too long decays slowly: a little above the optimum, 12 + 6.5 us per bit, at most 60.
-		const double   bits     = static_cast<double>(col->packed_bytes_hint) / (128.0 * n);
-		const double   lead_by_width = 12.0 + 6.5 * bits;
-		const double   lead_us  = ctx->read_ahead_us > 0 ? static_cast<double>(ctx->read_ahead_us) : (lead_by_width > 60.0 ? 60.0 : lead_by_width);
-		const double   lead     = lead_us * 1.0e6 / ps_vec * 0.78; // ... vectors per lead time at the decode's usual 0.78 of the full rate
-		const uint32_t lead_max = static_cast<uint32_t>(lead < 4096.0 ? 4096.0 : (lead > 4.0e9 ? 4.0e9 : lead));
-		const uint32_t lead_min = 2048; // about what is resident when a workgroup reports: those vectors' reads are under way
+		tag = next_progress_tag(ctx);
+		const alpgpu::ReadAheadPace pace = alpgpu::policy_read_ahead_pace(static_cast<double>(col->n_vectors), static_cast<double>(col->packed_bytes_hint),
+		                                                                  static_cast<double>(col->exc_bytes_hint), VB, ctx->read_ahead_us); // (decode_policy.hpp: the lead is a time)
 		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
 		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
-		if (alpgpu::launch_read_ahead(ctx->init_stream, col, 8, ctx->d_progress, tag, lead_min, lead_max, static_cast<uint32_t>(ps_vec), ctx->wall_tick_ps, static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, VB, ctx->d_progress, tag, pace.lead_min, pace.lead_max, pace.ps_per_vector, ctx->wall_tick_ps, static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
 			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
 		}
 		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
 	}
-	const int rc = alpgpu::launch_decode_column(ctx->stream, col, d_out, variant, ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), ahead ? ctx->d_progress : nullptr, tag);
+	int rc;
+	if constexpr (VB == 8) {
+		rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), decode_variant_for(ctx, col), ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), ahead ? ctx->d_progress : nullptr, tag);
+	} else {
+		const int shape = decode_shape_f32(ctx, col);
+		rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), shape & 0xFF, (ctx->decode_variant & 2) != 0, (shape >> 8) == 0xFF ? -1 : (shape >> 8), ahead ? ctx->d_progress : nullptr, tag);
+	}
 	if (ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); } // (the read-ahead leaves on its own once its last batch is in reach or the decode never shows up)
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
 	return ALPGPU_OK;
 }
 
-int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) {
+// ---- a column whose sizes the host does not know (round 6) ------------------------------------------------------------------------
+// alpgpu_encode_* leaves the stream sizes in device memory; the host learns them from alpgpu_column_totals, a synchronisation.  A caller that encodes and
+// decodes without it used to get the slowest shape (one vector per workgroup, no read-ahead: 0.51-0.58 on 2-6-bit vectors).  Now, for columns of at least
+// kUnhintedMinVectors vectors: the per-segment sums are taken on the stream (k_segment_sums, 17 us per 1 Mi vectors), k_unhinted_plan evaluates the rule on the
+// device (decode_policy.hpp) and EVERY candidate shape is launched, gated on the plan's word — closed candidates cost their dispatch only — with the read-ahead
+// beside them taking its lead and pace from the same words.  The sums also travel to page-locked host memory behind an event nobody waits for: the NEXT decode
+// of the same column (same descriptor and packed buffers, same length, not encoded again in between) finds them there and is planned on the host like a
+// hinted one, region by region included.  ALPGPU_OPT_DECODE_UNHINTED = 0: the old behaviour.
+constexpr uint64_t kUnhintedMinVectors = 65536;
+
+static LearnSlot* learn_slot_of(alpgpu_ctx* ctx, const alpgpu_column* col, int value_bytes) {
+	for (auto& l : ctx->learn) {
+		if (l.state != 0 && l.key == col->d_vectors && l.d_packed == col->d_packed && l.n_vectors == col->n_vectors && l.value_bytes == value_bytes) { return &l; }
+	}
+	return nullptr;
+}
+
+// the column with the sizes an earlier unhinted decode of it left behind, if they have arrived; false: nothing known (yet)
+static bool learned_hints(alpgpu_ctx* ctx, const alpgpu_column* col, int value_bytes, alpgpu_column* hinted) {
+	LearnSlot* l = learn_slot_of(ctx, col, value_bytes);
+	if (!l) { return false; }
+	if (l->state == 1) {
+		if (hipEventQuery(l->ev) != hipSuccess) {
+			(void)hipGetLastError(); // not ready: not an error
+			return false;
+		}
+		const uint64_t* sums = ctx->h_learn + static_cast<size_t>(l - ctx->learn) * 3 * kMaxSegments;
+		l->packed = l->exceptions = l->rd_vectors = 0;
+		for (uint32_t i = 0; i < l->n_seg; ++i) { l->packed += sums[3 * i], l->exceptions += sums[3 * i + 1], l->rd_vectors += sums[3 * i + 2]; }
+		l->state = 2;
+		if (l->n_seg >= 2) { // the decode's launch plan (plan_decode_runs), as alpgpu_column_totals would have left it
+			alpgpu_column c = *col;
+			SegmentTable* t = segment_table_new(ctx, &c, l->packed ? l->packed : 1, (value_bytes + 2ull) * l->exceptions);
+			for (uint32_t i = 0; i < t->n_seg && i < l->n_seg; ++i) { t->packed[i] = sums[3 * i], t->exc_cnt[i] = sums[3 * i + 1], t->rd_vectors[i] = sums[3 * i + 2]; }
+		}
+	}
+	*hinted = *col;
+	hinted->packed_bytes_hint     = l->packed ? l->packed : 1; // (a column of nothing but 0-bit vectors: "known, and narrow")
+	hinted->exc_bytes_hint        = (value_bytes + 2ull) * l->exceptions;
+	hinted->alp_rd_rowgroups_hint = 1 + l->rd_vectors / 100;
+	return true;
+}
+
+template <int VB>
+static int decode_unhinted(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
+	uint64_t* words = ctx->d_progress;
+	const uint64_t seg_vectors = segment_vectors_for(col->n_vectors);
+	const uint32_t n_seg       = static_cast<uint32_t>((col->n_vectors + seg_vectors - 1) / seg_vectors);
+	if (alpgpu::launch_segment_sums(ctx->stream, col, seg_vectors, n_seg, words + alpgpu::kCtxWordSegments) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "segment sums launch failed", hipGetLastError()); }
+	if (alpgpu::launch_unhinted_plan(ctx->stream, words, n_seg, col->n_vectors, VB, (ctx->read_ahead < 0 && ctx->streams_serialize) ? 0 : ctx->read_ahead, ctx->read_ahead_us, static_cast<uint32_t>(ctx->read_ahead_bits)) != ALPGPU_OK) {
+		return fail(ALPGPU_ERR_HIP, "plan launch failed", hipGetLastError());
+	}
+	// the sums, for the next decode of this column: to page-locked memory behind an event that is only ever queried
+	if (ctx->h_learn != nullptr) {
+		LearnSlot* l = learn_slot_of(ctx, col, VB);
+		if (!l) {
+			l               = &ctx->learn[ctx->learn_next];
+			ctx->learn_next = (ctx->learn_next + 1) % kLearnSlots;
+		}
+		if (l->state == 1) { (void)hipEventSynchronize(l->ev); } // (the slot's previous copy still in flight: a fifth unhinted column within microseconds)
+		l->key = col->d_vectors, l->d_packed = col->d_packed, l->n_vectors = col->n_vectors, l->value_bytes = VB, l->n_seg = n_seg;
+		l->state = 0;
+		if (hipMemcpyAsync(ctx->h_learn + static_cast<size_t>(l - ctx->learn) * 3 * kMaxSegments, words + alpgpu::kCtxWordSegments, 24ull * n_seg, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+		    hipEventRecord(l->ev, ctx->stream) == hipSuccess) {
+			l->state = 1;
+		} else {
+			(void)hipGetLastError(); // best effort: the column simply stays unhinted
+		}
+	}
+	const uint64_t tag        = next_progress_tag(ctx);
+	const bool     with_ahead = ctx->read_ahead > 0 || (ctx->read_ahead < 0 && !ctx->streams_serialize);
+	if (with_ahead) { // (the kernel leaves at once when the plan says "no read-ahead for this column")
+		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, VB, words, tag, 0, 0, 0, ctx->wall_tick_ps, 0, ctx->read_ahead_grid, true) != ALPGPU_OK) {
+			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
+		}
+		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
+	}
+	const bool plain = (ctx->decode_variant & 2) != 0;
+	int        rc    = ALPGPU_OK;
+	if constexpr (VB == 8) { // decode_policy.hpp: 1 = one vector per workgroup + 6 KiB, 2 = two per workgroup, 3 = one per workgroup + 11 KiB
+		const int variants[alpgpu::kUnhintedShapesF64] = {1 | (6 << 8), 0, 1 | (11 << 8)};
+		for (int c = 0; c < alpgpu::kUnhintedShapesF64 && rc == ALPGPU_OK; ++c) {
+			rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), variants[c] | (plain ? 2 : 0), ctx->n_cus, 0u, words, tag, static_cast<uint32_t>(c + 1));
+		}
+	} else { // 1 = two vectors per workgroup, 2 = four
+		const int vpw[alpgpu::kUnhintedShapesF32] = {2, 4};
+		for (int c = 0; c < alpgpu::kUnhintedShapesF32 && rc == ALPGPU_OK; ++c) {
+			rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), vpw[c], plain, 0, words, tag, static_cast<uint32_t>(c + 1));
+		}
+	}
+	if (with_ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
+	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
+	return ALPGPU_OK;
+}
+
+template <int VB>
+static int decode_column(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
-	if (col->n_vectors && (!col->d_vectors || !col->d_rowgroups)) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
+	alpgpu_column hinted;
+	const bool    unhinted = col->packed_bytes_hint == 0 && col->exc_bytes_hint == 0;
+	const bool    free_shape = ctx->decode_auto && ctx->decode_pairing == 0 && ctx->decode_pad_kib < 0 && (VB == 8 || ctx->decode_vpw == 0);
+	if (unhinted && ctx->decode_unhinted && free_shape && ctx->d_progress != nullptr && col->n_vectors >= kUnhintedMinVectors) {
+		if (learned_hints(ctx, col, VB, &hinted)) {
+			col = &hinted; // an earlier decode of this column took its sizes: planned on the host from here on
+		} else {
+			return decode_unhinted<VB>(ctx, col, d_out);
+		}
+	}
 	DecodeRun runs[kMaxRuns];
-	const int n_runs = plan_decode_runs(ctx, col, runs);
-	if (n_runs == 0) { return decode_one_f64(ctx, col, d_out); }
+	const int n_runs = plan_decode_runs(ctx, col, runs, VB);
+	if (n_runs == 0) { return decode_one<VB>(ctx, col, d_out); }
 	for (int i = 0; i < n_runs; ++i) { // regions of different kinds, each with its own launch shape (plan_decode_runs)
 		const alpgpu_column view = run_view(col, runs[i]);
-		if (const int rc = decode_one_f64(ctx, &view, d_out + runs[i].v0 * 1024)) { return rc; }
+		if (const int rc = decode_one<VB>(ctx, &view, static_cast<uint8_t*>(d_out) + runs[i].v0 * 1024 * VB)) { return rc; }
 	}
+	return ALPGPU_OK;
+}
+} // extern "C++"
+
+int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) { return decode_column<8>(ctx, col, d_out); }
+int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out) { return decode_column<4>(ctx, col, d_out); }
+
+// debug aids (tests): batches of 64 vectors the context's read-aheads have read so far; the plan words of its last unhinted decode
+// (out[0] shape, [1] lead_min | lead_max << 32, [2] ps per vector | max bits << 32, [3..5] packed bytes, exceptions, ALP_RD vectors).  Both wait for the stream.
+int alpgpu_debug_read_ahead_batches(alpgpu_ctx* ctx, uint64_t* batches) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!batches || !ctx->d_progress) { return fail(ALPGPU_ERR_INVALID, "null output"); }
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	ALPGPU_HIP(hipStreamSynchronize(ctx->init_stream));
+	ALPGPU_HIP(hipMemcpy(batches, ctx->d_progress + alpgpu::kCtxWordBatches, 8, hipMemcpyDeviceToHost));
+	return ALPGPU_OK;
+}
+int alpgpu_debug_forget_column(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!col) { return fail(ALPGPU_ERR_INVALID, "null column"); }
+	segment_table_forget(ctx, col);
+	return ALPGPU_OK;
+}
+int alpgpu_debug_unhinted_plan(alpgpu_ctx* ctx, uint64_t* out6) {
+	ALPGPU_CHECK_CTX(ctx);
+	if (!out6 || !ctx->d_progress) { return fail(ALPGPU_ERR_INVALID, "null output"); }
+	ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
+	uint64_t w[16];
+	ALPGPU_HIP(hipMemcpy(w, ctx->d_progress, sizeof(w), hipMemcpyDeviceToHost));
+	out6[0] = w[alpgpu::kCtxWordShape], out6[1] = w[alpgpu::kCtxWordLead], out6[2] = w[alpgpu::kCtxWordPace];
+	out6[3] = w[alpgpu::kCtxWordTotals], out6[4] = w[alpgpu::kCtxWordTotals + 1], out6[5] = w[alpgpu::kCtxWordTotals + 2];
 	return ALPGPU_OK;
 }
 
@@ -349,7 +517,13 @@ int alpgpu_decode_f64(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_out) 
 int alpgpu_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col) {
 	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
 	DecodeRun runs[kMaxRuns];
-	const int n_runs = plan_decode_runs(ctx, col, runs);
+	const int n_runs = plan_decode_runs(ctx, col, runs, 8);
+	return n_runs == 0 ? 1 : n_runs;
+}
+int alpgpu_decode_runs_f32(alpgpu_ctx* ctx, const alpgpu_column* col) {
+	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
+	DecodeRun runs[kMaxRuns];
+	const int n_runs = plan_decode_runs(ctx, col, runs, 4);
 	return n_runs == 0 ? 1 : n_runs;
 }
 int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_bytes, uint64_t* exc_bytes, int* overflow) {
@@ -360,20 +534,22 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_b
 		const bool count_rd = col->d_rowgroups != nullptr && col->n_rowgroups != 0;
 		if (count_rd && alpgpu::launch_count_rd_rowgroups(ctx->stream, col, col->d_totals + 7) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "rowgroup count launch failed", hipGetLastError()); }
 		// per-segment sums for the decode's launch plan (plan_decode_runs): columns long enough to have two segments
-		SegmentTable* seg = nullptr;
-		uint64_t      seg_sums[3 * kMaxSegments];
+		// (the table is filled first and gets its key last: an early return leaves no half-made entry that a later decode could match — ADVICE round 5)
+		uint64_t seg_sums[3 * kMaxSegments];
+		uint64_t seg_vectors = 0;
+		uint32_t n_seg       = 0;
 		segment_table_forget(ctx, col);
 		if (col->d_vectors && ctx->d_progress && col->n_vectors >= 2 * kSegmentMinVectors) {
-			seg = segment_table_new(ctx, col, 0, 0); // (the sizes: below, once they are here)
-			if (alpgpu::launch_segment_sums(ctx->stream, col, seg->seg_vectors, seg->n_seg, ctx->d_progress + 64) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "segment sums launch failed", hipGetLastError()); }
-			ALPGPU_HIP(hipMemcpyAsync(seg_sums, ctx->d_progress + 64, 24ull * seg->n_seg, hipMemcpyDeviceToHost, ctx->stream));
+			seg_vectors = segment_vectors_for(col->n_vectors);
+			n_seg       = static_cast<uint32_t>((col->n_vectors + seg_vectors - 1) / seg_vectors);
+			if (alpgpu::launch_segment_sums(ctx->stream, col, seg_vectors, n_seg, ctx->d_progress + alpgpu::kCtxWordSegments) != ALPGPU_OK) { return fail(ALPGPU_ERR_HIP, "segment sums launch failed", hipGetLastError()); }
+			ALPGPU_HIP(hipMemcpyAsync(seg_sums, ctx->d_progress + alpgpu::kCtxWordSegments, 24ull * n_seg, hipMemcpyDeviceToHost, ctx->stream));
 		}
 		ALPGPU_HIP(hipMemcpyAsync(t, col->d_totals, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
 		ALPGPU_HIP(hipStreamSynchronize(ctx->stream));
-		if (seg) {
-			for (uint32_t i = 0; i < seg->n_seg; ++i) { seg->packed[i] = seg_sums[3 * i], seg->exc_cnt[i] = seg_sums[3 * i + 1], seg->rd_vectors[i] = seg_sums[3 * i + 2]; }
-			seg->packed_bytes = t[0], seg->exc_bytes = t[1];
-			if (t[2] || t[3]) { seg->key = nullptr; } // an overflowed or unrecovered column: no plans
+		if (n_seg != 0 && !t[2] && !t[3]) { // (an overflowed or unrecovered column: no plans)
+			SegmentTable* seg = segment_table_new(ctx, col, t[0], t[1]);
+			for (uint32_t i = 0; i < seg->n_seg && i < n_seg; ++i) { seg->packed[i] = seg_sums[3 * i], seg->exc_cnt[i] = seg_sums[3 * i + 1], seg->rd_vectors[i] = seg_sums[3 * i + 2]; }
 		}
 		col->alp_rd_rowgroups_hint = count_rd ? 1 + t[7] : (col->n_vectors == 0 ? 1 : 0);
 	} else if (col->n_vectors != 0) {
@@ -388,18 +564,6 @@ int alpgpu_column_totals(alpgpu_ctx* ctx, alpgpu_column* col, uint64_t* packed_b
 	if (t[3]) { return fail(ALPGPU_ERR_HIP, "single-pass encode stalled in its offset look-back and was not recovered"); }
 	return t[2] ? fail(ALPGPU_ERR_CAPACITY, "an output stream overflowed its capacity") : ALPGPU_OK;
 }
-int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out) {
-	ALPGPU_CHECK_CTX(ctx);
-	if (!col || (!d_out && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }
-	if (col->n_vectors == 0) { return ALPGPU_OK; }
-	if (!col->d_vectors || !col->d_rowgroups) { return fail(ALPGPU_ERR_INVALID, "column has no descriptors"); }
-	const int vpw = ctx->decode_vpw ? ctx->decode_vpw : 2; // a float vector is 4 KiB: two per workgroup = the bytes of one double vector
-	if (alpgpu::launch_decode_column_f32(ctx->stream, col, d_out, vpw, (ctx->decode_variant & 2) != 0) != ALPGPU_OK) {
-		return fail(ALPGPU_ERR_HIP, "decode launch failed", hipGetLastError());
-	}
-	return ALPGPU_OK;
-}
-
 int alpgpu_decode_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums) {
 	ALPGPU_CHECK_CTX(ctx);
 	if (!col || (!d_sums && col->n_vectors)) { return fail(ALPGPU_ERR_INVALID, "null column or output"); }

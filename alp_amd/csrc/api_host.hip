@@ -25,11 +25,22 @@ struct HostPipe { // everything a call allocates, released on every return path
 	int         n_dev     = 0;
 	hipStream_t saved     = nullptr;
 	int         saved_unordered = 0;
+	int         saved_read_ahead = 0, saved_unhinted = 0;
 	alpgpu_ctx* ctx       = nullptr;
+	// The pipeline alternates ctx->stream between its two streams, so two chunks' decodes are in flight at once: they must not share the context's ONE progress word,
+	// fork / join events and side stream.  Chunks are far below the read-ahead's thresholds today; the pipeline says so instead of relying on it.
+	void bind(alpgpu_ctx* c) {
+		ctx              = c;
+		saved            = c->stream;
+		saved_unordered  = c->encode_unordered;
+		saved_read_ahead = c->read_ahead, saved_unhinted = c->decode_unhinted;
+		c->read_ahead = 0, c->decode_unhinted = 0;
+	}
 	~HostPipe() {
 		if (ctx) {
 			ctx->stream           = saved;
 			ctx->encode_unordered = saved_unordered;
+			ctx->read_ahead = saved_read_ahead, ctx->decode_unhinted = saved_unhinted;
 		}
 		for (int k = 0; k < 2; ++k) {
 			if (stream[k]) { (void)hipStreamSynchronize(stream[k]); }
@@ -60,9 +71,7 @@ int compress_host_piece(alpgpu_ctx* ctx, const void* h_in, uint64_t n_values, ui
 	const uint64_t VB       = 1024ull * VALUE_BYTES;
 	const uint64_t capacity = out_cap; // of the streams
 	HostPipe P;
-	P.ctx   = ctx;
-	P.saved = ctx->stream;
-	P.saved_unordered     = ctx->encode_unordered;
+	P.bind(ctx);
 	ctx->encode_unordered = 0; // a blob's streams are in vector order (byte for byte the reference's; the chunked decompression relies on it)
 	uint64_t total_p = 0, total_e = 0;
 	bool     blob_full = false;
@@ -383,8 +392,7 @@ int decompress_host_range(alpgpu_ctx* ctx, const void* h_blob, const alpgpu_blob
 	const uint64_t E1 = v_end < n ? desc_at(v_end).exc_off : h.exc_bytes;
 	if (P0 > P1 || E0 > E1 || P1 > h.packed_bytes || E1 > h.exc_bytes) { return fail(ALPGPU_ERR_INVALID, "blob: stream offsets do not ascend with the vector index"); }
 	HostPipe P;
-	P.ctx   = ctx;
-	P.saved = ctx->stream;
+	P.bind(ctx);
 	alpgpu_column col;
 	std::memset(&col, 0, sizeof(col));
 	col.n_vectors = nr, col.n_rowgroups = rg_end - rg_begin, col.packed_capacity = h.packed_bytes, col.exc_capacity = h.exc_bytes;

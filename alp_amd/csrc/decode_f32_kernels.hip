@@ -13,6 +13,7 @@
 // unit of the FastLanes u32 layout, alp_device_f32.hpp), and V consecutive vectors per workgroup keep the bytes in flight
 // per CU at the level of the double-precision kernel (V = 2 moves as many bytes per workgroup as one double vector).
 #include "alp_device_f32.hpp"
+#include "decode_policy.hpp"
 #include "launch.hpp"
 #include <cstdlib>
 
@@ -330,13 +331,20 @@ template <int V, bool NT_STORE, int SINK = kSinkStoreF>
 __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu_vector_desc* __restrict__ descs,
                                                                     const alpgpu_rowgroup_state* __restrict__ rgs, const uint8_t* __restrict__ packed,
                                                                     const uint8_t* __restrict__ excs, float* __restrict__ out, uint64_t n_vectors,
-                                                                    uint64_t wg_offset, float range_lo, float range_hi) {
+                                                                    uint64_t wg_offset, float range_lo, float range_hi, uint64_t* __restrict__ progress, uint64_t progress_tag,
+                                                                    uint32_t gate) {
 	__shared__ DecodeLdsF32 L[V];
 	const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
 	const int      wave = wave_in_wg();
 	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
 	if (v0 >= n_vectors) { return; }
+	if constexpr (SINK == kSinkStoreF) {
+		// a candidate launch of an unhinted decode runs only if the plan says so; the read-ahead's pace: every 128th workgroup says where the launch is
+		// (decode_kernels.hip: k_decode_column; round 6: the float store decode reports too)
+		if (gate != 0u && progress[kCtxWordShape] != static_cast<uint64_t>(gate)) { return; } // (kernel argument: uniform)
+		if (progress != nullptr && (blockIdx.x & 127u) == 0 && tid == 0) { __hip_atomic_store(progress, progress_tag | v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	}
 
 	alpgpu_vector_desc d[V];
 	uint32_t           pos[V];
@@ -403,31 +411,34 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 }
 
 template <int V>
-static void launch_v(hipStream_t stream, const alpgpu_column* col, float* d_out, bool nt) {
+static void launch_v(hipStream_t stream, const alpgpu_column* col, float* d_out, bool nt, int pad_kib, uint64_t* progress, uint64_t tag, uint32_t gate) {
 	const uint64_t n        = col->n_vectors;
 	const uint64_t n_wg     = (n + V - 1) / V;
 	const uint64_t kMaxGrid = 1ull << 30;
-	// experiment (ALPGPU_DECODE_F32_PAD_LDS_KIB): unused dynamic LDS that caps the workgroups resident per CU, as the double decode does for wide columns
-	static const unsigned pad_lds = std::getenv("ALPGPU_DECODE_F32_PAD_LDS_KIB") ? static_cast<unsigned>(std::atoi(std::getenv("ALPGPU_DECODE_F32_PAD_LDS_KIB"))) * 1024u : 0u;
+	// unused dynamic LDS that caps the workgroups resident per CU, as the double decode does by width (pad_kib < 0: ALPGPU_DECODE_F32_PAD_LDS_KIB, for experiments, else none)
+	static const int env_pad = std::getenv("ALPGPU_DECODE_F32_PAD_LDS_KIB") ? std::atoi(std::getenv("ALPGPU_DECODE_F32_PAD_LDS_KIB")) : 0;
+	const unsigned   pad_lds = static_cast<unsigned>(pad_kib >= 0 ? pad_kib : env_pad) * 1024u;
+	if (gate != 0 && progress == nullptr) { gate = 0; }
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
 		if (nt) {
-			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
+			hipLaunchKernelGGL((k_decode_column_f32<V, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f, progress, tag, gate);
 		} else {
-			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f);
+			hipLaunchKernelGGL((k_decode_column_f32<V, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0f, 0.0f, progress, tag, gate);
 		}
 	}
 }
 
 // vectors_per_wg in {1, 2, 4}
-int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores) {
+int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores, int pad_kib, uint64_t* progress, uint64_t progress_tag,
+                             uint32_t gate) {
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
 	if (vectors_per_wg == 1) {
-		launch_v<1>(stream, col, d_out, !plain_stores);
+		launch_v<1>(stream, col, d_out, !plain_stores, pad_kib, progress, progress_tag, gate);
 	} else if (vectors_per_wg == 2) {
-		launch_v<2>(stream, col, d_out, !plain_stores);
+		launch_v<2>(stream, col, d_out, !plain_stores, pad_kib, progress, progress_tag, gate);
 	} else {
-		launch_v<4>(stream, col, d_out, !plain_stores);
+		launch_v<4>(stream, col, d_out, !plain_stores, pad_kib, progress, progress_tag, gate);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
@@ -441,7 +452,7 @@ static int launch_sink_f32(hipStream_t stream, const alpgpu_column* col, void* d
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
 		hipLaunchKernelGGL((k_decode_column_f32<V, false, SINK>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc,
-		                   static_cast<float*>(d_result), n, off, lo, hi);
+		                   static_cast<float*>(d_result), n, off, lo, hi, static_cast<uint64_t*>(nullptr), 0ull, 0u);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

@@ -28,6 +28,7 @@
 // HBM traffic per vector is the algorithmic minimum: 32 B descriptor + 128*bw B packed + exception record read,
 // 8192 B written (rocprofv3 FETCH_SIZE/WRITE_SIZE: profiles/*_pmc.json); no intermediate goes to HBM.
 #include "alp_device.hpp"
+#include "decode_policy.hpp"
 #include "launch.hpp"
 #include <cstdlib>
 
@@ -662,6 +663,12 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	const int      wave = wave_in_wg();
 	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
 	if (v0 >= n_vectors) { return; }
+	// An unhinted decode (api_decode.hip) launches every candidate shape; the plan kernel in front of them has written which one runs (bits 8.. of patch_max
+	// = this launch's number, 0 = not a candidate: the usual launch).  One scalar load, taken by candidates only; a closed candidate costs its dispatch.
+	if (SINK == kSinkStore && (patch_max >> 8) != 0u) { // (kernel argument: uniform)
+		if (progress[kCtxWordShape] != static_cast<uint64_t>(patch_max >> 8)) { return; }
+		patch_max &= 0xFFu;
+	}
 	// the read-ahead's pace (read_ahead_kernels.hip): workgroups are dispatched in ascending order, every 128th says where the launch is
 	if (SINK == kSinkStore && progress != nullptr && (blockIdx.x & 127u) == 0 && tid == 0) {
 		__hip_atomic_store(progress, progress_tag | v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1017,9 +1024,13 @@ int launch_sink_direct(hipStream_t stream, const alpgpu_column* col, double lo, 
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max, uint64_t* progress, uint64_t progress_tag) {
+// whether this build has an arm that patches exceptions in after the stores (-DALPGPU_DECODE_PATCH_MODE=1 / 2; the default build has none: ALPGPU_OPT_DECODE_PATCH_AFTER is refused)
+bool decode_patch_arm_compiled() { return ALPGPU_DECODE_PATCH_MODE != 0; }
+
+int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max, uint64_t* progress, uint64_t progress_tag, uint32_t gate) {
 	(void)n_cus;
 	if (patch_max > 64u) { patch_max = 64u; } // one lane per patched exception (apply_patches)
+	if (gate != 0 && progress != nullptr) { patch_max |= gate << 8; } // (k_decode_column: a candidate launch of an unhinted decode)
 	const uint64_t n = col->n_vectors;
 	// variant bit 0: one vector per workgroup (default) instead of two; bit 1: plain instead of non-temporal stores; bit 2: FOUR vectors per
 	// workgroup over the narrow stage (columns of <= 16-bit vectors)

@@ -5,6 +5,7 @@
 // from alpgpu_encode_* are well-formed by construction and blobs are validated on the host (api_container.hip: validate_blob_vectors); this kernel
 // is the same set of checks for descriptors that reached HBM some other way.  One thread per vector.
 #include "alp_device.hpp"
+#include "decode_policy.hpp"
 #include "launch.hpp"
 
 namespace alpgpu {
@@ -81,6 +82,34 @@ __global__ __launch_bounds__(256) void k_segment_sums(const alpgpu_vector_desc* 
 int launch_segment_sums(hipStream_t stream, const alpgpu_column* col, uint64_t seg_vectors, uint32_t n_seg, uint64_t* d_out) {
 	if (hipMemsetAsync(d_out, 0, 24ull * n_seg, stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
 	hipLaunchKernelGGL(k_segment_sums, dim3(n_seg * kSegmentSplit), dim3(256), 0, stream, col->d_vectors, col->n_vectors, seg_vectors, reinterpret_cast<unsigned long long*>(d_out));
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
+// The plan of an UNHINTED decode (round 6; api_decode.hip: decode_unhinted): the column's sizes are not known on the host — it was encoded a moment ago on this
+// stream and nobody has called alpgpu_column_totals, a host synchronisation — so the rule (decode_policy.hpp: policy_unhinted, the same numbers the host's rule
+// uses) is evaluated here, from the segment sums k_segment_sums has just left in the context's words, and its answer goes into the plan words: which of the
+// candidate launches enqueued behind this kernel runs, and whether, how far ahead and at what pace the read-ahead beside them reads.  One wavefront.
+__global__ __launch_bounds__(64) void k_unhinted_plan(uint64_t* __restrict__ words, uint32_t n_seg, uint64_t n_vectors, int value_bytes, int read_ahead_option, int lead_us_option,
+                                                      uint32_t max_bits) {
+	if (threadIdx.x != 0) { return; }
+	uint64_t packed = 0, exceptions = 0, rd = 0;
+	for (uint32_t s = 0; s < n_seg; ++s) {
+		packed += words[kCtxWordSegments + 3 * s], exceptions += words[kCtxWordSegments + 3 * s + 1], rd += words[kCtxWordSegments + 3 * s + 2];
+	}
+	const UnhintedChoice c = policy_unhinted(n_vectors, static_cast<double>(packed), static_cast<double>(exceptions), static_cast<double>(rd), value_bytes, read_ahead_option);
+	uint64_t lead = 0, pace = 0;
+	if (c.ahead) {
+		const ReadAheadPace p = policy_read_ahead_pace(static_cast<double>(n_vectors), static_cast<double>(packed), (value_bytes + 2.0) * static_cast<double>(exceptions), value_bytes, lead_us_option);
+		lead = (static_cast<uint64_t>(p.lead_max) << 32) | p.lead_min;
+		pace = (static_cast<uint64_t>(max_bits) << 32) | p.ps_per_vector;
+	}
+	words[kCtxWordTotals] = packed, words[kCtxWordTotals + 1] = exceptions, words[kCtxWordTotals + 2] = rd;
+	words[kCtxWordLead]  = lead;
+	words[kCtxWordPace]  = pace;
+	words[kCtxWordShape] = static_cast<uint64_t>(c.shape);
+}
+int launch_unhinted_plan(hipStream_t stream, uint64_t* d_ctx_words, uint32_t n_seg, uint64_t n_vectors, int value_bytes, int read_ahead_option, int lead_us_option, uint32_t max_bits) {
+	hipLaunchKernelGGL(k_unhinted_plan, dim3(1), dim3(64), 0, stream, d_ctx_words, n_seg, n_vectors, value_bytes, read_ahead_option, lead_us_option, max_bits);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 

@@ -39,6 +39,20 @@ struct SegmentTable {
 	uint64_t    rd_vectors[kMaxSegments]; // vectors of ALP_RD rowgroups
 };
 
+// What an UNHINTED decode learned about a column (api_decode.hip: decode_unhinted): the per-segment sums taken on the stream travel to page-locked host words behind
+// an event that is only ever queried; once there, the next decode of the same column is planned on the host.  state 0: empty, 1: copy in flight, 2: sizes known.
+constexpr int kLearnSlots = 4;
+struct LearnSlot {
+	const void* key;       // col->d_vectors
+	const void* d_packed;
+	uint64_t    n_vectors;
+	int         value_bytes;
+	uint32_t    n_seg;
+	int         state;
+	hipEvent_t  ev;
+	uint64_t    packed, exceptions, rd_vectors;
+};
+
 struct alpgpu_ctx {
 	int         device;
 	hipStream_t own_stream;
@@ -65,15 +79,20 @@ struct alpgpu_ctx {
 	int         decode_patch_max;  // ALPGPU_OPT_DECODE_PATCH_AFTER: ALP vectors with 1..this many exceptions are patched after their stores (0: never; <= 64)
 	int         decode_patch_shape; // 1 (default): a column whose vectors are patched picks its launch shape like a column without exceptions (ALPGPU_DECODE_PATCH_SHAPE=0 for A/B runs)
 	int         read_ahead;        // ALPGPU_OPT_DECODE_READ_AHEAD: the store decode runs with a read-ahead into the Infinity Cache on the second stream (read_ahead_kernels.hip)
+	int         streams_serialize; // the process runs with GPU_MAX_HW_QUEUES=1 / AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING: left to itself (-1) the library starts no read-ahead
 	int         read_ahead_us;     // ... this many microseconds ahead of the decode kernel (0: 12 + 6.5 us per packed bit of the vectors, at most 60)
 	int         read_ahead_grid;   // ... by this many eight-wavefront workgroups
 	int         read_ahead_bits;   // ... records of vectors of at most this many packed bits per value (the descriptors of all)
-	uint64_t*   d_progress;        // ... paced by this word of device memory (2 KiB: [0] the decode's position, tagged; [1] never written; [64..159] alpgpu_column_totals' segment sums)
+	uint64_t*   d_progress;        // ... paced by this word of device memory (2 KiB; the map of its words: decode_policy.hpp)
 	uint64_t    progress_gen;      // ... whose tag changes with every launch
 	uint32_t    wall_tick_ps;      // picoseconds per tick of the device's wall_clock64() (the read-ahead's naps)
 	int         decode_segments;   // ALPGPU_OPT_DECODE_SEGMENTS: a column whose regions differ is decoded region by region, each with its own launch shape (1, default)
 	SegmentTable seg_tables[4];    // ... from the per-segment sizes alpgpu_column_totals / alpgpu_column_from_blob last saw (host-side, keyed by the descriptor buffer)
 	int         seg_next;
+	int         decode_unhinted;   // ALPGPU_OPT_DECODE_UNHINTED (1, default): a column whose sizes the host does not know gets them summed on the stream and its launch shape chosen on the device
+	LearnSlot   learn[kLearnSlots]; // ... and what those sums said, for the next decode of the same column
+	int         learn_next;
+	uint64_t*   h_learn;           // page-locked: kLearnSlots x 3 x kMaxSegments words
 	int         pipelined_consumer; // 1: the fused consumers through the persistent LDS-ring kernel (consume_kernels.hip; its own summation order)
 	void*       workspace;       // scan workspace (tile sums / tile status words), grown on demand
 	uint64_t    workspace_bytes;
@@ -118,6 +137,7 @@ ALPGPU_INTERNAL int check_column(const alpgpu_column* col, uint64_t n_vectors);
 // api_decode.hip: the per-segment sizes the decode's launch plan is made from (a column that is encoded again has new regions)
 constexpr uint64_t kSegmentMinVectors = 32800; // a multiple of 400: runs begin on rowgroup boundaries and on even vectors
 ALPGPU_INTERNAL void          segment_table_forget(alpgpu_ctx* ctx, const alpgpu_column* col);
+ALPGPU_INTERNAL uint64_t      segment_vectors_for(uint64_t n_vectors);
 ALPGPU_INTERNAL SegmentTable* segment_table_new(alpgpu_ctx* ctx, const alpgpu_column* col, uint64_t packed_bytes, uint64_t exc_bytes);
 // api_container.hip: a serialized column's header and descriptors, checked on the host
 ALPGPU_INTERNAL int  validate_blob_header(const void* h_blob, uint64_t size, uint64_t value_bytes, alpgpu_blob_header& h);

@@ -14,14 +14,17 @@ constexpr int kStateUnpublished = 0xFF;
 // decode_kernels.hip
 // patch_max: ALP vectors with 1..patch_max (<= 64) exceptions are decoded without any per-value lookup and patched after their stores (0: never)
 // progress (nullable): a word of device memory the kernel's workgroups report their position to, tagged (read_ahead_kernels.hip)
+// gate (unhinted decode, api_decode.hip): != 0 -> the launch runs only if the context's shape word (progress[kCtxWordShape], decode_policy.hpp) holds this value
 int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d_out, int variant, int n_cus, uint32_t patch_max, uint64_t* progress = nullptr,
-                         uint64_t progress_tag = 0);
+                         uint64_t progress_tag = 0, uint32_t gate = 0);
+bool decode_patch_arm_compiled();
 // read_ahead_kernels.hip: the column's descriptors, packed words and exception records read into the Infinity Cache a bounded distance ahead of the decode
 // kernel that reports to d_progress with this tag (lead_min / lead_max in vectors; value_bytes 8 or 4; grid workgroups of four wavefronts)
 // ps_per_vector: picoseconds the decode needs per vector AT LEAST (the read-ahead's workgroups sleep by it between looks at the progress word);
 // ps_per_tick: of wall_clock64() on this device (hipDeviceAttributeWallClockRate)
-int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
-                      uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid); // max_bits: records of wider vectors are left alone (their descriptors are read)
+// d_ctx_words: the context's 2 KiB of device words (decode_policy.hpp); from_plan: lead, pace and max_bits are read from its plan words (an unhinted decode)
+int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, uint64_t* d_ctx_words, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
+                      uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid, bool from_plan = false); // max_bits: records of wider vectors are left alone (their descriptors are read)
 int launch_decode_sum(hipStream_t stream, const alpgpu_column* col, double* d_sums, int vectors_per_wg);
 int launch_decode_count_range(hipStream_t stream, const alpgpu_column* col, double lo, double hi, uint32_t* d_counts);
 // the same sinks, one wavefront per vector, packed words straight from HBM (no stage, no barrier); count = false: per-vector sums (double), true: counts (u32)
@@ -40,6 +43,8 @@ int launch_validate_column(hipStream_t stream, const alpgpu_column* col, uint32_
 int launch_count_rd_rowgroups(hipStream_t stream, const alpgpu_column* col, uint64_t* d_count);
 // d_out[3 s .. 3 s + 2] = {packed bytes, exceptions, ALP_RD vectors} of segment s (seg_vectors consecutive vectors each)
 int launch_segment_sums(hipStream_t stream, const alpgpu_column* col, uint64_t seg_vectors, uint32_t n_seg, uint64_t* d_out);
+// the unhinted decode's plan (decode_policy.hpp: policy_unhinted) from the segment sums just taken, into the context's plan words; one small workgroup
+int launch_unhinted_plan(hipStream_t stream, uint64_t* d_ctx_words, uint32_t n_seg, uint64_t n_vectors, int value_bytes, int read_ahead_option, int lead_us_option, uint32_t max_bits);
 
 // init_kernels.hip
 int launch_rowgroup_init(hipStream_t stream, const double* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order, uint64_t rg_first = 0,
@@ -110,7 +115,9 @@ int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t*
 
 
 // ---- single precision (decode_f32_kernels.hip, encode_f32_kernels.hip, init_kernels.hip, primitive_f32_kernels.hip) ----
-int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores);
+// pad_kib: unused dynamic LDS per workgroup (residency cap); progress / tag / gate: as launch_decode_column
+int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores, int pad_kib = -1, uint64_t* progress = nullptr,
+                             uint64_t progress_tag = 0, uint32_t gate = 0);
 int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
                              uint64_t rg_first = 0, uint64_t rg_count = 0);
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate = nullptr);

@@ -12,6 +12,7 @@
 // [progress + lead_min, progress + lead_max): not so far ahead that the cache has dropped the lines again, not behind the decode.  The word carries
 // the launch's tag in its top bits, so a stale value of an earlier decode reads as "not started".  Best effort by construction: a read-ahead that
 // leaves early or never runs changes nothing but the decode's speed.
+#include "decode_policy.hpp"   // the words of context memory an unhinted decode's plan arrives in
 #include "encode_lookback.hpp" // status_load, record_sizes
 #include "launch.hpp"
 
@@ -25,7 +26,10 @@ namespace alpgpu {
 constexpr int      kAheadWaves  = ALPGPU_AHEAD_WAVES; // wavefronts per read-ahead workgroup (few, fat workgroups: one lane of each polls)
 constexpr int      kAheadUnroll = 16;       // 16-byte loads in flight per lane and round (16 KiB per wavefront)
 constexpr uint64_t kAheadVecMask = (1ull << 40) - 1ull;
-constexpr uint64_t kAheadPatiencePs = 50000000000ull; // 50 ms without news from the decode before a workgroup gives up
+// Patience (round 6): how long a workgroup goes without news from the decode before it leaves.  Until round 5 a flat 50 ms — wherever
+// the two kernels cannot run side by side (one hardware queue, AMD_SERIALIZE_KERNEL, a --pmc pass, a debugger) every decode of a narrow column then cost 50 ms.  Now
+// from the column: the launcher passes the FIRST word's patience (the decode kernel is enqueued right behind this one: 200 us, or a quarter of the decode's own
+// estimated duration if that is longer) and the steady state's (twice that estimate, at least 200 us) in ticks of wall_clock64().
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
@@ -68,52 +72,78 @@ __device__ __forceinline__ uint32_t touch_span(const uint8_t* __restrict__ strea
 	return x;
 }
 
-// mode (experiments, ALPGPU_READ_AHEAD_MODE): bit 0 = pace only, read nothing; bit 1 = read without pacing; bit 2 = sleep ~1.5 ms and leave
+// mode (experiments, ALPGPU_READ_AHEAD_MODE): bit 0 = pace only, read nothing; bit 1 = read without pacing; bit 2 = sleep ~1.5 ms and leave; bit 4 = the lead stays as given
+// mode bit 3 (set by the launcher, not an experiment): the lead, the pace and the widest record come from the context's plan words (decode_policy.hpp: an UNHINTED
+// decode, whose sizes were summed on this stream a moment ago; a lead of 0 there = this column gets no read-ahead: leave)
 template <int VALUE_BYTES>
 __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_vector_desc* __restrict__ descs, const uint8_t* __restrict__ packed,
-                                                                const uint8_t* __restrict__ excs, uint64_t n_vectors, const uint64_t* __restrict__ progress,
-                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, uint32_t* __restrict__ hole, uint32_t mode) {
+                                                                const uint8_t* __restrict__ excs, uint64_t n_vectors, uint64_t* __restrict__ ctx_words,
+                                                                uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, uint32_t mode,
+                                                                uint32_t patience_first_ticks, uint32_t patience_ticks) {
 	// One workgroup = kAheadWaves consecutive batches of 64 vectors per round; ONE lane of the workgroup reads the progress word, and while the round is
 	// out of reach it does so every ~7 us only: the word lives on one memory channel, and every poll of every waiting wavefront is a trip to it.
 	__shared__ uint64_t s_seen;
 	__shared__ uint32_t s_go;
+	__shared__ uint32_t s_lead;
+	const uint64_t* progress = ctx_words + kCtxWordProgress;
+	uint32_t*       hole     = reinterpret_cast<uint32_t*>(ctx_words + kCtxWordHole);
 	const int      lane  = lane_id();
 	const int      wave  = wave_in_wg();
 	if (mode & 4u) { // experiment: resident for ~1.5 ms, touching nothing
 		for (int k = 0; k < 440; ++k) { __builtin_amdgcn_s_sleep(127); }
 		return;
 	}
+	if (mode & 8u) { // (uniform: kernel argument)
+		const uint64_t lead = ctx_words[kCtxWordLead], pace = ctx_words[kCtxWordPace];
+		lead_min = static_cast<uint32_t>(lead), lead_max = static_cast<uint32_t>(lead >> 32);
+		ps_per_vector = static_cast<uint32_t>(pace), max_bits = static_cast<uint32_t>(pace >> 32);
+		if (lead_max == 0 || ps_per_vector == 0) { return; }
+		// (patience of an unhinted launch: the launcher does not know the decode's duration either — from the pace just read)
+		const uint64_t est_ticks = n_vectors * static_cast<uint64_t>(ps_per_vector) / ps_per_tick;
+		const uint64_t floor_t   = 200000000ull / ps_per_tick; // 200 us
+		const uint64_t first = est_ticks / 4 > floor_t ? est_ticks / 4 : floor_t, steady = 2 * est_ticks > floor_t ? 2 * est_ticks : floor_t;
+		patience_first_ticks = first > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(first);
+		patience_ticks       = steady > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(steady);
+	}
 	const uint64_t round = static_cast<uint64_t>(gridDim.x) * kAheadWaves * 64;
 	uint32_t       x     = 0;
 	uint64_t       seen  = 0; // the decode's position as last read: first vector of a workgroup that has been dispatched
+	// The lead stretches itself (round 6): a workgroup whose batch was asked for with less than an eighth of the lead to spare — the decode was nearly there
+	// when the reads went out, the cliff of profiles/r05_read_ahead.txt, whose place moves from box to box — goes a quarter further ahead from its next
+	// round on, up to three times the lead it was given.  Too long a lead decays slowly, too short a one falls off: this errs to the safe side.
+	uint32_t       lead  = lead_max;
 	for (uint64_t wg_first = static_cast<uint64_t>(blockIdx.x) * kAheadWaves * 64; wg_first < n_vectors; wg_first += round) {
 		if (!(mode & 2u)) {
 			if (threadIdx.x == 0) {
-				// Sleep until the decode is lead_max vectors short of this round, by the clock: the decode advances at most one vector per ps_per_vector
+				// Sleep until the decode is lead vectors short of this round, by the clock: the decode advances at most one vector per ps_per_vector
 				// (the host's estimate at the full HBM rate, so the sleep never overshoots), 0.9 of the way per nap, one poll per nap.
 				uint32_t go      = 1;
 				uint64_t changed = wall_clock64();
 				for (;;) {
 					const uint64_t w = status_load(progress);
 					if ((w & ~kAheadVecMask) == tag && (w & kAheadVecMask) > seen) { seen = w & kAheadVecMask, changed = wall_clock64(); }
-					if (wg_first < seen + lead_max) { break; }                          // in reach
-					if (wall_clock64() - changed > kAheadPatiencePs / ps_per_tick) { go = 0; break; } // the decode is not coming (its launch failed?): leave
-					const uint64_t togo  = wg_first - (seen + lead_max) + 1;                       // vectors
+					if (wg_first < seen + lead) { break; }                          // in reach
+					if (wall_clock64() - changed > (seen == 0 ? patience_first_ticks : patience_ticks)) { go = 0; break; } // the decode is not coming (it cannot run beside this kernel, or its launch failed): leave
+					const uint64_t togo  = wg_first - (seen + lead) + 1;                       // vectors
 					uint64_t       ticks = (togo * ps_per_vector / ps_per_tick) * 9ull / 10ull;        // ticks of wall_clock64() (100 MHz on MI355X; the host asks the runtime)
 					const uint64_t t_min = 1000000ull / ps_per_tick, t_max = 200000000ull / ps_per_tick; // 1 us .. 200 us
 					ticks                = ticks < t_min ? t_min : (ticks > t_max ? t_max : ticks);
+					if (seen == 0 && ticks > patience_first_ticks / 2) { ticks = patience_first_ticks / 2 + 1; } // (before the first word: never sleep past the patience)
 					const uint64_t until = wall_clock64() + ticks;
 					while (wall_clock64() < until) { __builtin_amdgcn_s_sleep(32); }
 				}
-				s_seen = seen, s_go = go;
+				if (go && !(mode & 16u) && seen != 0 && wg_first < seen + lead - lead / 8 * 7 && lead < 3 * lead_max) { lead += lead_max / 4; } // late: less than an eighth of the lead to spare
+				s_seen = seen, s_go = go, s_lead = lead;
 			}
 			__syncthreads();
 			seen                = s_seen;
 			const uint32_t go   = s_go;
+			lead                = s_lead;
 			__syncthreads();
 			if (!go) { break; }
 			if (wg_first + kAheadWaves * 64 <= seen + lead_min) { continue; } // the decode is already there
 		}
+		if (threadIdx.x == 0) { __hip_atomic_fetch_add(ctx_words + kCtxWordBatches, static_cast<uint64_t>(kAheadWaves), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } // (debug counter; nobody waits for it)
 		const uint64_t first = wg_first + static_cast<uint64_t>(wave) * 64;
 		if (first >= n_vectors || (mode & 1u)) { continue; }
 		const uint64_t     v = first + lane;
@@ -152,18 +182,24 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 	if (x == 0x9E3779B9u && n_vectors == ~0ull) { *hole = x; } // (never: what keeps the loads)
 }
 
-// lead_min / lead_max in vectors; value_bytes 8 (double column) or 4 (float column)
-int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, const uint64_t* d_progress, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
-                      uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid) {
+// lead_min / lead_max in vectors; value_bytes 8 (double column) or 4 (float column); from_plan: lead, pace and widest record from the context's plan words
+int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_bytes, uint64_t* d_ctx_words, uint64_t tag, uint32_t lead_min, uint32_t lead_max,
+                      uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid, bool from_plan) {
 	if (col->n_vectors == 0 || grid <= 0) { return ALPGPU_OK; }
-	static const uint32_t mode = std::getenv("ALPGPU_READ_AHEAD_MODE") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_MODE"))) : 0u;
-	uint32_t* hole = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(d_progress) + 1);
+	static const uint32_t env_mode = std::getenv("ALPGPU_READ_AHEAD_MODE") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_MODE"))) : 0u;
+	static const bool     no_adapt = std::getenv("ALPGPU_READ_AHEAD_ADAPT") && std::atoi(std::getenv("ALPGPU_READ_AHEAD_ADAPT")) == 0;
+	const uint32_t mode = (env_mode & ~8u) | (from_plan ? 8u : 0u) | (no_adapt ? 16u : 0u);
+	// patience: see above.  The decode's duration at the full HBM rate (ps_per_vector), in ticks
+	const uint64_t est   = col->n_vectors * static_cast<uint64_t>(ps_per_vector) / (ps_per_tick ? ps_per_tick : 1u);
+	const uint64_t floor_t = 200000000ull / (ps_per_tick ? ps_per_tick : 1u);
+	const uint64_t first = est / 4 > floor_t ? est / 4 : floor_t, steady = 2 * est > floor_t ? 2 * est : floor_t;
+	const uint32_t pf = first > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(first), ps = steady > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(steady);
 	if (value_bytes == 8) {
 		hipLaunchKernelGGL((k_read_ahead<8>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_progress, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, hole, mode);
+		                   d_ctx_words, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, mode, pf, ps);
 	} else {
 		hipLaunchKernelGGL((k_read_ahead<4>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_progress, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, hole, mode);
+		                   d_ctx_words, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, mode, pf, ps);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

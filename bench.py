@@ -61,22 +61,28 @@ def lib_sha16() -> str:
     return hashlib.sha256(open(capi.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
-def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=None, exc_per_vec=0, first_vector: int = 0):
+def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=None, exc_per_vec=0, first_vector: int = 0, value_bytes: int = 8):
     """Synthetic ALP-encoded column in HBM (descriptors on host -> device; packed words generated on device).  exc_per_vec: one count for every
-    vector, or an array with one count per vector whose non-zero entries are all the same (the bimodal column)."""
+    vector, or an array with one count per vector whose non-zero entries are all the same (the bimodal column).  value_bytes = 4: a float column
+    (32-bit words, bit widths 0..32, 6-byte exception entries, (e, f) within the float tables)."""
     v = np.arange(n_vectors, dtype=np.uint64) + np.uint64(first_vector)  # global vector index of this shard's vectors
     rg = (v // np.uint64(100)).astype(np.int64)
-    bw = (1 + rg % 53) if bw_of_rowgroup is None else np.broadcast_to(np.asarray(bw_of_rowgroup), rg.shape)
+    bw = (1 + rg % (53 if value_bytes == 8 else 32)) if bw_of_rowgroup is None else np.broadcast_to(np.asarray(bw_of_rowgroup), rg.shape)
     bw = bw.astype(np.int64)
-    f = np.minimum(12, np.floor((62 - bw) * np.log10(2.0))).astype(np.int64)
-    f = np.maximum(f, 0)
-    e = f + 2
+    if value_bytes == 8:
+        f = np.minimum(12, np.floor((62 - bw) * np.log10(2.0))).astype(np.int64)
+        f = np.maximum(f, 0)
+        e = f + 2
+    else:  # float: 10^f * 2^bw stays inside int32, e <= 10 (Constants<float>::MAX_EXPONENT)
+        f = np.clip(np.floor((30 - bw) * np.log10(2.0)).astype(np.int64), 0, 8)
+        e = np.minimum(f + 2, 10)
     with np.errstate(over="ignore"):
-        base = (splitmix64(v + np.uint64(seed) * np.uint64(0x632BE59BD9B4E019)) % (np.uint64(1) << bw.astype(np.uint64))).astype(np.int64)
+        base = (splitmix64(v + np.uint64(seed) * np.uint64(0x632BE59BD9B4E019)) % (np.uint64(1) << np.minimum(bw, 30 if value_bytes == 4 else 63).astype(np.uint64))).astype(np.int64)
     cnt = np.broadcast_to(np.asarray(exc_per_vec, dtype=np.int64), (n_vectors,))
     c = int(cnt.max()) if n_vectors else 0
     assert ((cnt == 0) | (cnt == c)).all()
-    rec = (10 * c + 7) // 8 * 8
+    eb1 = value_bytes + 2  # bytes per exception: the value's bits + a 16-bit position
+    rec = (eb1 * c + 7) // 8 * 8
     vec = np.zeros(n_vectors, capi.VECTOR_DTYPE)
     vec["bw"], vec["e"], vec["f"], vec["base"] = bw, e, f, base
     vec["scheme"] = capi.SCHEME_ALP
@@ -89,7 +95,7 @@ def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=N
     rgs = np.zeros((n_vectors + 99) // 100, capi.ROWGROUP_DTYPE)
     rgs["scheme"] = capi.SCHEME_ALP
     rgs["k"] = 1
-    col = capi.DeviceColumn(n_vectors, device, packed_capacity=packed_bytes + 1024, exc_capacity=n_rec * rec + 64)
+    col = capi.DeviceColumn(n_vectors, device, packed_capacity=packed_bytes + 1024, exc_capacity=n_rec * rec + 64, dtype="f64" if value_bytes == 8 else "f32")
     dev = col.vectors.device
     col.vectors.copy_(torch.from_numpy(vec.view(np.uint8).reshape(-1)).to(dev))
     col.rowgroups[: rgs.size * 32] = torch.from_numpy(rgs.view(np.uint8).reshape(-1)).to(dev)
@@ -102,15 +108,15 @@ def build_decode_column(n_vectors: int, device: int, seed: int, bw_of_rowgroup=N
     if c:
         rng = np.random.default_rng(seed)
         one = np.zeros(rec, np.uint8)
-        one[: 8 * c] = rng.integers(0, 255, 8 * c)
-        one[8 * c: 10 * c] = np.sort(rng.choice(1024, c, replace=False)).astype(np.uint16).view(np.uint8)
+        one[: value_bytes * c] = rng.integers(0, 255, value_bytes * c)
+        one[value_bytes * c: eb1 * c] = np.sort(rng.choice(1024, c, replace=False)).astype(np.uint16).view(np.uint8)
         col.exc[: n_rec * rec] = torch.from_numpy(one).to(dev).repeat(n_rec)
     col.totals[0] = packed_bytes
     col.totals[1] = n_rec * rec
     col.c.packed_bytes_hint, col.c.exc_bytes_hint = packed_bytes, n_rec * rec  # what alpgpu_column_totals would report
     col.c.alp_rd_rowgroups_hint = 1  # ... "no ALP_RD rowgroup" (informational)
-    # algorithmic bytes per launch: read 128*bw + 10*exc + 13, write 8192, per vector
-    alg_bytes = int((128 * bw + 10 * cnt + 13 + 8192).sum())
+    # algorithmic bytes per launch: read 128*bw + (8 + 2)*exc + 13, write 8192, per vector (float: 6 bytes per exception, 4096 written)
+    alg_bytes = int((128 * bw + eb1 * cnt + 13 + 1024 * value_bytes).sum())
     return col, vec, alg_bytes
 
 

@@ -149,8 +149,9 @@ int         alpgpu_use_own_stream(alpgpu_ctx* ctx);
 int         alpgpu_synchronize(alpgpu_ctx* ctx);
 /* tuning knobs (never change results).  ALPGPU_OPT_DECODE_VECTORS_PER_WG: 1 or 2 consecutive vectors per decode
  * workgroup, or 0 (default) = choose from the column's size hints: 2 keeps twice the bytes in flight and is faster for
- * narrow columns (average packed width <= 17 bits; <= 20 bits when there are about two or more exceptions per vector that go through the mask: crossovers
- * re-measured at one-bit resolution in round 4), 1 for wider ones — every ALP_RD column — and when no hint is present.
+ * narrow columns (average packed width <= 17 bits; <= 22 bits when there are about two or more exceptions per vector: crossovers
+ * re-measured at one-bit resolution in rounds 4 and 5), 1 for wider ones — every ALP_RD column.  A column without size hints: ALPGPU_OPT_DECODE_UNHINTED.
+ * Float columns: 1, 2 or 4; 0 = 2, and 4 for columns of narrow vectors whose sizes are known (round 6).
  * 4 (double columns; round 4) = four vectors per workgroup over a 2.25 KiB stage, vectors wider than 17 bits read straight from HBM:
  * built to lift the narrow widths' floor, measured SLOWER than 2 at every width (profiles/r04_decode_floor.txt), never chosen by 0.
  * ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
@@ -217,12 +218,15 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * resident per CU (160 KiB / (its own 9.6 or 19.3 KiB + this)); -1 (default) = chosen from the column's size hints (what a CU wants
  * is an amount of bytes in flight).  Never changes results. */
 #define ALPGPU_OPT_DECODE_RESIDENCY_PAD 11
-/* ALPGPU_OPT_DECODE_READ_AHEAD (double store decode; round 5): alpgpu_decode_f64 starts a READ-AHEAD beside the decode kernel — a few persistent workgroups
+/* ALPGPU_OPT_DECODE_READ_AHEAD (store decode, double since round 5, float since round 6): alpgpu_decode_f64 / _f32 start a READ-AHEAD beside the decode kernel — a few persistent workgroups
  * on the context's second stream that pull descriptors, packed words and exception records into the Infinity Cache ALPGPU_OPT_DECODE_READ_AHEAD_US
  * microseconds (default 0 = by the vectors' width: 18 us at 1 bit .. 60 us from 8 bits on) ahead of the decode kernel, which tells them where it is; the decode's two dependent reads then hit the cache.
  *   -1 (default)  columns of >= 262144 vectors of at most 6 packed bits per value on average (7 when they have exceptions) whose size hints are set (+3-24 % there; wider columns lose);
  *    0            never;   1  every column of >= 32768 vectors whose size hints are set (measurements).
- * Same output bytes.  The two kernels are joined on the context's stream: work enqueued behind alpgpu_decode_f64 waits for both. */
+ * Same output bytes.  The two kernels are joined on the context's stream: work enqueued behind alpgpu_decode_f64 waits for both.
+ * Where kernels of two streams cannot run side by side (GPU_MAX_HW_QUEUES=1, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, a counter-collection pass) the read-ahead
+ * leaves when no word from the decode arrives (round 6: within max(200 us, a quarter of the decode's own estimated duration); until round 5 a flat 50 ms), and a context
+ * created with one of those three variables set does not start it on its own (-1 behaves as 0).  One context runs ONE store decode at a time (one progress word). */
 #define ALPGPU_OPT_DECODE_READ_AHEAD 12
 #define ALPGPU_OPT_DECODE_READ_AHEAD_US 13
 /* ALPGPU_OPT_DECODE_SEGMENTS (double store decode; round 5; default 1): alpgpu_column_totals and alpgpu_column_from_blob remember, in the context, the sizes of up to 32
@@ -230,14 +234,31 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * and decodes run by run, each with the launch shape (and read-ahead) its own sizes call for — a column whose regions differ is no longer decoded in the shape of its average.
  * Columns of one kind, columns without the call, forced launch shapes: one launch, as before.  0 = never.  alpgpu_decode_runs tells.  Same bytes. */
 #define ALPGPU_OPT_DECODE_SEGMENTS 14
+/* ALPGPU_OPT_DECODE_UNHINTED (round 6; default 1): a column of >= 65536 vectors whose packed_bytes_hint and exc_bytes_hint are both 0 — encoded a moment ago, nobody called
+ * alpgpu_column_totals (a host synchronisation) — is not decoded in the slowest shape any more: its sizes are summed on the stream, the launch rule is evaluated on the
+ * DEVICE and every candidate shape is launched gated on its answer (closed candidates cost their dispatch), with the read-ahead taking its lead and pace from the same
+ * device words.  The sums also travel to page-locked host memory behind an event that is only queried: the next alpgpu_decode_* of the same column (same buffers and
+ * length, not encoded again through this context in between) is planned on the host like a hinted one.  No host synchronisation anywhere.  0 = one vector per
+ * workgroup (float: two), no read-ahead, as before.  Same bytes. */
+#define ALPGPU_OPT_DECODE_UNHINTED 15
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */
 int         alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
 /* ... and whether that decode would run with the read-ahead beside it (ALPGPU_OPT_DECODE_READ_AHEAD): 1 / 0; negative on bad arguments */
 int         alpgpu_decode_reads_ahead(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32);
-/* ... and in how many launches alpgpu_decode_f64 would decode it (ALPGPU_OPT_DECODE_SEGMENTS): 1, or the number of runs; negative on bad arguments */
+/* ... and in how many launches alpgpu_decode_f64 (alpgpu_decode_runs_f32: alpgpu_decode_f32) would decode it (ALPGPU_OPT_DECODE_SEGMENTS): 1, or the number of runs; negative
+ * on bad arguments.  The three functions above describe the plan of a column whose sizes the host knows, for the column as a WHOLE: a column decoded in several runs gets
+ * a shape per run (alpgpu_decode_runs > 1), an unhinted one the shape its device-side plan picks (alpgpu_debug_unhinted_plan). */
 int         alpgpu_decode_runs(alpgpu_ctx* ctx, const alpgpu_column* col);
+int         alpgpu_decode_runs_f32(alpgpu_ctx* ctx, const alpgpu_column* col);
+/* debug aids (tests; both wait for the context's streams): batches of 64 vectors this context's read-aheads have read since it was created; and the plan of its last
+ * unhinted decode: out6[0] the candidate that ran (double: 1 = one vector per workgroup, 2 = two, 3 = one with seven workgroups per CU; float: 1 = two, 2 = four),
+ * [1] read-ahead lead_min | lead_max << 32 in vectors (0: none), [2] picoseconds per vector | widest record read ahead << 32, [3..5] packed bytes, exceptions, ALP_RD vectors */
+int         alpgpu_debug_read_ahead_batches(alpgpu_ctx* ctx, uint64_t* batches);
+int         alpgpu_debug_unhinted_plan(alpgpu_ctx* ctx, uint64_t* out6);
+/* ... and: forget what the context remembers about this column (its segments, what an unhinted decode learned), as every alpgpu_encode_* into it does */
+int         alpgpu_debug_forget_column(alpgpu_ctx* ctx, const alpgpu_column* col);
 /* ---- host-resident columns -----------------------------------------------------------------------------------------------
  * The reference's callers (publication/source_code/bench_compression_ratio/alp.cpp:198-229) hold the column and what they
  * compress it into in host memory.  These entry points take it from there: n_values values at h_in (the last vector may be

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # entry points that by design do not touch the device (documented in include/alpgpu.h) or only read host-side fields of the context
-HOST_ONLY = {"alpgpu_set_stream", "alpgpu_use_own_stream", "alpgpu_set_option", "alpgpu_decode_vectors_per_wg", "alpgpu_decode_reads_ahead", "alpgpu_decode_runs", "alpgpu_device_info"}
+HOST_ONLY = {"alpgpu_set_stream", "alpgpu_use_own_stream", "alpgpu_set_option", "alpgpu_decode_vectors_per_wg", "alpgpu_decode_reads_ahead", "alpgpu_decode_runs", "alpgpu_decode_runs_f32", "alpgpu_device_info"}
 
 
 def functions(text):

@@ -1,0 +1,24 @@
+#!/bin/bash
+# r06_call.sh <step>: ONE gpurun call of round 6 (every step under its own wall-clock guard; logs under gpurun_out/r06/<step>/).
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/r06_call.sh 1'
+step=$1
+out=gpurun_out/r06/$step
+mkdir -p $out
+run() { # seconds, log, command...
+  t=$1; log=$2; shift 2
+  echo "== $* (limit ${t}s)" | tee -a $out/$log
+  timeout $t "$@" >> $out/$log 2>&1
+  echo "== rc $?" | tee -a $out/$log
+}
+case $step in
+1) # first look: the whole GPU suite on the split library + round 6's decode policy; the float sweep; what an unhinted decode costs; the self-stretching lead
+  run 600 tests.txt python -m pytest tests -m gpu -x -q
+  run 400 f32_sweep.txt python tools/sweep_f32_decode.py
+  run 200 unhinted.txt python tools/time_unhinted.py
+  ALPGPU_READ_AHEAD_ADAPT=0 run 120 adapt_off.txt python tools/time_read_ahead.py
+  ALPGPU_READ_AHEAD_ADAPT=1 run 120 adapt_on.txt python tools/time_read_ahead.py
+  run 300 bench.txt python bench.py
+  ;;
+*) echo "unknown step $step";;
+esac
+tail -n 40 $out/*.txt | cut -c1-400
