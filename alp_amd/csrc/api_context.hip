@@ -131,6 +131,32 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 		const char* q   = std::getenv("GPU_MAX_HW_QUEUES");
 		ctx->streams_serialize = ((ser && std::atoi(ser) != 0) || (blk && std::atoi(blk) != 0) || (q && std::atoi(q) == 1)) ? 1 : 0;
 	}
+	ctx->read_ahead_bits = std::getenv("ALPGPU_READ_AHEAD_BITS") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_BITS")) : 128;
+	ctx->d_progress      = nullptr;
+	ctx->progress_gen    = 0;
+	{
+		int khz = 0;
+		if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { khz = 100000; } // 100 MHz: gfx9's s_memrealtime
+		ctx->wall_tick_ps = static_cast<uint32_t>(1000000000ll / khz);
+		if (ctx->wall_tick_ps == 0) { ctx->wall_tick_ps = 1; }
+	}
+	ctx->workspace       = nullptr;
+	ctx->workspace_bytes = 0;
+	ctx->ws_stream       = nullptr;
+	ctx->ws_busy         = 0;
+	if (hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) {
+		(void)hipStreamDestroy(ctx->own_stream);
+		delete ctx;
+		return fail(ALPGPU_ERR_HIP, "hipEventCreate failed");
+	}
+	if (hipMalloc(reinterpret_cast<void**>(&ctx->d_progress), 2048) != hipSuccess || hipMemset(ctx->d_progress, 0, 2048) != hipSuccess) {
+		if (ctx->d_progress) { (void)hipFree(ctx->d_progress); }
+		(void)hipEventDestroy(ctx->ws_event);
+		(void)hipStreamDestroy(ctx->init_stream);
+		(void)hipStreamDestroy(ctx->own_stream);
+		delete ctx;
+		return fail(ALPGPU_ERR_HIP, "hipMalloc of the context's progress word failed");
+	}
 	// what unhinted decodes learn about their columns (api_decode.hip): page-locked words + one event per slot; without them such columns simply stay unhinted
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_learn), sizeof(uint64_t) * kLearnSlots * 3 * kMaxSegments, hipHostMallocDefault) != hipSuccess) {
 		(void)hipGetLastError();
