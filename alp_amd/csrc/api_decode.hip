@@ -102,7 +102,8 @@ static int decode_shape_f32(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 	int vpw = ctx->decode_vpw ? ctx->decode_vpw : 2;
 	if (ctx->decode_vpw == 0 && ctx->decode_auto && col->packed_bytes_hint != 0 && col->n_vectors != 0) {
 		const double bits = static_cast<double>(col->packed_bytes_hint) / (128.0 * static_cast<double>(col->n_vectors));
-		if (bits <= (column_decodes_with_exceptions(ctx, col) ? alpgpu::kFourVectorsBitsExcF32 : alpgpu::kFourVectorsBitsF32)) { vpw = 4; }
+		const double four = column_decodes_with_exceptions(ctx, col) ? alpgpu::kFourVectorsBitsExcF32 : alpgpu::kFourVectorsBitsF32; // (0: never — decode_policy.hpp)
+		if (four > 0.0 && bits <= four) { vpw = 4; }
 	}
 	return vpw | ((ctx->decode_pad_kib >= 0 ? ctx->decode_pad_kib : 0xFF) << 8);
 }
@@ -361,12 +362,12 @@ static int decode_one(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 
 // ---- a column whose sizes the host does not know (round 6) ------------------------------------------------------------------------
 // alpgpu_encode_* leaves the stream sizes in device memory; the host learns them from alpgpu_column_totals, a synchronisation.  A caller that encodes and
-// decodes without it used to get the slowest shape (one vector per workgroup, no read-ahead: 0.51-0.58 on 2-6-bit vectors).  Now, for columns of at least
-// kUnhintedMinVectors vectors: the per-segment sums are taken on the stream (k_segment_sums, 17 us per 1 Mi vectors), k_unhinted_plan evaluates the rule on the
-// device (decode_policy.hpp) and EVERY candidate shape is launched, gated on the plan's word — closed candidates cost their dispatch only — with the read-ahead
-// beside them taking its lead and pace from the same words.  The sums also travel to page-locked host memory behind an event nobody waits for: the NEXT decode
-// of the same column (same descriptor and packed buffers, same length, not encoded again in between) finds them there and is planned on the host like a
-// hinted one, region by region included.  ALPGPU_OPT_DECODE_UNHINTED = 0: the old behaviour.
+// decodes without it used to get one vector per workgroup and no read-ahead (0.50 on 4-bit vectors where the hinted decode reaches 0.72-0.76).  Now, for columns of
+// at least kUnhintedMinVectors vectors: the per-segment sums are taken on the stream (k_segment_sums, 17 us per 1 Mi vectors), k_unhinted_plan evaluates the rule on
+// the device (decode_policy.hpp) and the read-ahead beside the decode takes its lead and pace — or "not for this column" — from the plan's words.  The sums also
+// travel to page-locked host memory behind an event nobody waits for: the NEXT decode of the same column (same descriptor and packed buffers, same length, not
+// encoded again in between) finds them there and is planned on the host like a hinted one, launch shape and regions included (call 1b: 1.00-1.05 of the hinted
+// figure from the second decode on).  The launch shape of the FIRST decode: see decode_unhinted.  ALPGPU_OPT_DECODE_UNHINTED = 0: the old behaviour.
 constexpr uint64_t kUnhintedMinVectors = 65536;
 
 static LearnSlot* learn_slot_of(alpgpu_ctx* ctx, const alpgpu_column* col, int value_bytes) {
@@ -440,16 +441,21 @@ static int decode_unhinted(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_ou
 	}
 	const bool plain = (ctx->decode_variant & 2) != 0;
 	int        rc    = ALPGPU_OK;
+	// Which launch.  A closed candidate is not free: the dispatcher hands out ~5.5 workgroups per nanosecond, so 1 Mi empty workgroups cost 0.19 ms — 10-17 % of a
+	// decode (call 1b: first unhinted decode 0.59-0.68 of peak against 0.72-0.81 hinted with all three candidates launched).  Default (1) therefore: ONE launch in the
+	// shape a column without hints always got (double: one vector per workgroup, 6 KiB pad; float: two), un-gated, and the device-side plan steers the read-ahead only —
+	// which is what narrow columns gain most from — while the sizes travel to the host for the next decode.  2: every candidate, gated (the measured alternative).
 	if constexpr (VB == 8) { // decode_policy.hpp: 1 = one vector per workgroup + 6 KiB, 2 = two per workgroup, 3 = one per workgroup + 11 KiB
-		const int variants[alpgpu::kUnhintedShapesF64] = {1 | (6 << 8), 0, 1 | (11 << 8)};
-		for (int c = 0; c < alpgpu::kUnhintedShapesF64 && rc == ALPGPU_OK; ++c) {
-			rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), variants[c] | (plain ? 2 : 0), ctx->n_cus, 0u, words, tag, static_cast<uint32_t>(c + 1));
+		if (ctx->decode_unhinted == 2) {
+			const int variants[alpgpu::kUnhintedShapesF64] = {1 | (6 << 8), 0, 1 | (11 << 8)};
+			for (int c = 0; c < alpgpu::kUnhintedShapesF64 && rc == ALPGPU_OK; ++c) {
+				rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), variants[c] | (plain ? 2 : 0), ctx->n_cus, 0u, words, tag, static_cast<uint32_t>(c + 1));
+			}
+		} else {
+			rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), 1 | (6 << 8) | (plain ? 2 : 0), ctx->n_cus, 0u, words, tag, 0u);
 		}
-	} else { // 1 = two vectors per workgroup, 2 = four
-		const int vpw[alpgpu::kUnhintedShapesF32] = {2, 4};
-		for (int c = 0; c < alpgpu::kUnhintedShapesF32 && rc == ALPGPU_OK; ++c) {
-			rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), vpw[c], plain, 0, words, tag, static_cast<uint32_t>(c + 1));
-		}
+	} else {
+		rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), 2, plain, 0, words, tag, 0u);
 	}
 	if (with_ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }

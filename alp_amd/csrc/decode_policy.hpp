@@ -27,17 +27,20 @@ constexpr uint64_t kReadAheadVectors = 262144; // shorter columns: the cold star
 constexpr double   kTwoVectorsBits    = 17.5;  // two vectors per workgroup up to here without exceptions ...
 constexpr double   kTwoVectorsBitsExc = 22.0;  // ... and with (about two or more per vector)
 // ---- float columns (a vector is 4 KiB; two per workgroup are the bytes in flight of one double vector): tools/sweep_f32_decode.py, profiles/r06_float_decode.txt ----
+// Measured (call 1b, 1 Mi float vectors, fractions of 8 TB/s): cold, two vectors per workgroup are ahead of one at every width and of four wherever there are exceptions; without
+// exceptions four are 1-2 points ahead at 6-14 bits only (and at 1 bit): not worth a rule — always two.  The read-ahead lifts 2-7-bit columns from 0.49-0.60 to
+// 0.60-0.63 (with exceptions 0.44-0.54 -> 0.51-0.54) and loses from 8 bits on and at 1 bit; leads of ~20 us beat the double rule's 30-50.
 #ifndef ALPGPU_F32_READ_AHEAD_BITS
-#define ALPGPU_F32_READ_AHEAD_BITS 4.5
+#define ALPGPU_F32_READ_AHEAD_BITS 7.5
 #endif
 #ifndef ALPGPU_F32_READ_AHEAD_BITS_EXC
-#define ALPGPU_F32_READ_AHEAD_BITS_EXC 5.5
+#define ALPGPU_F32_READ_AHEAD_BITS_EXC 7.5
 #endif
 #ifndef ALPGPU_F32_FOUR_VECTORS_BITS
-#define ALPGPU_F32_FOUR_VECTORS_BITS 8.5
+#define ALPGPU_F32_FOUR_VECTORS_BITS 0.0
 #endif
 #ifndef ALPGPU_F32_FOUR_VECTORS_BITS_EXC
-#define ALPGPU_F32_FOUR_VECTORS_BITS_EXC 10.5
+#define ALPGPU_F32_FOUR_VECTORS_BITS_EXC 0.0
 #endif
 constexpr double kReadAheadBitsF32     = ALPGPU_F32_READ_AHEAD_BITS;
 constexpr double kReadAheadBitsExcF32  = ALPGPU_F32_READ_AHEAD_BITS_EXC;
@@ -50,7 +53,8 @@ __host__ __device__ inline bool policy_with_exceptions(double n_vectors, double 
 // the read-ahead on its own (ALPGPU_OPT_DECODE_READ_AHEAD = -1): long columns of narrow vectors only
 __host__ __device__ inline bool policy_read_ahead_auto(uint64_t n_vectors, double packed_bytes, bool with_exc, int value_bytes) {
 	const double limit = value_bytes == 8 ? (with_exc ? kReadAheadBitsExc : kReadAheadBits) : (with_exc ? kReadAheadBitsExcF32 : kReadAheadBitsF32);
-	return n_vectors >= kReadAheadVectors && packed_bytes <= limit * 128.0 * static_cast<double>(n_vectors);
+	const double least = value_bytes == 8 ? 0.0 : 1.5; // (float columns of 1-bit vectors: 0.75 cold, 0.72 with the second stream of reads)
+	return n_vectors >= kReadAheadVectors && packed_bytes <= limit * 128.0 * static_cast<double>(n_vectors) && packed_bytes >= least * 128.0 * static_cast<double>(n_vectors);
 }
 
 // The read-ahead's pace and lead.  The lead is a TIME: what the read-ahead brings into the Infinity Cache stays there for some tens of microseconds only (the
@@ -66,7 +70,7 @@ __host__ __device__ inline ReadAheadPace policy_read_ahead_pace(double n_vectors
 	const double per_vec   = (packed_bytes + exc_bytes) / n_vectors + 32.0;
 	const double ps_vec    = (out_bytes + per_vec) / 8.0; // picoseconds per vector at 8 TB/s: an upper bound of the decode's rate (the read-ahead's naps by it never overshoot)
 	const double bits      = packed_bytes / (128.0 * n_vectors);
-	const double by_width  = 12.0 + 6.5 * bits;
+	const double by_width  = value_bytes == 8 ? 12.0 + 6.5 * bits : 12.0 + 3.0 * bits; // (float columns: ~20 us at 3-6 bits, call 1b)
 	const double lead_us   = lead_us_option > 0 ? static_cast<double>(lead_us_option) : (by_width > 60.0 ? 60.0 : by_width);
 	const double lead      = lead_us * 1.0e6 / ps_vec * 0.78;
 	ReadAheadPace p;
@@ -79,9 +83,9 @@ __host__ __device__ inline ReadAheadPace policy_read_ahead_pace(double n_vectors
 // ---- the unhinted decode's candidate launches (api_decode.hip launches all of them; k_unhinted_plan says which one runs) ----
 // double: 1 = one vector per workgroup, 6 KiB pad (up to ~38 bits); 2 = two vectors per workgroup (narrow vectors); 3 = one per workgroup, 11 KiB pad
 //         (seven workgroups per CU: vectors of 38 bits and more, ALP_RD columns)
-// float : 1 = two vectors per workgroup; 2 = four (narrow vectors)
+// float : 1 = two vectors per workgroup (the only shape the rule uses: four never pay, see above)
 constexpr int kUnhintedShapesF64 = 3;
-constexpr int kUnhintedShapesF32 = 2;
+constexpr int kUnhintedShapesF32 = 1;
 struct UnhintedChoice {
 	int  shape; // 1-based
 	bool ahead;
@@ -99,7 +103,7 @@ __host__ __device__ inline UnhintedChoice policy_unhinted(uint64_t n_vectors, do
 		c.shape           = narrow ? 2 : ((rd || bits >= 38.0) ? 3 : 1);
 		if (read_ahead_option < 0 && c.ahead && !with_exc) { c.shape = 1; } // under the read-ahead one vector per workgroup is the best shape without exceptions
 	} else {
-		c.shape = bits <= (with_exc ? kFourVectorsBitsExcF32 : kFourVectorsBitsF32) ? 2 : 1;
+		c.shape = 1;
 	}
 	return c;
 }

@@ -20,6 +20,7 @@
 #include "encode_device.hpp"
 #include "encode_lookback.hpp"
 #include "launch.hpp"
+#include "search_device.hpp"
 
 namespace alpgpu {
 
@@ -367,12 +368,25 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 // writes, descriptor for descriptor; only WHERE a tile's bytes lie in the two streams follows the order in which tiles finished their analysis
 // instead of vector order (the eight vectors of a tile stay together, in order).  A decoder never notices: descriptors carry offsets.
 // (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
-template <bool UNORDERED>
+// ---- the rowgroup search as work items of the tiles themselves (round 6; SEARCH = 1) ------------------------------------------------
+// Beside the encode the persistent search kernel holds one of a CU's three tile slots for two thirds of the encode's time (~0.30 ms of 3.0 exposed), while every
+// tile's worker wavefronts sit parked for ~2.6 us of their ~14 us waiting for the ordered offset.  The (e, f) walk — 27 items per rowgroup: (sampled vector, round of
+// 64 candidates) over 32 samples, ~1.2 us of one wavefront each — is what the search's time goes to (0.57 of 0.58 ms on ALP columns).  With SEARCH the tiles run those
+// items themselves, between "sizes published" and "offset needed": the global tile t = 25 B + j (25 tiles = 200 vectors = two rowgroups) works on rowgroups
+// 2 B + kTileSearchAhead and + 1: wavefronts 1 and 2 of tile j take items 2 j and 2 j + 1, wavefront 3 of tiles 0..3 items 50..53.  An item's samples (one 8-byte
+// load per lane, issued behind the size publication so that the pack covers the trip) are walked as v_readlane broadcasts, the candidate's multipliers come from two
+// 19-entry tables held one entry per lane (ds_bpermute), its key — (size << 8 | candidate) + 1 in 21 bits, all-ones for "no candidate" — is ADDED into the field of
+// its round in the sampled vector's word (three fields per 64-bit word, zero at launch): one fire-and-forget atomic, nobody waits for it.
+constexpr uint32_t kTileSearchAhead = 256; // rowgroups between an item's tile and its rowgroup (= the head the search kernel does in front: api_encode.hip)
+constexpr int      kTileSearchWordsPerRg = 16; // 9 used: one per sampled vector
+
+template <bool UNORDERED, int SEARCH = 0>
 __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_lean(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                                     alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
                                                                                     uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
                                                                                     uint64_t packed_capacity_entry, uint64_t exc_capacity_entry, uint64_t v_first, uint64_t n_vectors_launch,
-                                                                                    const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states) {
+                                                                                    const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states,
+                                                                                    uint64_t column_vectors, unsigned long long* __restrict__ search_words) {
 	__builtin_amdgcn_s_setprio(ALPGPU_ENC_PRIO);
 #ifdef ALPGPU_LEAN_LATE_ARGS
 	(void)descs_entry, (void)packed_entry, (void)excs_entry, (void)packed_capacity_entry, (void)exc_capacity_entry;
@@ -529,6 +543,42 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	}
 	const uint64_t base_p = totals[0], base_e = totals[1];
 
+	// SEARCH: this wavefront's item, if any — its samples and the two tables are asked for HERE (the pack and the record below cover the trip)
+	bool     has_item = false;
+	int      item_round = 0;
+	uint64_t item_word = 0; // index into search_words
+	double   item_smp = 0.0, item_tab_e = 0.0, item_tab_f = 0.0;
+	uint32_t item_ef = 0;
+	if constexpr (SEARCH != 0) {
+		if (wave >= 1 && wave <= 3) { // wave-uniform
+			const uint64_t gtile = (v_first >> 3) + tile; // (launches begin on multiples of 8 vectors)
+			const uint64_t blk   = gtile / 25u;
+			const int      j     = static_cast<int>(gtile - blk * 25u);
+			const int      item  = wave == 1 ? 2 * j : (wave == 2 ? 2 * j + 1 : (j < 4 ? 50 + j : -1));
+			if (item >= 0) {
+				const uint64_t rg_i  = 2 * blk + kTileSearchAhead + static_cast<uint64_t>(item / 27);
+				const int      q     = item % 27;
+				const int      sv    = q / 3;
+				const uint64_t rg_v0 = rg_i * kRowgroup;
+				if (rg_v0 < column_vectors) {
+					const uint64_t nv   = column_vectors - rg_v0 < kRowgroup ? column_vectors - rg_v0 : kRowgroup;
+					const int      n_sv = static_cast<int>((nv + 11) / 12);
+					if (sv < n_sv) {
+						has_item   = true;
+						item_round = q - 3 * sv;
+						item_word  = rg_i * kTileSearchWordsPerRg + static_cast<uint64_t>(sv);
+						item_smp   = in[(rg_v0 + 12ull * sv) * kVec + 32ull * (lane & 31)];
+						item_tab_e = kExpArr[lane < 24 ? lane : 23];
+						item_tab_f = kFracArr[lane < 21 ? lane : 20];
+						const int c = lane + 64 * item_round;
+						const int ci = c < PrecF64::kNumCombos ? c : PrecF64::kNumCombos - 1;
+						item_ef    = static_cast<uint32_t>(kCombos64.e[ci]) | (static_cast<uint32_t>(kCombos64.f[ci]) << 8);
+					}
+				}
+			}
+		}
+	}
+
 	ALPGPU_LEAN_STOP(5, base_p + base_e + my_p + my_e);
 	LookbackFirst look_first {0, 0};
 	(void)look_first;
@@ -590,6 +640,42 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	}
 
 	ALPGPU_LEAN_STOP(7, buf[lane] + buf[600 + lane] + base_p);
+	// ---- SEARCH: the item, in what would be this wavefront's wait for the tile's offset ----
+	bool reload_x = false;
+	if constexpr (SEARCH != 0) {
+		if (has_item) { // wave-uniform
+			const int e = static_cast<int>(item_ef & 0xFFu), f = static_cast<int>(item_ef >> 8);
+			PrecF64::Coef k;
+			k.exp10         = __shfl(item_tab_e, e);
+			k.frac_f        = __shfl(item_tab_f, f);
+			k.frac_e        = __shfl(item_tab_f, e);
+			k.fact_d        = __shfl(item_tab_e, f); // 10^f <= 10^18: exact
+			k.sentinel_from = f == 0 ? kUpperLimit : __builtin_inf();
+			k.fact          = kFactArr[f]; // (read by the rare literal arm only)
+			PrecF64::Acc acc;
+			PrecF64::start(acc);
+#pragma unroll 1
+			for (int s0 = 0; s0 < 32; s0 += 4) {
+				PrecF64::step(acc, readlane_f64(item_smp, s0), k);
+				PrecF64::step(acc, readlane_f64(item_smp, s0 + 1), k);
+				PrecF64::step(acc, readlane_f64(item_smp, s0 + 2), k);
+				PrecF64::step(acc, readlane_f64(item_smp, s0 + 3), k);
+			}
+			PrecF64::finish(acc);
+			uint32_t key = 0xFFFFFFFFu;
+			if (lane + 64 * item_round < PrecF64::kNumCombos && acc.non_exc >= 2) { // encoder.hpp:182
+				const uint32_t size = 32u * static_cast<uint32_t>(PrecF64::bits(acc.mx, acc.mn)) + static_cast<uint32_t>(32 - acc.non_exc) * (PrecF64::kExcBits + 16u);
+				key                 = (size << 8) | static_cast<uint32_t>(lane + 64 * item_round);
+			}
+			key = wave_min_u32(key);
+			if (lane == 0) {
+				const unsigned long long field = key == 0xFFFFFFFFu ? 0x1FFFFFull : static_cast<unsigned long long>(key) + 1ull;
+				__hip_atomic_fetch_add(search_words + item_word, field << (21 * item_round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			reload_x = true;
+		}
+	}
+
 	// ---- the ordered offset ----
 	// Wavefront 0 finds the tile's offset; the others have nothing left to do but their stores, so they PARK at a workgroup barrier until it
 	// arrives there too (k_encode_fused keeps its workers spinning on an LDS word: they used to pack meanwhile; here a spinning worker would
@@ -683,7 +769,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		// The input is still in the registers of wavefronts 1..7, which only slept on an LDS word meanwhile; wavefront 0 ran the look-back, whose
 		// registers the input would not fit beside (the budget of three tiles per CU): it reads its vector again (an L2 / Infinity-Cache hit).
 		VecIn xb = x;
-		if (wave == 0) { xb = load_vector(in, v, lane); }
+		if (wave == 0 || reload_x) { xb = load_vector(in, v, lane); } // (a wavefront that ran a search item gave its input's registers to it)
 		wave_lds_sync();
 		const int words_b = bw - kLeanImageWords;
 		if (alp) {
@@ -704,15 +790,19 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 }
 
 // the same launch sequence as launch_encode_fused_range (encode_kernels.hip) with the kernel above
+// search_words != nullptr: the tiles run the rowgroup search's (e, f) walk as work items in their look-back wait (SEARCH = 1); column_vectors = the whole column's
 void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
-                          uint32_t spin_limit, uint32_t async_states, bool unordered) {
-	if (unordered) {
-		hipLaunchKernelGGL(k_encode_lean<true>, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
-		                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
+                          uint32_t spin_limit, uint32_t async_states, bool unordered, uint64_t column_vectors, uint64_t* search_words) {
+	unsigned long long* sw = reinterpret_cast<unsigned long long*>(search_words);
+#define ALPGPU_LAUNCH_LEAN(U, S)                                                                                                                                            \
+	hipLaunchKernelGGL((k_encode_lean<U, S>), dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, \
+	                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states, column_vectors, sw)
+	if (sw != nullptr) {
+		if (unordered) { ALPGPU_LAUNCH_LEAN(true, 1); } else { ALPGPU_LAUNCH_LEAN(false, 1); }
 	} else {
-		hipLaunchKernelGGL(k_encode_lean<false>, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
-		                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
+		if (unordered) { ALPGPU_LAUNCH_LEAN(true, 0); } else { ALPGPU_LAUNCH_LEAN(false, 0); }
 	}
+#undef ALPGPU_LAUNCH_LEAN
 }
 
 } // namespace alpgpu

@@ -187,7 +187,9 @@ int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_by
                       uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, int grid, bool from_plan) {
 	if (col->n_vectors == 0 || grid <= 0) { return ALPGPU_OK; }
 	static const uint32_t env_mode = std::getenv("ALPGPU_READ_AHEAD_MODE") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_MODE"))) : 0u;
-	static const bool     no_adapt = std::getenv("ALPGPU_READ_AHEAD_ADAPT") && std::atoi(std::getenv("ALPGPU_READ_AHEAD_ADAPT")) == 0;
+	// (the self-stretching lead: built, measured — call 1b: +4-5 points where the lead is 20-30 % short, nothing where it is half, -1.5 % at the shipped lead on columns with
+	//  exceptions — and OFF unless ALPGPU_READ_AHEAD_ADAPT=1: profiles/r06_decode_policy.txt)
+	static const bool     no_adapt = !(std::getenv("ALPGPU_READ_AHEAD_ADAPT") && std::atoi(std::getenv("ALPGPU_READ_AHEAD_ADAPT")) != 0);
 	const uint32_t mode = (env_mode & ~8u) | (from_plan ? 8u : 0u) | (no_adapt ? 16u : 0u);
 	// patience: see above.  The decode's duration at the full HBM rate (ps_per_vector), in ticks
 	const uint64_t est   = col->n_vectors * static_cast<uint64_t>(ps_per_vector) / (ps_per_tick ? ps_per_tick : 1u);

@@ -235,12 +235,20 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * Columns of one kind, columns without the call, forced launch shapes: one launch, as before.  0 = never.  alpgpu_decode_runs tells.  Same bytes. */
 #define ALPGPU_OPT_DECODE_SEGMENTS 14
 /* ALPGPU_OPT_DECODE_UNHINTED (round 6; default 1): a column of >= 65536 vectors whose packed_bytes_hint and exc_bytes_hint are both 0 — encoded a moment ago, nobody called
- * alpgpu_column_totals (a host synchronisation) — is not decoded in the slowest shape any more: its sizes are summed on the stream, the launch rule is evaluated on the
- * DEVICE and every candidate shape is launched gated on its answer (closed candidates cost their dispatch), with the read-ahead taking its lead and pace from the same
- * device words.  The sums also travel to page-locked host memory behind an event that is only queried: the next alpgpu_decode_* of the same column (same buffers and
- * length, not encoded again through this context in between) is planned on the host like a hinted one.  No host synchronisation anywhere.  0 = one vector per
- * workgroup (float: two), no read-ahead, as before.  Same bytes. */
+ * alpgpu_column_totals (a host synchronisation) — no longer decodes blind: its sizes are summed on the stream and the launch rule is evaluated on the DEVICE.
+ *   1  the decode kernel is launched in the shape such a column always got (one vector per workgroup; float: two) and the read-ahead beside it takes "whether", its lead
+ *      and its pace from the device-side plan (long narrow columns: 0.50 -> 0.60 of the HBM peak on the first decode); the sums travel to page-locked host memory behind an
+ *      event that is only queried, and the next alpgpu_decode_* of the same column (same buffers and length, not encoded again through this context in between) is planned
+ *      on the host like a hinted one — shape, residency, regions (0.72-0.76);
+ *   2  as 1, and the first decode launches EVERY candidate shape gated on the plan's word (closed candidates cost their dispatch: ~0.19 ms per 1 Mi empty workgroups,
+ *      which is why this is not the default: profiles/r06_decode_policy.txt);
+ *   0  one vector per workgroup (float: two), no read-ahead, nothing learned: as before round 6.
+ * No host synchronisation in any mode.  Same bytes. */
 #define ALPGPU_OPT_DECODE_UNHINTED 15
+/* ALPGPU_OPT_ENCODE_TILE_SEARCH (double columns under ALPGPU_ENCODE_KERNEL_LEAN, whole columns of >= 1024 rowgroups; round 6): 1 = the encode's tiles run the rowgroup
+ * search's (e, f) candidate walk themselves, as work items between "sizes published" and "offset needed" (the wait for the ordered offset), instead of a persistent
+ * search kernel that holds one of a CU's three tile slots beside them.  Same bytes.  DESIGN.md §3.2, profiles/r06_encode_levers.txt. */
+#define ALPGPU_OPT_ENCODE_TILE_SEARCH 16
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */

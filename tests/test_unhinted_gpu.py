@@ -41,11 +41,13 @@ def narrow_input(n, exc, seed=5):
 
 def test_a_column_decoded_right_behind_its_encode_gets_its_shape_and_read_ahead_from_the_device(ctx, oracle):
     """VERDICT round 5 item 3, as written: a 300 000-vector 4-bit column with 20 exceptions per vector is encoded and decoded WITHOUT alpgpu_column_totals.  The
-    sizes are summed on the stream, the rule runs on the device (two vectors per workgroup + the read-ahead for this column), the read-ahead really reads (its
-    batch counter moves), the bytes are the input's — and the oracle's on a sample; the second decode is planned on the host from what the first one learned."""
+    sizes are summed on the stream, the rule runs on the device (it would pick two vectors per workgroup, and it starts the read-ahead for this column), the read-ahead
+    really reads (its batch counter moves), the bytes are the input's — and the oracle's on a sample; the second decode is planned on the host from what the first one
+    learned; the same with every candidate shape launched and gated (option value 2)."""
     import torch
     n = 300000
     x = narrow_input(n, 20)
+    from alp_amd import capi
     col = ctx.encode(x)  # no column_totals: the hints stay 0
     assert col.c.packed_bytes_hint == 0 and col.c.exc_bytes_hint == 0
     assert not ctx.decode_reads_ahead(col) and ctx.decode_vectors_per_wg(col) == 1  # what the host-side rule would do with it
@@ -67,43 +69,47 @@ def test_a_column_decoded_right_behind_its_encode_gets_its_shape_and_read_ahead_
     ctx.decode(col, out2)
     after = ctx.read_ahead_batches()
     assert torch.equal(out2.view(torch.int64), x.view(torch.int64)) and after - mid >= n // 64 // 4
-    # an encode into the same buffers forgets what was learned
+    # an encode into the same buffers forgets what was learned; this time with every candidate shape launched, gated on the plan's word
     y = narrow_input(n, 0, seed=6)
     ctx.encode(y, col)
-    out3 = ctx.decode(col)
-    plan3 = ctx.unhinted_plan()
+    try:
+        ctx.set_option(capi.OPT_DECODE_UNHINTED, 2)
+        out3 = ctx.decode(col)
+        plan3 = ctx.unhinted_plan()
+    finally:
+        ctx.set_option(capi.OPT_DECODE_UNHINTED, 1)
     assert torch.equal(out3.view(torch.int64), y.view(torch.int64))
     assert plan3["shape"] == 1 and plan3["exceptions"] < n // 10 and plan3["lead_max"] >= 4096, plan3  # no exceptions: one vector per workgroup under the read-ahead
 
 
 @pytest.mark.parametrize("vb", [8, 4])
 def test_unhinted_decode_picks_the_shape_of_the_hinted_one_and_writes_the_same_bytes(ctx, vb):
-    """hand-built columns of several widths, hints zeroed: the device plan names the candidate the host rule would launch; same bytes as the hinted decode;
-    with the option off, too"""
+    """hand-built columns of several widths, hints zeroed: the device plan names the candidate the host rule would launch; same bytes as the hinted decode in every
+    mode of the option: 1 (one launch, the plan steers the read-ahead), 2 (every candidate launched, gated on the plan), 0 (off)"""
     import torch
     import bench
     from alp_amd import capi
     n = 140000
     tdt = torch.int64 if vb == 8 else torch.int32
-    cases = [(4, 0, 2), (4, 20, 2), (12, 0, 2), (28, 0, 1), (44, 0, 3)] if vb == 8 else [(3, 0, 2), (3, 20, 2), (20, 0, 1), (30, 5, 1)]
+    cases = [(4, 0, 2), (4, 20, 2), (12, 0, 2), (28, 0, 1), (44, 0, 3)] if vb == 8 else [(3, 0, 1), (3, 20, 1), (20, 0, 1), (30, 5, 1)]
     for bw, exc, shape in cases:
         col, _, _ = bench.build_decode_column(n, 0, seed=3, bw_of_rowgroup=bw, exc_per_vec=exc, value_bytes=vb)
         ref = ctx.decode(col).clone()
         hinted_vpw = ctx.decode_vectors_per_wg(col)
         col.c.packed_bytes_hint, col.c.exc_bytes_hint = 0, 0
         out = torch.zeros_like(ref)
-        ctx.decode(col, out)
-        plan = ctx.unhinted_plan()
-        assert torch.equal(out.view(tdt), ref.view(tdt)), (bw, exc)
-        assert plan["shape"] == shape, (bw, exc, plan)
-        assert {8: {1: 1, 2: 2, 3: 1}, 4: {1: 2, 2: 4}}[vb][plan["shape"]] == hinted_vpw, (bw, exc, plan, hinted_vpw)
-        assert plan["lead_max"] == 0  # 140 000 vectors: too short for the read-ahead on its own
-        ctx.forget(col)
         try:
-            ctx.set_option(capi.OPT_DECODE_UNHINTED, 0)
-            out.zero_()
-            ctx.decode(col, out)
-            assert torch.equal(out.view(tdt), ref.view(tdt))
+            for mode in (1, 2, 0):
+                ctx.forget(col)
+                ctx.set_option(capi.OPT_DECODE_UNHINTED, mode)
+                out.zero_()
+                ctx.decode(col, out)
+                assert torch.equal(out.view(tdt), ref.view(tdt)), (bw, exc, mode)
+                if mode:
+                    plan = ctx.unhinted_plan()
+                    assert plan["shape"] == shape, (bw, exc, plan)
+                    assert {8: {1: 1, 2: 2, 3: 1}, 4: {1: 2}}[vb][plan["shape"]] == hinted_vpw, (bw, exc, plan, hinted_vpw)
+                    assert plan["lead_max"] == 0  # 140 000 vectors: too short for the read-ahead on its own
         finally:
             ctx.set_option(capi.OPT_DECODE_UNHINTED, 1)
         del col

@@ -19,6 +19,12 @@ case $step in
   ALPGPU_READ_AHEAD_ADAPT=1 run 120 adapt_on.txt python tools/time_read_ahead.py
   run 300 bench.txt python bench.py
   ;;
+2) # the whole GPU suite again; the tiles' search items (experiment: vectors alone with / without them); the decode of encoder output in a grid of shapes
+  run 600 tests.txt python -m pytest tests -m gpu -x -q
+  run 300 encode.txt python tools/time_encode.py
+  run 300 decode_encoded.txt python tools/time_decode_encoded.py
+  run 200 unhinted.txt python tools/time_unhinted.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400

@@ -31,9 +31,16 @@ for kind in kinds:
     ctx.encode(x, col)
     pb, eb, ov = ctx.column_totals(col)
     alg = bench.encode_alg_bytes(n, pb, eb)
-    for u in (0, 1):
-        ctx.set_option(capi.OPT_ENCODE_UNORDERED, u)
-        vs[u].append(bench.time_launches(lambda: ctx.encode_vectors(x, col), 5, 2)[0])
+    ts = {(u, t): [] for u in (0, 1) for t in (0, 1)}  # vectors alone (states ready), with / without the tiles' search items (ALPGPU_OPT_ENCODE_TILE_SEARCH)
+    for rep in range(3):
+        for u in (0, 1):
+            for t in (0, 1):
+                ctx.set_option(capi.OPT_ENCODE_UNORDERED, u)
+                ctx.set_option(capi.OPT_ENCODE_TILE_SEARCH, t)
+                ts[(u, t)].append(bench.time_launches(lambda: ctx.encode_vectors(x, col), 5, 2)[0])
+    ctx.set_option(capi.OPT_ENCODE_TILE_SEARCH, 0)
+    vs[0].append(min(ts[(0, 0)])), vs[1].append(min(ts[(1, 0)]))
+    print(f"{kind}: vectors alone (states ready), ms: " + " | ".join(f"unordered={u} tile_search={t}: " + " ".join(f"{v:.3f}" for v in ts[(u, t)]) for u in (0, 1) for t in (0, 1)), flush=True)
     ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
     ctx.encode(x, col)
     ctx.decode(col, out)
