@@ -225,12 +225,12 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
 	switch (option) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
-		if (value != 0 && value != 1 && value != 2 && value != 4) {
-			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2 or (float columns) 4");
+		if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) {
+			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2, 4 or (float columns: one wavefront per vector) 8");
 		}
 		ctx->decode_auto    = value == 0;
 		ctx->decode_vpw     = static_cast<int>(value);
-		ctx->decode_variant = (ctx->decode_variant & ~5) | (value >= 2 ? 0 : 1) | (value == 4 ? 4 : 0); // (4: four vectors over the narrow stage)
+		ctx->decode_variant = (ctx->decode_variant & ~5) | ((value == 2 || value == 4) ? 0 : 1) | (value == 4 ? 4 : 0); // (4: four vectors over the narrow stage; 8: float columns only, double columns take 1)
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_TWO_PASS:
 		ctx->encode_two_pass = value ? 1 : 0;

@@ -54,6 +54,8 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		// narrow vectors under the read-ahead: their reads hit the Infinity Cache, and ONE vector per workgroup — the shape that suffers most from the two round
 		// trips (0.53 at 2-6 bits) — becomes the best one (0.75-0.80); with exceptions two per workgroup stay ahead (0.68-0.74 against 0.64-0.68)
 		if (ctx->read_ahead < 0 && read_ahead_for(ctx, col) && !with_exc) { variant = (variant & ~5) | 1; }
+		// (almost) nothing but 0-bit vectors — a pure stream of stores, e.g. the gov26 shape: one vector per workgroup (and six workgroups per CU, below): 0.71 -> 0.82 (call 2)
+		if (hinted && bits <= alpgpu::kEmptyVectorsBits) { variant = (variant & ~5) | 1; }
 	}
 	// Narrow vectors WITH exceptions: the pair kernel (k_decode_pairs, both vectors' loads in flight together when both are narrow, one after the
 	// other otherwise) is 1-4 % ahead of k_decode_column<2> up to 18 bits (tools/sweep_pairing.py, profiles/r04_decode_floor.txt section 4); without
@@ -81,6 +83,8 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 			// (+5-7 %); ALP_RD columns — more arithmetic per value — seven
 			if (mostly_rd) {
 				pad_kib = 11;
+			} else if (bits <= alpgpu::kEmptyVectorsBits) {
+				pad_kib = 14; // a pure stream of stores wants few workgroups per CU, like wide vectors
 			} else if (with_exc) {
 				pad_kib = bits >= 46.0 ? 14 : (bits >= 38.0 ? 11 : 6);
 			} else {

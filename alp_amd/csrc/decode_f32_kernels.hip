@@ -429,10 +429,12 @@ static void launch_v(hipStream_t stream, const alpgpu_column* col, float* d_out,
 	}
 }
 
-// vectors_per_wg in {1, 2, 4}
+static int launch_store_direct_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int pad_kib, uint64_t* progress, uint64_t progress_tag); // (below, behind its kernel)
+// vectors_per_wg in {1, 2, 4}; 8 = one wavefront per vector
 int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores, int pad_kib, uint64_t* progress, uint64_t progress_tag,
                              uint32_t gate) {
 	if (col->n_vectors == 0) { return ALPGPU_OK; }
+	if (vectors_per_wg == 8) { return launch_store_direct_f32(stream, col, d_out, pad_kib, progress, progress_tag); } // (no gate: never a candidate of an unhinted decode)
 	if (vectors_per_wg == 1) {
 		launch_v<1>(stream, col, d_out, !plain_stores, pad_kib, progress, progress_tag, gate);
 	} else if (vectors_per_wg == 2) {
@@ -478,7 +480,7 @@ struct __attribute__((aligned(16))) SinkWaveLdsF32 {
 template <int SINK>
 __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                       const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, double* __restrict__ out,
-                                                                      uint64_t n_vectors, uint64_t wg_offset, float lo, float hi) {
+                                                                      uint64_t n_vectors, uint64_t wg_offset, float lo, float hi, uint64_t* __restrict__ progress, uint64_t progress_tag) {
 	#ifdef ALPGPU_SINK_REGISTER_MARGIN
 	asm volatile("" ::: "v64"); // decode_kernels.hip: k_sink_direct
 #endif
@@ -487,6 +489,9 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	const int      wv   = wave_in_wg();
 	const uint64_t v    = (wg_offset + blockIdx.x) * (kDecThreadsF / 64) + wv;
 	if (v >= n_vectors) { return; } // wave-uniform; no barrier anywhere in this kernel
+	if constexpr (SINK == kSinkStoreF) { // the store form reports where the launch is, for the read-ahead (k_decode_column_f32 does the same): every 32nd workgroup = every 128th vector
+		if (progress != nullptr && (blockIdx.x & 31u) == 0 && threadIdx.x == 0) { __hip_atomic_store(progress, progress_tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	}
 	SinkWaveLdsF32&          L      = S[wv];
 	const alpgpu_vector_desc d      = descs[v];
 	const RdDict             dict   = load_vector_consts_f32(rgs, v, d);
@@ -569,6 +574,19 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 		return;
 	}
 #endif
+	if constexpr (SINK == kSinkStoreF) {
+		// Round 6: the same wavefront as a STORE decoder (ALPGPU_OPT_DECODE_VECTORS_PER_WG = 8 for float columns): lane L's four quads are the 16-byte units L, 64 + L,
+		// 128 + L, 192 + L of the vector — four store instructions of 1 KiB each, no barrier, one wave-uniform prologue per vector instead of four.
+		float* dst = reinterpret_cast<float*>(out) + v * kVec;
+		if (cnt <= (is_alp ? kExcStageF : 2 * kExcStageF)) { // wave-uniform: every exception value is staged — the instance without a load between the stores
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { finish_quad_f32<true, kSinkStoreF, SinkWaveLdsF32, false>(L, w[q], d, dict, em, rec, dst, 64 * q + lane, q, lane, nullptr, 0.0f, 0.0f); }
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { finish_quad_f32<true, kSinkStoreF, SinkWaveLdsF32, true>(L, w[q], d, dict, em, rec, dst, 64 * q + lane, q, lane, nullptr, 0.0f, 0.0f); }
+		}
+		return;
+	}
 	double part[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int q = 0; q < 4; ++q) { finish_quad_f32<false, SINK>(L, w[q], d, dict, em, rec, nullptr, 64 * q + lane, q, lane, &part[q], lo, hi); }
@@ -583,6 +601,16 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	}
 }
 
+// one wavefront per vector, four vectors per workgroup, no barrier: k_sink_direct_f32 as a store decoder (non-temporal stores)
+static int launch_store_direct_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int pad_kib, uint64_t* progress, uint64_t progress_tag) {
+	const uint64_t n = col->n_vectors, n_wg = (n + 3) / 4, kMaxGrid = 1ull << 30;
+	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
+		hipLaunchKernelGGL((k_sink_direct_f32<kSinkStoreF>), dim3(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), dim3(kDecThreadsF), pad_kib > 0 ? static_cast<unsigned>(pad_kib) * 1024u : 0u, stream,
+		                   col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, reinterpret_cast<double*>(d_out), n, off, 0.0f, 0.0f, progress, progress_tag);
+	}
+	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
+}
+
 int launch_sink_direct_f32(hipStream_t stream, const alpgpu_column* col, float lo, float hi, void* d_out, bool count) {
 	const uint64_t n = col->n_vectors;
 	if (n == 0) { return ALPGPU_OK; }
@@ -592,9 +620,9 @@ int launch_sink_direct_f32(hipStream_t stream, const alpgpu_column* col, float l
 	for (uint64_t off = 0; off < n_wg; off += kMaxGrid) {
 		const dim3 grid(static_cast<unsigned>(n_wg - off < kMaxGrid ? n_wg - off : kMaxGrid)), block(kDecThreadsF);
 		if (count) {
-			hipLaunchKernelGGL((k_sink_direct_f32<kSinkCountF>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, lo, hi);
+			hipLaunchKernelGGL((k_sink_direct_f32<kSinkCountF>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, lo, hi, static_cast<uint64_t*>(nullptr), 0ull);
 		} else {
-			hipLaunchKernelGGL((k_sink_direct_f32<kSinkSumF>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, 0.0f, 0.0f);
+			hipLaunchKernelGGL((k_sink_direct_f32<kSinkSumF>), grid, block, 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, static_cast<double*>(d_out), n, off, 0.0f, 0.0f, static_cast<uint64_t*>(nullptr), 0ull);
 		}
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;

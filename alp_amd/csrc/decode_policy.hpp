@@ -26,6 +26,7 @@ constexpr double   kReadAheadBitsExc = 7.5;    // ... and with exceptions
 constexpr uint64_t kReadAheadVectors = 262144; // shorter columns: the cold start and the join of the second stream eat the gain
 constexpr double   kTwoVectorsBits    = 17.5;  // two vectors per workgroup up to here without exceptions ...
 constexpr double   kTwoVectorsBitsExc = 22.0;  // ... and with (about two or more per vector)
+constexpr double   kEmptyVectorsBits    = 0.75; // columns of (almost) nothing but 0-bit vectors: one vector per workgroup, six workgroups per CU, no read-ahead (call 2, the gov26 column)
 // ---- float columns (a vector is 4 KiB; two per workgroup are the bytes in flight of one double vector): tools/sweep_f32_decode.py, profiles/r06_float_decode.txt ----
 // Measured (call 1b, 1 Mi float vectors, fractions of 8 TB/s): cold, two vectors per workgroup are ahead of one at every width and of four wherever there are exceptions; without
 // exceptions four are 1-2 points ahead at 6-14 bits only (and at 1 bit): not worth a rule — always two.  The read-ahead lifts 2-7-bit columns from 0.49-0.60 to
@@ -53,7 +54,9 @@ __host__ __device__ inline bool policy_with_exceptions(double n_vectors, double 
 // the read-ahead on its own (ALPGPU_OPT_DECODE_READ_AHEAD = -1): long columns of narrow vectors only
 __host__ __device__ inline bool policy_read_ahead_auto(uint64_t n_vectors, double packed_bytes, bool with_exc, int value_bytes) {
 	const double limit = value_bytes == 8 ? (with_exc ? kReadAheadBitsExc : kReadAheadBits) : (with_exc ? kReadAheadBitsExcF32 : kReadAheadBitsF32);
-	const double least = value_bytes == 8 ? 0.0 : 1.5; // (float columns of 1-bit vectors: 0.75 cold, 0.72 with the second stream of reads)
+	// (float columns of 1-bit vectors: 0.75 cold, 0.72 with the second stream of reads; double columns of almost nothing but 0-bit vectors — the gov26 shape, a pure stream of
+	//  stores: 0.82 with six workgroups per CU and no second stream, 0.71-0.72 with it: kEmptyVectorsBits)
+	const double least = value_bytes == 8 ? kEmptyVectorsBits : 1.5;
 	return n_vectors >= kReadAheadVectors && packed_bytes <= limit * 128.0 * static_cast<double>(n_vectors) && packed_bytes >= least * 128.0 * static_cast<double>(n_vectors);
 }
 
@@ -98,9 +101,9 @@ __host__ __device__ inline UnhintedChoice policy_unhinted(uint64_t n_vectors, do
 	UnhintedChoice c;
 	c.ahead = read_ahead_option > 0 ? n_vectors >= 32768 : (read_ahead_option < 0 && policy_read_ahead_auto(n_vectors, packed_bytes, with_exc, value_bytes));
 	if (value_bytes == 8) {
-		const bool narrow = bits <= (with_exc ? kTwoVectorsBitsExc : kTwoVectorsBits);
+		const bool narrow = bits <= (with_exc ? kTwoVectorsBitsExc : kTwoVectorsBits) && bits > kEmptyVectorsBits;
 		const bool rd     = 2.0 * rd_vectors > n;
-		c.shape           = narrow ? 2 : ((rd || bits >= 38.0) ? 3 : 1);
+		c.shape           = narrow ? 2 : ((rd || bits >= 38.0 || bits <= kEmptyVectorsBits) ? 3 : 1);
 		if (read_ahead_option < 0 && c.ahead && !with_exc) { c.shape = 1; } // under the read-ahead one vector per workgroup is the best shape without exceptions
 	} else {
 		c.shape = 1;

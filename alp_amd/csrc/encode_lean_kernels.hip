@@ -368,15 +368,19 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 // writes, descriptor for descriptor; only WHERE a tile's bytes lie in the two streams follows the order in which tiles finished their analysis
 // instead of vector order (the eight vectors of a tile stay together, in order).  A decoder never notices: descriptors carry offsets.
 // (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
-// ---- the rowgroup search as work items of the tiles themselves (round 6; SEARCH = 1) ------------------------------------------------
+// ---- the rowgroup search as work items of the tiles themselves (round 6; SEARCH != 0) -----------------------------------------------
 // Beside the encode the persistent search kernel holds one of a CU's three tile slots for two thirds of the encode's time (~0.30 ms of 3.0 exposed), while every
-// tile's worker wavefronts sit parked for ~2.6 us of their ~14 us waiting for the ordered offset.  The (e, f) walk — 27 items per rowgroup: (sampled vector, round of
-// 64 candidates) over 32 samples, ~1.2 us of one wavefront each — is what the search's time goes to (0.57 of 0.58 ms on ALP columns).  With SEARCH the tiles run those
-// items themselves, between "sizes published" and "offset needed": the global tile t = 25 B + j (25 tiles = 200 vectors = two rowgroups) works on rowgroups
-// 2 B + kTileSearchAhead and + 1: wavefronts 1 and 2 of tile j take items 2 j and 2 j + 1, wavefront 3 of tiles 0..3 items 50..53.  An item's samples (one 8-byte
-// load per lane, issued behind the size publication so that the pack covers the trip) are walked as v_readlane broadcasts, the candidate's multipliers come from two
-// 19-entry tables held one entry per lane (ds_bpermute), its key — (size << 8 | candidate) + 1 in 21 bits, all-ones for "no candidate" — is ADDED into the field of
-// its round in the sampled vector's word (three fields per 64-bit word, zero at launch): one fire-and-forget atomic, nobody waits for it.
+// tile's worker wavefronts sit parked waiting for the ordered offset.  The (e, f) walk — 27 items per rowgroup: (sampled vector, round of 64 candidates) over 32
+// samples — is what the search's time goes to (0.57 of 0.58 ms on ALP columns).  With SEARCH the tiles run those items themselves, between "sizes published" and
+// "offset needed": the global tile t = 25 B + j (25 tiles = 200 vectors = two rowgroups) works on rowgroups 2 B + kTileSearchAhead and + 1; tile j takes items 2 j and
+// 2 j + 1, tiles 6, 12, 18, 24 one of the four left over as well.  An item's samples (one 8-byte load per lane, issued behind the size publication so that the pack
+// covers the trip) are walked as v_readlane broadcasts, the candidate's multipliers come from two 19-entry tables held one entry per lane (ds_bpermute).
+//   First form (call 2, profiles/r06_encode_levers.txt): one wavefront per item, all 32 samples: ~1.9 us per item against the ~0.8 us of wait that hides it — the vector
+//   encode alone 2.67 -> 3.09 ms (unordered 2.33 -> 3.03), i.e. slower than the shipped encode WITH its search beside it (2.92-2.99).
+//   This form: an item is SPLIT over the wavefronts of a group (three wavefronts x 11 samples; two x 16 in the tiles that carry three items), whose partial counts
+//   and ranges meet in LDS (ds_add / ds_max / ds_min on 64 candidates x {count, max, min}, associative: the same integers) at the barrier every wavefront of the tile
+//   takes anyway; behind it the group's first wavefront turns them into the item's key — (size << 8 | candidate) + 1 in 21 bits, all-ones for "no candidate" — and ADDS
+//   it into the field of its round in the sampled vector's word (three fields per 64-bit word, zero at launch): one fire-and-forget atomic, nobody waits for it.
 constexpr uint32_t kTileSearchAhead = 256; // rowgroups between an item's tile and its rowgroup (= the head the search kernel does in front: api_encode.hip)
 constexpr int      kTileSearchWordsPerRg = 16; // 9 used: one per sampled vector
 
@@ -407,6 +411,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	__shared__ uint64_t s_excl;
 	__shared__ uint32_t s_count;
 	__shared__ uint32_t s_ready;
+	// SEARCH: where the partial results of an item's wavefronts meet (three groups x 64 candidates)
+	__shared__ uint32_t  s_item_cnt[SEARCH != 0 ? 3 : 1][64];
+	__shared__ long long s_item_max[SEARCH != 0 ? 3 : 1][64], s_item_min[SEARCH != 0 ? 3 : 1][64];
 	const int           lane = lane_id();
 	const int           wave = wave_in_wg();
 	const uint64_t      tile = blockIdx.x;
@@ -457,6 +464,13 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		s_count = 0;
 		s_ready = 0;
 		s_excl  = ~0ull;
+	}
+	if constexpr (SEARCH != 0) {
+		if (threadIdx.x < 192) {
+			s_item_cnt[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
+			s_item_max[threadIdx.x >> 6][threadIdx.x & 63] = INT64_MIN;
+			s_item_min[threadIdx.x >> 6][threadIdx.x & 63] = INT64_MAX;
+		}
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
 #endif
@@ -543,19 +557,22 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	}
 	const uint64_t base_p = totals[0], base_e = totals[1];
 
-	// SEARCH: this wavefront's item, if any — its samples and the two tables are asked for HERE (the pack and the record below cover the trip)
-	bool     has_item = false;
-	int      item_round = 0;
+	// SEARCH: this wavefront's share of an item, if any — its samples and the two tables are asked for HERE (the pack and the record below cover the trip)
+	bool     has_item = false, item_lead = false;
+	int      item_round = 0, item_group = 0, item_s0 = 0, item_s1 = 0;
 	uint64_t item_word = 0; // index into search_words
 	double   item_smp = 0.0, item_tab_e = 0.0, item_tab_f = 0.0;
 	uint32_t item_ef = 0;
 	if constexpr (SEARCH != 0) {
-		if (wave >= 1 && wave <= 3) { // wave-uniform
+		if (wave >= 1 && wave <= 6) { // wave-uniform
 			const uint64_t gtile = (v_first >> 3) + tile; // (launches begin on multiples of 8 vectors)
 			const uint64_t blk   = gtile / 25u;
 			const int      j     = static_cast<int>(gtile - blk * 25u);
-			const int      item  = wave == 1 ? 2 * j : (wave == 2 ? 2 * j + 1 : (j < 4 ? 50 + j : -1));
-			if (item >= 0) {
+			const bool     three = j != 0 && j % 6 == 0;    // tiles 6, 12, 18, 24 carry one of the items 50..53 as well: groups of two wavefronts there
+			const int      gsz   = three ? 2 : 3;
+			const int      group = (wave - 1) / gsz, part = (wave - 1) - group * gsz;
+			const int      item  = group == 0 ? 2 * j : (group == 1 ? 2 * j + 1 : 49 + j / 6);
+			{
 				const uint64_t rg_i  = 2 * blk + kTileSearchAhead + static_cast<uint64_t>(item / 27);
 				const int      q     = item % 27;
 				const int      sv    = q / 3;
@@ -565,6 +582,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 					const int      n_sv = static_cast<int>((nv + 11) / 12);
 					if (sv < n_sv) {
 						has_item   = true;
+						item_lead  = part == 0;
+						item_group = group;
+						item_s0    = part * 32 / gsz, item_s1 = (part + 1) * 32 / gsz;
 						item_round = q - 3 * sv;
 						item_word  = rg_i * kTileSearchWordsPerRg + static_cast<uint64_t>(sv);
 						item_smp   = in[(rg_v0 + 12ull * sv) * kVec + 32ull * (lane & 31)];
@@ -655,22 +675,16 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 			PrecF64::Acc acc;
 			PrecF64::start(acc);
 #pragma unroll 1
-			for (int s0 = 0; s0 < 32; s0 += 4) {
+			for (int s0 = item_s0; s0 + 2 <= item_s1; s0 += 2) { // (two per trip, spelled out: the unroller declines this body — a rarely taken branch inside)
 				PrecF64::step(acc, readlane_f64(item_smp, s0), k);
 				PrecF64::step(acc, readlane_f64(item_smp, s0 + 1), k);
-				PrecF64::step(acc, readlane_f64(item_smp, s0 + 2), k);
-				PrecF64::step(acc, readlane_f64(item_smp, s0 + 3), k);
 			}
+			if ((item_s1 - item_s0) & 1) { PrecF64::step(acc, readlane_f64(item_smp, item_s1 - 1), k); }
 			PrecF64::finish(acc);
-			uint32_t key = 0xFFFFFFFFu;
-			if (lane + 64 * item_round < PrecF64::kNumCombos && acc.non_exc >= 2) { // encoder.hpp:182
-				const uint32_t size = 32u * static_cast<uint32_t>(PrecF64::bits(acc.mx, acc.mn)) + static_cast<uint32_t>(32 - acc.non_exc) * (PrecF64::kExcBits + 16u);
-				key                 = (size << 8) | static_cast<uint32_t>(lane + 64 * item_round);
-			}
-			key = wave_min_u32(key);
-			if (lane == 0) {
-				const unsigned long long field = key == 0xFFFFFFFFu ? 0x1FFFFFull : static_cast<unsigned long long>(key) + 1ull;
-				__hip_atomic_fetch_add(search_words + item_word, field << (21 * item_round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (acc.non_exc != 0) { // this wavefront's samples into the group's meeting place (LDS; the tile's barrier below publishes them to the group's first wavefront)
+				__hip_atomic_fetch_add(&s_item_cnt[item_group][lane], static_cast<uint32_t>(acc.non_exc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_max(&s_item_max[item_group][lane], static_cast<long long>(acc.mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_min(&s_item_min[item_group][lane], static_cast<long long>(acc.mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 			reload_x = true;
 		}
@@ -706,6 +720,22 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	const uint64_t mine_sz = lane < wave ? s_size[lane & (kFusedWaves - 1)] : 0ull;
 	const uint64_t local   = wave_sum_u64(mine_sz);
 	const uint64_t excl    = s_excl;
+	if constexpr (SEARCH != 0) {
+		if (has_item && item_lead) { // the item's key from what its wavefronts left in LDS (all of them are past the barrier above)
+			const int       non_exc = static_cast<int>(s_item_cnt[item_group][lane]);
+			const long long mx = s_item_max[item_group][lane], mn = s_item_min[item_group][lane];
+			uint32_t        key = 0xFFFFFFFFu;
+			if (lane + 64 * item_round < PrecF64::kNumCombos && non_exc >= 2) { // encoder.hpp:182
+				const uint32_t size = 32u * static_cast<uint32_t>(PrecF64::bits(mx, mn)) + static_cast<uint32_t>(32 - non_exc) * (PrecF64::kExcBits + 16u);
+				key                 = (size << 8) | static_cast<uint32_t>(lane + 64 * item_round);
+			}
+			key = wave_min_u32(key);
+			if (lane == 0) {
+				const unsigned long long field = key == 0xFFFFFFFFu ? 0x1FFFFFull : static_cast<unsigned long long>(key) + 1ull;
+				__hip_atomic_fetch_add(search_words + item_word, field << (21 * item_round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
 	if (excl == ~0ull) { return; } // stalled: nothing of this tile is written
 	const uint64_t pre = excl + local;
 	d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;

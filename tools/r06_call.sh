@@ -25,6 +25,12 @@ case $step in
   run 300 decode_encoded.txt python tools/time_decode_encoded.py
   run 200 unhinted.txt python tools/time_unhinted.py
   ;;
+3) # the tiles' search items split over wavefronts (second form); the float store decode with one wavefront per vector; the decode grid again (the empty-vectors rule)
+  run 300 encode.txt python tools/time_encode.py
+  WIDTHS=1,2,3,4,5,6,7,8,10,12,16,20,24,28,32 run 400 f32_sweep.txt python tools/sweep_f32_decode.py
+  PADS=0,6,14 run 200 decode_encoded.txt python tools/time_decode_encoded.py
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py tests/test_unhinted_gpu.py tests/test_decode_gpu.py -m gpu -x -q
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400

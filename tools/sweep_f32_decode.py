@@ -20,14 +20,14 @@ ahead_upto = int(os.environ.get("AHEAD_UPTO", "12"))
 ctx = capi.Context(0)
 out = torch.empty(n * 1024, dtype=torch.float32, device="cuda:0")
 print(f"lib {bench.lib_sha16()}  n={n}")
-print("bw exc |  vpw1   vpw2   vpw4 | auto(vpw,ahead) | read-ahead on, by (vpw, lead us): ...")
+print("bw exc |  vpw1   vpw2   vpw4   one wave per vector | auto(vpw,ahead) | read-ahead on, by (vpw, lead us): ...")
 for exc in excs:
     for bw in widths:
         c, _, ab = bench.build_decode_column(n, 0, seed=7, bw_of_rowgroup=bw, exc_per_vec=exc, value_bytes=4)
         f = lambda ms: ab / ms / 1e6 / 8000  # noqa: E731
         row = []
         ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 0)
-        for vpw in (1, 2, 4):
+        for vpw in (1, 2, 4, 8):
             ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
             row.append(f(bench.time_launches(lambda: ctx.decode(c, out), 7, 4)[0]))
         ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
@@ -37,7 +37,7 @@ for exc in excs:
         ra = []
         if bw <= ahead_upto:
             ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 1)
-            for vpw in (1, 2, 4):
+            for vpw in (2, 8):
                 for lead in leads:
                     ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
                     ctx.set_option(capi.OPT_DECODE_READ_AHEAD_US, lead)
@@ -45,5 +45,5 @@ for exc in excs:
             ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
             ctx.set_option(capi.OPT_DECODE_READ_AHEAD_US, 0)
             ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
-        print(f"{bw:2d} {exc:3d} | {row[0]:.3f}  {row[1]:.3f}  {row[2]:.3f} | {auto:.3f} {shape} | {' '.join(ra)}", flush=True)
+        print(f"{bw:2d} {exc:3d} | {row[0]:.3f}  {row[1]:.3f}  {row[2]:.3f}  {row[3]:.3f} | {auto:.3f} {shape} | {' '.join(ra)}", flush=True)
         del c
