@@ -343,21 +343,26 @@ static int decode_one(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 	uint64_t   tag   = 0;
 	if (ahead) {
 		tag = next_progress_tag(ctx);
-		const alpgpu::ReadAheadPace pace = alpgpu::policy_read_ahead_pace(static_cast<double>(col->n_vectors), static_cast<double>(col->packed_bytes_hint),
-		                                                                  static_cast<double>(col->exc_bytes_hint), VB, ctx->read_ahead_us); // (decode_policy.hpp: the lead is a time)
-		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
-		if (alpgpu::launch_read_ahead(ctx->init_stream, col, VB, ctx->d_progress, tag, pace.lead_min, pace.lead_max, pace.ps_per_vector, ctx->wall_tick_ps, static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
-			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
-		}
-		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
+		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream)); // (the read-ahead may start where the decode may)
 	}
+	// The decode kernel is enqueued FIRST (round 6; until round 5 the read-ahead was): whatever delays the host between the two launches — the lazy load of a code
+	// object on a process's first decode takes milliseconds — then costs the read-ahead a late start instead of its patience (a read-ahead that waits for a decode
+	// that is not even enqueued leaves, and that decode then runs without one).  The side stream has the higher priority: its few workgroups are placed at once.
 	int rc;
 	if constexpr (VB == 8) {
 		rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), decode_variant_for(ctx, col), ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), ahead ? ctx->d_progress : nullptr, tag);
 	} else {
 		const int shape = decode_shape_f32(ctx, col);
 		rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), shape & 0xFF, (ctx->decode_variant & 2) != 0, (shape >> 8) == 0xFF ? -1 : (shape >> 8), ahead ? ctx->d_progress : nullptr, tag);
+	}
+	if (ahead) {
+		const alpgpu::ReadAheadPace pace = alpgpu::policy_read_ahead_pace(static_cast<double>(col->n_vectors), static_cast<double>(col->packed_bytes_hint),
+		                                                                  static_cast<double>(col->exc_bytes_hint), VB, ctx->read_ahead_us); // (decode_policy.hpp: the lead is a time)
+		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, VB, ctx->d_progress, tag, pace.lead_min, pace.lead_max, pace.ps_per_vector, ctx->wall_tick_ps, static_cast<uint32_t>(ctx->read_ahead_bits), ctx->read_ahead_grid) != ALPGPU_OK) {
+			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
+		}
+		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
 	}
 	if (ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); } // (the read-ahead leaves on its own once its last batch is in reach or the decode never shows up)
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
@@ -416,33 +421,9 @@ static int decode_unhinted(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_ou
 	if (alpgpu::launch_unhinted_plan(ctx->stream, words, n_seg, col->n_vectors, VB, (ctx->read_ahead < 0 && ctx->streams_serialize) ? 0 : ctx->read_ahead, ctx->read_ahead_us, static_cast<uint32_t>(ctx->read_ahead_bits)) != ALPGPU_OK) {
 		return fail(ALPGPU_ERR_HIP, "plan launch failed", hipGetLastError());
 	}
-	// the sums, for the next decode of this column: to page-locked memory behind an event that is only ever queried
-	if (ctx->h_learn != nullptr) {
-		LearnSlot* l = learn_slot_of(ctx, col, VB);
-		if (!l) {
-			l               = &ctx->learn[ctx->learn_next];
-			ctx->learn_next = (ctx->learn_next + 1) % kLearnSlots;
-		}
-		if (l->state == 1) { (void)hipEventSynchronize(l->ev); } // (the slot's previous copy still in flight: a fifth unhinted column within microseconds)
-		l->key = col->d_vectors, l->d_packed = col->d_packed, l->n_vectors = col->n_vectors, l->value_bytes = VB, l->n_seg = n_seg;
-		l->state = 0;
-		if (hipMemcpyAsync(ctx->h_learn + static_cast<size_t>(l - ctx->learn) * 3 * kMaxSegments, words + alpgpu::kCtxWordSegments, 24ull * n_seg, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-		    hipEventRecord(l->ev, ctx->stream) == hipSuccess) {
-			l->state = 1;
-		} else {
-			(void)hipGetLastError(); // best effort: the column simply stays unhinted
-		}
-	}
 	const uint64_t tag        = next_progress_tag(ctx);
 	const bool     with_ahead = ctx->read_ahead > 0 || (ctx->read_ahead < 0 && !ctx->streams_serialize);
-	if (with_ahead) { // (the kernel leaves at once when the plan says "no read-ahead for this column")
-		ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
-		if (alpgpu::launch_read_ahead(ctx->init_stream, col, VB, words, tag, 0, 0, 0, ctx->wall_tick_ps, 0, ctx->read_ahead_grid, true) != ALPGPU_OK) {
-			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
-		}
-		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
-	}
+	if (with_ahead) { ALPGPU_HIP(hipEventRecord(ctx->ev_fork, ctx->stream)); }
 	const bool plain = (ctx->decode_variant & 2) != 0;
 	int        rc    = ALPGPU_OK;
 	// Which launch.  A closed candidate is not free: the dispatcher hands out ~5.5 workgroups per nanosecond, so 1 Mi empty workgroups cost 0.19 ms — 10-17 % of a
@@ -460,6 +441,36 @@ static int decode_unhinted(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_ou
 		}
 	} else {
 		rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), 2, plain, 0, words, tag, 0u);
+	}
+	if (with_ahead) { // behind the decode's launch (decode_one says why); the kernel leaves at once when the plan says "no read-ahead for this column"
+		ALPGPU_HIP(hipStreamWaitEvent(ctx->init_stream, ctx->ev_fork, 0));
+		if (alpgpu::launch_read_ahead(ctx->init_stream, col, VB, words, tag, 0, 0, 0, ctx->wall_tick_ps, 0, ctx->read_ahead_grid, true) != ALPGPU_OK) {
+			return fail(ALPGPU_ERR_HIP, "read-ahead launch failed", hipGetLastError());
+		}
+		ALPGPU_HIP(hipEventRecord(ctx->ev_join, ctx->init_stream));
+	}
+	// the sums, for the next decode of this column: to page-locked memory behind an event that is only ever queried (enqueued BEHIND the decode: the copy delays nothing)
+	if (ctx->h_learn != nullptr) {
+		LearnSlot* l = learn_slot_of(ctx, col, VB);
+		if (!l) {
+			l               = &ctx->learn[ctx->learn_next];
+			ctx->learn_next = (ctx->learn_next + 1) % kLearnSlots;
+		}
+		// (a slot whose copy is still in flight — the same column decoded again before its sizes arrived, or a fifth unhinted column within microseconds — is left
+		//  alone: no host synchronisation here either; the earlier copy lands, or this column simply stays unhinted a little longer)
+		const bool busy = l->state == 1 && hipEventQuery(l->ev) != hipSuccess;
+		if (busy) {
+			(void)hipGetLastError();
+		} else {
+			l->key = col->d_vectors, l->d_packed = col->d_packed, l->n_vectors = col->n_vectors, l->value_bytes = VB, l->n_seg = n_seg;
+			l->state = 0;
+			if (hipMemcpyAsync(ctx->h_learn + static_cast<size_t>(l - ctx->learn) * 3 * kMaxSegments, words + alpgpu::kCtxWordSegments, 24ull * n_seg, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+			    hipEventRecord(l->ev, ctx->stream) == hipSuccess) {
+				l->state = 1;
+			} else {
+				(void)hipGetLastError(); // best effort: the column simply stays unhinted
+			}
+		}
 	}
 	if (with_ahead) { ALPGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
 	if (rc != ALPGPU_OK) { return fail(rc, "decode launch failed", hipGetLastError()); }
