@@ -22,6 +22,8 @@
 #include "launch.hpp"
 #include "search_device.hpp"
 
+#include <cstdlib>
+
 namespace alpgpu {
 
 #ifndef ALPGPU_ENC_PRIO
@@ -819,10 +821,291 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	if (lane == 0) { LEAN_ARG_DESCS[v] = d; }
 }
 
+// ---- the persistent, software-pipelined form (round 6; ALPGPU_OPT_ENCODE_PIPELINED) ---------------------------------------------------------------------------
+// A wavefront of k_encode_lean spends its ~14 us in three waits it cannot shorten — its input's round trip (2.5 us under load), its tile's ordered offset (2.6 us:
+// the slowest of ~60 predecessor tiles plus a trip across the fabric), the acknowledgement of its stores (2.4 us) — with ~2200 instructions in between, and a CU holds
+// three tiles.  The waits do not overlap because a workgroup lives for ONE tile.  Here a workgroup lives for many: it takes tiles from an in-order counter (one atomic
+// per tile, asked for two tiles ahead, so that its answer is never waited for), and the input of its NEXT tile is requested in front of the wait for the CURRENT
+// tile's offset: the two longest waits of a wavefront's life run side by side.  What a wavefront holds across the wait is the next tile's vector (32 VGPRs) where
+// k_encode_lean held the current one; a vector wider than the image (every ALP_RD vector) reads its input a second time for its second pass, as wavefront 0 always
+// did.  Same bytes: the same device functions in the same order per vector, the same status words and look-back (encode_lookback.hpp, told the launch's tile count).
+// Forward progress: tile t is taken by a workgroup that is resident, after tiles 0 .. t-1 were taken by workgroups that are resident (or done): the look-back never
+// waits for a tile nobody runs — which one-workgroup-per-tile launches only get from the dispatcher's habit of starting workgroups in order.  Every wait stays
+// bounded and the recovery route behind it, as before.
+// LDS words that a tile's wavefronts exchange come in three sets (iteration mod 3): the set of iteration i + 1 is cleared at the top of iteration i — last read behind
+// the barrier of iteration i - 2, which every wavefront left before it reached the barrier of iteration i - 1; first written behind the barrier of iteration i.  The tile
+// queue has three slots for the same reason.  ONE barrier per tile.
+// (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
+// OCC = wavefronts per SIMD the register budget admits: 6 (<= 80 VGPRs: three workgroups per CU) or 4 (<= 128: two per CU, nothing spilled)
+template <int OCC>
+__global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
+                                                                                    alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
+                                                                                    uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
+                                                                                    uint64_t packed_capacity_entry, uint64_t exc_capacity_entry, uint64_t v_first, uint64_t n_vectors_launch,
+                                                                                    const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states, uint32_t n_tiles,
+                                                                                    unsigned int* __restrict__ tile_counter) {
+	__builtin_amdgcn_s_setprio(ALPGPU_ENC_PRIO);
+	(void)descs_entry, (void)packed_entry, (void)excs_entry, (void)packed_capacity_entry, (void)exc_capacity_entry;
+	__shared__ LeanLds  lds[kFusedWaves];
+	__shared__ uint64_t s_size[3][kFusedWaves]; // iteration k uses set k % 3
+	__shared__ uint64_t s_excl[3];
+	__shared__ uint32_t s_count[3];
+	__shared__ uint32_t s_ready[3];
+	__shared__ uint32_t s_queue[3]; // tile of iteration k at s_queue[k % 3]
+	const int lane = lane_id();
+	const int wave = wave_in_wg();
+	uint64_t* buf  = lds[wave].buf;
+	// prologue: the first two tiles of this workgroup, both sets of exchange words
+	if (threadIdx.x == 0) {
+		const uint32_t a = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t b = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_queue[0] = a, s_queue[1] = b, s_queue[2] = 0xFFFFFFFFu;
+		s_count[0] = s_count[1] = s_count[2] = 0;
+		s_ready[0] = s_ready[1] = s_ready[2] = 0;
+		s_excl[0] = s_excl[1] = s_excl[2] = ~0ull;
+	}
+	__syncthreads();
+	const uint64_t base_p = totals[0], base_e = totals[1]; // bytes used by earlier launches of this column: constant while this launch runs
+	uint32_t tile = s_queue[0];
+	if (tile >= n_tiles) { return; } // workgroup-uniform: more workgroups than tiles
+	// the first tile's input and state poll
+	uint64_t vl   = static_cast<uint64_t>(tile) * kFusedWaves + wave;
+	bool     live = vl < n_vectors_launch;
+	uint64_t v    = v_first + vl;
+	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
+	uint32_t st_word = async_states ? rowgroup_state_poll_begin(rgp, lane) : reinterpret_cast<const uint32_t*>(rgp)[lane & 7];
+	VecIn    x       = load_vector_policy(in, live ? v : v_first, lane, true);
+#pragma unroll 1
+	for (uint32_t it = 0;; ++it) {
+		const int      set       = static_cast<int>(it % 3u);
+		const uint32_t next_tile = s_queue[(it + 1) % 3]; // (published behind the previous iteration's barrier, or by the prologue)
+		uint32_t       acquired  = 0xFFFFFFFFu;
+		if (threadIdx.x == 0) { // the tile after next: asked for now, looked at in front of this iteration's barrier
+			acquired = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// the set of the NEXT iteration: last used two iterations ago (every wavefront has passed a barrier since its last read of it), first
+			// written behind this iteration's barrier
+			const int clear = static_cast<int>((it + 1) % 3u);
+			s_count[clear]  = 0;
+			s_ready[clear]  = 0;
+			s_excl[clear]   = ~0ull;
+		}
+		bool                        state_ok = true;
+		const alpgpu_rowgroup_state st       = async_states ? rowgroup_state_poll_finish(rgp, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
+		if (!state_ok) { // wave-uniform
+			if (lane == 0) { status_store(totals + 3, 1ull); }
+			return;
+		}
+		alpgpu_vector_desc d;
+		d.packed_off = d.exc_off = 0;
+		d.base                   = 0;
+		d.bw = d.e = d.f = d.lbw = 0;
+		d.exc_cnt = d.scheme = 0;
+		uint64_t ballots[8][2];
+#pragma unroll
+		for (int m = 0; m < 8; ++m) { ballots[m][0] = ballots[m][1] = 0; }
+		int      cnt = 0;
+		uint64_t acc0 = 0, acc1 = 0;
+		uint64_t fill_minus_base = 0, base_plus_magic = 0;
+		uint32_t wide_steps = 0;
+		double   exp10 = 1.0, frac_f = 1.0;
+		if (live) {
+			d.scheme = st.scheme;
+			if (st.scheme == ALPGPU_SCHEME_ALP) {
+				int e, f;
+				if (st.k > 1) {
+					second_level_select(x, &st, reinterpret_cast<double*>(buf), lane, e, f);
+				} else {
+					e = st.combos[0];
+					f = st.combos[1];
+				}
+				LeanAlp R;
+				lean_analyze_alp(x, e, f, lane, R);
+				d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
+				cnt             = R.cnt;
+				wide_steps      = R.wide_steps;
+				fill_minus_base = static_cast<uint64_t>(R.filler) - static_cast<uint64_t>(R.base);
+				base_plus_magic = 0x4338000000000000ull + static_cast<uint64_t>(R.base);
+				exp10           = opaque_uniform(kExpArr[e]);
+				frac_f          = kFracArr[f];
+#pragma unroll
+				for (int m = 0; m < 8; ++m) { ballots[m][0] = R.ballot[m][0], ballots[m][1] = R.ballot[m][1]; }
+			} else {
+				LeanRd R;
+				lean_analyze_rd(x, st, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, async_states != 0);
+				d.bw = st.rd_rbw, d.lbw = st.rd_lbw;
+				cnt  = R.cnt;
+				acc0 = R.acc0, acc1 = R.acc1;
+#pragma unroll
+				for (int m = 0; m < 8; ++m) { ballots[m][0] = R.ballot[m][0], ballots[m][1] = R.ballot[m][1]; }
+			}
+			d.exc_cnt = static_cast<uint16_t>(cnt);
+		}
+		uint64_t my_p = 0, my_e = 0; // bytes
+		if (live) { record_sizes<8>(d, my_p, my_e); }
+		if (lane == 0) {
+			s_size[set][wave] = status_pack(0, my_p >> 7, my_e >> 3);
+			const uint32_t arrived = __hip_atomic_fetch_add(&s_count[set], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (arrived == kFusedWaves - 1) {
+				uint64_t aggregate = 0;
+#pragma unroll
+				for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[set][w]; }
+				status_store(status + tile, kFlagAggregate | aggregate);
+			}
+		}
+		// ---- pack (first window) and exception record into LDS ----
+		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
+		const int  bw  = d.bw;
+		LeanAlpPack A;
+		A.exp10 = exp10, A.frac_f = frac_f;
+		A.base_plus_magic = uniform_u64(base_plus_magic), A.fill_minus_base = uniform_u64(fill_minus_base);
+		A.wide_steps      = wide_steps;
+		const int  words_a = bw < kLeanImageWords ? bw : kLeanImageWords;
+		const bool wide_v  = bw > kLeanImageWords;
+		if (alp) {
+			if (!wide_v) {
+				lean_pack_alp<false>(buf, x, A, ballots, bw, 0, words_a, lane);
+			} else {
+				lean_pack_alp<true>(buf, x, A, ballots, bw, 0, kLeanImageWords, lane);
+			}
+		} else {
+			lean_pack_rd(buf, x, bw, 0, words_a, lane);
+		}
+		const uint32_t rec_off    = static_cast<uint32_t>(128 * words_a);
+		const bool     rec_staged = my_e <= kLeanBufBytes - rec_off;
+		const uint32_t val_bytes  = alp ? 8u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
+		uint8_t*       img        = reinterpret_cast<uint8_t*>(buf) + rec_off;
+		if (cnt > 0 && rec_staged) {
+			if (lane == 0) { reinterpret_cast<uint64_t*>(img)[(my_e >> 3) - 1] = 0ull; }
+			wave_lds_sync();
+			for_each_exception(ballots, lane, [&](int r, int m, int j) {
+				const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
+				if (alp) {
+					reinterpret_cast<uint64_t*>(img)[r] = bits;
+				} else {
+					reinterpret_cast<uint16_t*>(img)[r] = static_cast<uint16_t>(bits >> bw);
+				}
+				reinterpret_cast<uint16_t*>(img + val_bytes)[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
+			});
+			wave_lds_sync();
+		}
+		// ---- the next tile's input, in front of the wait for this tile's offset (wavefront 0: behind its look-back, whose status loads must not queue behind 8 KiB) ----
+		const bool     have_next = next_tile < n_tiles; // workgroup-uniform
+		const uint64_t vl_n      = static_cast<uint64_t>(next_tile) * kFusedWaves + wave;
+		const bool     live_n    = have_next && vl_n < n_vectors_launch;
+		const uint64_t v_n       = v_first + vl_n;
+		const alpgpu_rowgroup_state* rgp_n = rgs + (live_n ? v_n : v_first) / kRowgroup;
+		uint32_t st_word_n = 0;
+		VecIn    x_n;
+		if (wave != 0) {
+			if (have_next) {
+				st_word_n = async_states ? rowgroup_state_poll_begin(rgp_n, lane) : reinterpret_cast<const uint32_t*>(rgp_n)[lane & 7];
+				x_n       = load_vector_policy(in, live_n ? v_n : v_first, lane, true);
+			}
+		} else {
+			if (threadIdx.x == 0) { s_queue[(it + 2) % 3] = acquired; } // (asked for at the top of this iteration: long since there)
+			tile_lookback(tile, status, totals, s_size[set], &s_count[set], &s_excl[set], &s_ready[set], lane, spin_limit, nullptr, n_tiles);
+			if (have_next) {
+				st_word_n = async_states ? rowgroup_state_poll_begin(rgp_n, lane) : reinterpret_cast<const uint32_t*>(rgp_n)[lane & 7];
+				x_n       = load_vector_policy(in, live_n ? v_n : v_first, lane, true);
+			}
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the next tile's loads
+		const uint64_t mine_sz = lane < wave ? s_size[set][lane & (kFusedWaves - 1)] : 0ull;
+		const uint64_t local   = wave_sum_u64(mine_sz);
+		const uint64_t excl    = s_excl[set];
+		if (excl == ~0ull) { return; } // stalled: nothing of this tile is written, the workgroup ends (the recovery route redoes the column)
+		const uint64_t pre = excl + local;
+		d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
+		d.exc_off          = base_e + (pre & 0x7FFFFFFFull) * 8ull;
+		bool fits = true;
+		if (live && (d.packed_off + my_p > late_kernel_arg<uint64_t>(kArgPackedCap) || d.exc_off + my_e > late_kernel_arg<uint64_t>(kArgExcCap))) {
+			fits = false;
+			if (lane == 0) {
+				__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				late_kernel_arg<alpgpu_vector_desc*>(kArgDescs)[v] = empty_descriptor();
+			}
+		}
+		if (live && fits) {
+			uint8_t* dst = late_kernel_arg<uint8_t*>(kArgPacked) + d.packed_off;
+			uint8_t* rec = late_kernel_arg<uint8_t*>(kArgExcs) + d.exc_off;
+			if (cnt > 0) {
+				if (rec_staged) {
+					const uint64_t* img64 = reinterpret_cast<const uint64_t*>(img);
+					uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
+					const int       n_w   = static_cast<int>(my_e >> 3);
+					for (int w0 = 0; w0 < n_w; w0 += 256) {
+						uint64_t q[4];
+#pragma unroll
+						for (int k = 0; k < 4; ++k) {
+							const int w = w0 + 64 * k + lane;
+							q[k]        = w < n_w ? img64[w] : 0ull;
+						}
+#pragma unroll
+						for (int k = 0; k < 4; ++k) {
+							const int w = w0 + 64 * k + lane;
+							if (w < n_w) { __builtin_nontemporal_store(q[k], rec64 + w); }
+						}
+					}
+				} else { // a record larger than its staging room (rare): the vector is read again and the record written from it
+					const VecIn xr   = load_vector(in, v, lane);
+					uint16_t*   rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
+					for_each_exception(ballots, lane, [&](int r, int m, int j) {
+						const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? xr.x[m].x : xr.x[m].y));
+						if (alp) {
+							reinterpret_cast<uint64_t*>(rec)[r] = bits;
+						} else {
+							reinterpret_cast<uint16_t*>(rec)[r] = static_cast<uint16_t>(bits >> bw);
+						}
+						rpos[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
+					});
+					const int n_pos = static_cast<int>((my_e - val_bytes) >> 1);
+					if (cnt + lane < n_pos) { rpos[cnt + lane] = 0; }
+				}
+			}
+			lean_store_image(buf, 8 * words_a, reinterpret_cast<ull2v*>(dst), lane);
+			if (wide_v) { // words 32.. of every column pair, through the same image: the input once more (its registers hold the next tile's vector by now)
+				const VecIn xb = load_vector(in, v, lane);
+				wave_lds_sync();
+				const int words_b = bw - kLeanImageWords;
+				if (alp) {
+					lean_pack_alp<true>(buf, xb, A, ballots, bw, kLeanImageWords, words_b, lane);
+				} else {
+					lean_pack_rd(buf, xb, bw, kLeanImageWords, words_b, lane);
+				}
+				lean_store_image(buf, 8 * words_b, reinterpret_cast<ull2v*>(dst + kLeanImageBytes), lane);
+			}
+			if (!alp && lane < 32) {
+				uint32_t* out32 = reinterpret_cast<uint32_t*>(dst + 128ull * d.bw);
+				for (int k = 0; k < d.lbw; ++k) {
+					out32[32 * k + lane] = (static_cast<uint32_t>(acc0 >> (16 * k)) & 0xFFFFu) | ((static_cast<uint32_t>(acc1 >> (16 * k)) & 0xFFFFu) << 16);
+				}
+			}
+			if (lane == 0) { late_kernel_arg<alpgpu_vector_desc*>(kArgDescs)[v] = d; }
+		}
+		if (!have_next) { return; } // workgroup-uniform
+		wave_lds_sync(); // (this wavefront's reads of its image are issued before the next tile's pack writes it: one wavefront's LDS operations run in order)
+		tile = next_tile, vl = vl_n, live = live_n, v = v_n, rgp = rgp_n, st_word = st_word_n, x = x_n;
+	}
+}
+
 // the same launch sequence as launch_encode_fused_range (encode_kernels.hip) with the kernel above
 // search_words != nullptr: the tiles run the rowgroup search's (e, f) walk as work items in their look-back wait (SEARCH = 1); column_vectors = the whole column's
+// pipelined (ordered only): k_encode_pipe — persistent workgroups, three per CU, that take tiles from the counter word behind the status words (+ 2; zeroed with them)
 void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
-                          uint32_t spin_limit, uint32_t async_states, bool unordered, uint64_t column_vectors, uint64_t* search_words) {
+                          uint32_t spin_limit, uint32_t async_states, bool unordered, uint64_t column_vectors, uint64_t* search_words, int pipelined_workgroups) {
+	if (pipelined_workgroups > 0 && !unordered && search_words == nullptr) {
+		const unsigned grid = n_tiles < static_cast<unsigned>(pipelined_workgroups) ? n_tiles : static_cast<unsigned>(pipelined_workgroups);
+		unsigned int* counter = reinterpret_cast<unsigned int*>(d_workspace + lookback_words(n_tiles) + 2);
+		static const bool roomy = std::getenv("ALPGPU_ENCODE_PIPE_ROOMY") != nullptr; // A/B: the 128-register instance whatever the workgroup count
+		if (roomy || pipelined_workgroups <= 2 * 256) { // (two per CU or fewer: the instance with 128 registers)
+			hipLaunchKernelGGL(k_encode_pipe<4>, dim3(grid), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals,
+			                   col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states, n_tiles, counter);
+		} else {
+			hipLaunchKernelGGL(k_encode_pipe<6>, dim3(grid), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals,
+			                   col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states, n_tiles, counter);
+		}
+		return;
+	}
 	unsigned long long* sw = reinterpret_cast<unsigned long long*>(search_words);
 #define ALPGPU_LAUNCH_LEAN(U, S)                                                                                                                                            \
 	hipLaunchKernelGGL((k_encode_lean<U, S>), dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, \

@@ -31,6 +31,12 @@ case $step in
   PADS=0,6,14 run 200 decode_encoded.txt python tools/time_decode_encoded.py
   run 300 tests.txt python -m pytest tests/test_float_gpu.py tests/test_unhinted_gpu.py tests/test_decode_gpu.py -m gpu -x -q
   ;;
+4) # the persistent, software-pipelined encode: parity under both instances, then its timing; the float / unhinted tests that failed in call 3
+  ALPGPU_ENCODE_PIPELINED=3 run 400 tests_pipe3.txt python -m pytest tests/test_encode_gpu.py tests/test_async_init_gpu.py tests/test_recovery_gpu.py tests/test_reference_gpu.py -m gpu -x -q
+  ALPGPU_ENCODE_PIPELINED=2 run 400 tests_pipe2.txt python -m pytest tests/test_encode_gpu.py tests/test_async_init_gpu.py tests/test_recovery_gpu.py tests/test_reference_gpu.py -m gpu -x -q
+  run 300 encode.txt python tools/time_encode.py
+  run 300 tests.txt python -m pytest tests/test_unhinted_gpu.py tests/test_float_gpu.py tests/test_decode_gpu.py -m gpu -x -q
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
