@@ -856,10 +856,12 @@ __global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const dou
 	const int wave = wave_in_wg();
 	uint64_t* buf  = lds[wave].buf;
 	// prologue: the first two tiles of this workgroup, both sets of exchange words
+	constexpr uint32_t kPending = 0xFFFFFFFEu; // a queue slot whose tile has been asked for and not yet published
 	if (threadIdx.x == 0) {
-		const uint32_t a = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const uint32_t b = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		s_queue[0] = a, s_queue[1] = b, s_queue[2] = 0xFFFFFFFFu;
+		// ONE tile ahead, never two in a row for one workgroup: tile t + 1 must not sit queued behind tile t in the same workgroup while every other workgroup's
+		// look-back waits for its size (the first form took two tiles in its prologue and ran 3 x slower than the one-workgroup-per-tile kernel: call 4)
+		s_queue[0] = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_queue[1] = kPending, s_queue[2] = kPending;
 		s_count[0] = s_count[1] = s_count[2] = 0;
 		s_ready[0] = s_ready[1] = s_ready[2] = 0;
 		s_excl[0] = s_excl[1] = s_excl[2] = ~0ull;
@@ -878,10 +880,10 @@ __global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const dou
 #pragma unroll 1
 	for (uint32_t it = 0;; ++it) {
 		const int      set       = static_cast<int>(it % 3u);
-		const uint32_t next_tile = s_queue[(it + 1) % 3]; // (published behind the previous iteration's barrier, or by the prologue)
 		uint32_t       acquired  = 0xFFFFFFFFu;
-		if (threadIdx.x == 0) { // the tile after next: asked for now, looked at in front of this iteration's barrier
-			acquired = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (threadIdx.x == 0) { // the next tile: asked for now, published (LDS) behind this wavefront's analysis, looked at by every wavefront in front of its prefetch
+			acquired                = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s_queue[(it + 2) % 3] = kPending; // (the slot of the iteration after next: its last readers left the previous iteration's barrier)
 			// the set of the NEXT iteration: last used two iterations ago (every wavefront has passed a barrier since its last read of it), first
 			// written behind this iteration's barrier
 			const int clear = static_cast<int>((it + 1) % 3u);
@@ -952,6 +954,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const dou
 				status_store(status + tile, kFlagAggregate | aggregate);
 			}
 		}
+		if (threadIdx.x == 0) { __hip_atomic_store(&s_queue[(it + 1) % 3], acquired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // (asked for at the top of this iteration: there by now)
 		// ---- pack (first window) and exception record into LDS ----
 		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
 		const int  bw  = d.bw;
@@ -989,6 +992,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const dou
 			wave_lds_sync();
 		}
 		// ---- the next tile's input, in front of the wait for this tile's offset (wavefront 0: behind its look-back, whose status loads must not queue behind 8 KiB) ----
+		uint32_t next_tile;
+		while ((next_tile = __hip_atomic_load(&s_queue[(it + 1) % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kPending) { __builtin_amdgcn_s_sleep(1); } // (an LDS word; published long ago)
 		const bool     have_next = next_tile < n_tiles; // workgroup-uniform
 		const uint64_t vl_n      = static_cast<uint64_t>(next_tile) * kFusedWaves + wave;
 		const bool     live_n    = have_next && vl_n < n_vectors_launch;
@@ -1002,7 +1007,6 @@ __global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const dou
 				x_n       = load_vector_policy(in, live_n ? v_n : v_first, lane, true);
 			}
 		} else {
-			if (threadIdx.x == 0) { s_queue[(it + 2) % 3] = acquired; } // (asked for at the top of this iteration: long since there)
 			tile_lookback(tile, status, totals, s_size[set], &s_count[set], &s_excl[set], &s_ready[set], lane, spin_limit, nullptr, n_tiles);
 			if (have_next) {
 				st_word_n = async_states ? rowgroup_state_poll_begin(rgp_n, lane) : reinterpret_cast<const uint32_t*>(rgp_n)[lane & 7];

@@ -37,6 +37,11 @@ case $step in
   run 300 encode.txt python tools/time_encode.py
   run 300 tests.txt python -m pytest tests/test_unhinted_gpu.py tests/test_float_gpu.py tests/test_decode_gpu.py -m gpu -x -q
   ;;
+5) # the pipelined encode with tiles taken one ahead
+  ALPGPU_ENCODE_PIPELINED=2 run 400 tests_pipe2.txt python -m pytest tests/test_encode_gpu.py tests/test_async_init_gpu.py tests/test_recovery_gpu.py tests/test_reference_gpu.py -m gpu -x -q
+  run 300 encode.txt python tools/time_encode.py 1048576 mixed
+  ALPGPU_ENCODE_PIPE_ROOMY=1 run 300 encode_roomy.txt python tools/time_encode.py 1048576 mixed
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
