@@ -71,7 +71,7 @@ _sig("alpgpu_synchronize", _int, _vp)
 _sig("alpgpu_set_option", _int, _vp, _int, C.c_int64)
 OPT_DECODE_VECTORS_PER_WG, OPT_DECODE_PLAIN_STORES, OPT_ENCODE_TWO_PASS, OPT_DEBUG_FORCE_STALL, OPT_CONSUMER_PIPELINED, OPT_ENCODE_ASYNC_INIT, OPT_ENCODE_KERNEL, OPT_DECODE_PAIRING = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_DECODE_PATCH_AFTER, OPT_ENCODE_UNORDERED, OPT_DECODE_RESIDENCY_PAD = 9, 10, 11
-OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US, OPT_DECODE_SEGMENTS, OPT_DECODE_UNHINTED, OPT_ENCODE_TILE_SEARCH, OPT_ENCODE_PIPELINED = 12, 13, 14, 15, 16, 17
+OPT_DECODE_READ_AHEAD, OPT_DECODE_READ_AHEAD_US, OPT_DECODE_SEGMENTS, OPT_DECODE_UNHINTED = 12, 13, 14, 15
 ENCODE_KERNEL_LEAN, ENCODE_KERNEL_CLASSIC = 0, 1
 _sig("alpgpu_device_info", _int, _vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_u64))
 _sig("alpgpu_decode_vectors_per_wg", _int, _vp, C.POINTER(CColumn), _int)

@@ -112,9 +112,6 @@ int alpgpu_ctx_create(int device, alpgpu_ctx** out_ctx) {
 	ctx->decode_patch_shape = std::getenv("ALPGPU_DECODE_PATCH_SHAPE") ? std::atoi(std::getenv("ALPGPU_DECODE_PATCH_SHAPE")) : 1;
 	ctx->decode_pairing  = std::getenv("ALPGPU_DECODE_PAIRING") ? (std::atoi(std::getenv("ALPGPU_DECODE_PAIRING")) & 3) : 0; // (A/B runs)
 	ctx->encode_kernel   = std::getenv("ALPGPU_ENCODE_KERNEL") ? std::atoi(std::getenv("ALPGPU_ENCODE_KERNEL")) : ALPGPU_ENCODE_KERNEL_LEAN; // (A/B runs)
-	ctx->encode_pipelined = std::getenv("ALPGPU_ENCODE_PIPELINED") ? std::atoi(std::getenv("ALPGPU_ENCODE_PIPELINED")) : 0; // (A/B runs; workgroups per CU)
-	if (ctx->encode_pipelined < 0 || ctx->encode_pipelined > 8) { ctx->encode_pipelined = 0; }
-	ctx->encode_tile_search = std::getenv("ALPGPU_ENCODE_TILE_SEARCH") ? std::atoi(std::getenv("ALPGPU_ENCODE_TILE_SEARCH")) : 0; // (A/B runs)
 	ctx->encode_unordered = std::getenv("ALPGPU_ENCODE_UNORDERED") ? std::atoi(std::getenv("ALPGPU_ENCODE_UNORDERED")) : 0; // (A/B runs)
 	ctx->read_ahead      = std::getenv("ALPGPU_DECODE_READ_AHEAD") ? std::atoi(std::getenv("ALPGPU_DECODE_READ_AHEAD")) : -1; // -1: by the column (read_ahead_for)
 	ctx->read_ahead_us   = std::getenv("ALPGPU_READ_AHEAD_US") ? std::atoi(std::getenv("ALPGPU_READ_AHEAD_US")) : 0; // 0: by the vectors' width (alpgpu_decode_f64)
@@ -261,14 +258,6 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 		return ALPGPU_OK;
 	case ALPGPU_OPT_ENCODE_UNORDERED:
 		ctx->encode_unordered = value ? 1 : 0;
-		return ALPGPU_OK;
-	case ALPGPU_OPT_ENCODE_PIPELINED:
-		if (value < 0 || value > 8) { return fail(ALPGPU_ERR_INVALID, "encode pipelined: 0 (one workgroup per tile) or 1..8 persistent workgroups per CU (3 = what fits)"); }
-		ctx->encode_pipelined = static_cast<int>(value);
-		return ALPGPU_OK;
-	case ALPGPU_OPT_ENCODE_TILE_SEARCH:
-		if (value < 0 || value > 1) { return fail(ALPGPU_ERR_INVALID, "encode tile search: 0 (the persistent search kernel beside the encode) or 1 (the tiles run the candidate walk in their look-back wait)"); }
-		ctx->encode_tile_search = static_cast<int>(value);
 		return ALPGPU_OK;
 	case ALPGPU_OPT_DECODE_UNHINTED:
 		if (value < 0 || value > 2) { return fail(ALPGPU_ERR_INVALID, "unhinted decode: 0 (as before round 6), 1 (sizes summed on the stream, read-ahead planned on the device, learned for the next decode) or 2 (1 + every candidate shape launched, gated)"); }

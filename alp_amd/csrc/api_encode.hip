@@ -58,9 +58,7 @@ static int encode_vectors_f64(alpgpu_ctx* ctx, const double* d_in, uint64_t n_ve
 	if (ctx->encode_two_pass) {
 		rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus);
 	} else {
-		const int kernel = ctx->encode_kernel | ((ctx->encode_unordered && ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN) ? alpgpu::kEncodeUnorderedFlag : 0) |
-		                   ((ctx->encode_tile_search && ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN) ? alpgpu::kEncodeTileSearchFlag : 0) |
-		                   ((ctx->encode_pipelined && ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN && !ctx->encode_unordered) ? (alpgpu::kEncodePipelinedFlag | ((ctx->encode_pipelined * ctx->n_cus) << 16)) : 0);
+		const int kernel = ctx->encode_kernel | ((ctx->encode_unordered && ctx->encode_kernel == ALPGPU_ENCODE_KERNEL_LEAN) ? alpgpu::kEncodeUnorderedFlag : 0);
 		rc = alpgpu::launch_encode_fused(ctx->stream, d_in, n_vectors, col, ws, ctx->force_stall != 0, async_states, ctx->ev_join, ctx->ev_head, kernel); // (waits for / joins the search's stream)
 		if (rc == ALPGPU_OK) { rc = alpgpu::launch_encode_vectors(ctx->stream, d_in, n_vectors, col, ws, ctx->n_cus, col->d_totals + 6); }
 	}

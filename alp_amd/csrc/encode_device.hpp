@@ -54,8 +54,6 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src_lane) {
 	return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) { return __longlong_as_double(readlane_i64(__double_as_longlong(v), src_lane)); }
-
 // A wave-uniform lane mask (a ballot) as this lane's predicate: the SGPR pair is used directly as the select mask.
 __device__ __forceinline__ bool lane_in(uint64_t ballot) { return __builtin_amdgcn_inverse_ballot_w64(ballot); }
 

@@ -608,13 +608,10 @@ int launch_traffic_probe(hipStream_t stream, const void* d_in, void* d_out, uint
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
-// words of workspace in front of the tile search's per-rowgroup words (encode_lean_kernels.hip: SEARCH): the status words of the longest launch, rounded up
-uint64_t encode_search_words_offset() { return (lookback_words(kFusedMaxVectors / kFusedWaves) + 16 + 15) / 16 * 16; }
 uint64_t encode_workspace_bytes(uint64_t n_vectors) {
 	const uint64_t two_pass = ((n_vectors + kScanTile - 1) / kScanTile) * 16 + 16;
 	const uint64_t per_launch = n_vectors < kFusedMaxVectors ? n_vectors : kFusedMaxVectors;
-	uint64_t       fused    = lookback_words((per_launch + kFusedWaves - 1) / kFusedWaves) * 8 + 64;
-	if (n_vectors >= 1024ull * kRowgroup) { fused = (encode_search_words_offset() + 16ull * ((n_vectors + kRowgroup - 1) / kRowgroup) + 16) * 8; } // + 16 words per rowgroup behind them
+	const uint64_t fused    = lookback_words((per_launch + kFusedWaves - 1) / kFusedWaves) * 8 + 64;
 	return two_pass > fused ? two_pass : fused;
 }
 
@@ -628,32 +625,21 @@ int launch_encode_reset_totals(hipStream_t stream, const alpgpu_column* col) {
 // async_head / async_join (with async_states): the events behind the head of the search and behind the persistent rest; the stream
 // waits for the first in front of the first encode launch, for the second in front of the LAST finish kernel, which then clears the tags
 void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
-                          uint32_t spin_limit, uint32_t async_states, bool unordered, uint64_t column_vectors, uint64_t* search_words, int pipelined_workgroups);
-// (encode_lean_kernels.hip)
+                          uint32_t spin_limit, uint32_t async_states, bool unordered); // encode_lean_kernels.hip
 int launch_encode_fused_range(hipStream_t stream, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t v_first, uint64_t n_range,
                               bool force_stall, bool async_states, hipEvent_t async_join, hipEvent_t async_head, int kernel) {
-	// the tiles run the rowgroup search's candidate walk themselves (kEncodeTileSearchFlag; lean kernel, whole long columns): their words, zero at launch
-	uint64_t* search_words = nullptr;
-	if ((kernel & kEncodeTileSearchFlag) && (kernel & 0xFF) == ALPGPU_ENCODE_KERNEL_LEAN && v_first == 0 && n_range == col->n_vectors && col->n_vectors >= 1024ull * kRowgroup) {
-		search_words = d_workspace + encode_search_words_offset();
-		if (hipMemsetAsync(search_words, 0, 128ull * ((col->n_vectors + kRowgroup - 1) / kRowgroup), stream) != hipSuccess) { return ALPGPU_ERR_HIP; }
-	}
-	// the persistent, software-pipelined form of the lean kernel (kEncodePipelinedFlag, bits 16.. = workgroups to launch: three per CU)
-	const int pipelined_workgroups = (kernel & kEncodePipelinedFlag) ? (kernel >> 16) : 0;
-	kernel &= ~(kEncodeTileSearchFlag | kEncodePipelinedFlag | ~0xFFFF);
 	for (uint64_t first = v_first; first < v_first + n_range; first += kFusedMaxVectors) {
 		const uint64_t left     = v_first + n_range - first;
 		const uint64_t n_launch = left < kFusedMaxVectors ? left : kFusedMaxVectors;
 		const uint64_t n_tiles  = (n_launch + kFusedWaves - 1) / kFusedWaves;
-		if (hipMemsetAsync(d_workspace, 0, (lookback_words(n_tiles) + 4) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; } // (+ the unordered form's counter word, the pipelined form's tile counter)
+		if (hipMemsetAsync(d_workspace, 0, (lookback_words(n_tiles) + 1) * 8, stream) != hipSuccess) { return ALPGPU_ERR_HIP; } // (+ the unordered form's counter word)
 		if (async_states && first == v_first && async_head != nullptr) { // the head of the search (side stream) is what the first tiles need
 			if (hipStreamWaitEvent(stream, async_head, 0) != hipSuccess) { return ALPGPU_ERR_HIP; }
 		}
 		const bool      unordered = kernel == (ALPGPU_ENCODE_KERNEL_LEAN | kEncodeUnorderedFlag); // (the lean kernel only; force_stall has nothing to stall there)
 		const uint64_t* reserve   = unordered ? d_workspace + lookback_words(n_tiles) : nullptr;
 		if ((kernel & ~kEncodeUnorderedFlag) == ALPGPU_ENCODE_KERNEL_LEAN) {
-			launch_k_encode_lean(stream, static_cast<unsigned>(n_tiles), d_in, col, d_workspace, first, n_launch, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u, unordered, col->n_vectors,
-			                     search_words, pipelined_workgroups);
+			launch_k_encode_lean(stream, static_cast<unsigned>(n_tiles), d_in, col, d_workspace, first, n_launch, force_stall ? 0u : kSpinLimit, async_states ? 1u : 0u, unordered);
 		} else {
 			hipLaunchKernelGGL(k_encode_fused, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups,
 			                   col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals, col->packed_capacity, col->exc_capacity, first,

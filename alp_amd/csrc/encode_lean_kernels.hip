@@ -20,9 +20,6 @@
 #include "encode_device.hpp"
 #include "encode_lookback.hpp"
 #include "launch.hpp"
-#include "search_device.hpp"
-
-#include <cstdlib>
 
 namespace alpgpu {
 
@@ -370,29 +367,12 @@ __device__ __forceinline__ void lean_store_image(const uint64_t* image, int n_un
 // writes, descriptor for descriptor; only WHERE a tile's bytes lie in the two streams follows the order in which tiles finished their analysis
 // instead of vector order (the eight vectors of a tile stay together, in order).  A decoder never notices: descriptors carry offsets.
 // (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
-// ---- the rowgroup search as work items of the tiles themselves (round 6; SEARCH != 0) -----------------------------------------------
-// Beside the encode the persistent search kernel holds one of a CU's three tile slots for two thirds of the encode's time (~0.30 ms of 3.0 exposed), while every
-// tile's worker wavefronts sit parked waiting for the ordered offset.  The (e, f) walk — 27 items per rowgroup: (sampled vector, round of 64 candidates) over 32
-// samples — is what the search's time goes to (0.57 of 0.58 ms on ALP columns).  With SEARCH the tiles run those items themselves, between "sizes published" and
-// "offset needed": the global tile t = 25 B + j (25 tiles = 200 vectors = two rowgroups) works on rowgroups 2 B + kTileSearchAhead and + 1; tile j takes items 2 j and
-// 2 j + 1, tiles 6, 12, 18, 24 one of the four left over as well.  An item's samples (one 8-byte load per lane, issued behind the size publication so that the pack
-// covers the trip) are walked as v_readlane broadcasts, the candidate's multipliers come from two 19-entry tables held one entry per lane (ds_bpermute).
-//   First form (call 2, profiles/r06_encode_levers.txt): one wavefront per item, all 32 samples: ~1.9 us per item against the ~0.8 us of wait that hides it — the vector
-//   encode alone 2.67 -> 3.09 ms (unordered 2.33 -> 3.03), i.e. slower than the shipped encode WITH its search beside it (2.92-2.99).
-//   This form: an item is SPLIT over the wavefronts of a group (three wavefronts x 11 samples; two x 16 in the tiles that carry three items), whose partial counts
-//   and ranges meet in LDS (ds_add / ds_max / ds_min on 64 candidates x {count, max, min}, associative: the same integers) at the barrier every wavefront of the tile
-//   takes anyway; behind it the group's first wavefront turns them into the item's key — (size << 8 | candidate) + 1 in 21 bits, all-ones for "no candidate" — and ADDS
-//   it into the field of its round in the sampled vector's word (three fields per 64-bit word, zero at launch): one fire-and-forget atomic, nobody waits for it.
-constexpr uint32_t kTileSearchAhead = 256; // rowgroups between an item's tile and its rowgroup (= the head the search kernel does in front: api_encode.hip)
-constexpr int      kTileSearchWordsPerRg = 16; // 9 used: one per sampled vector
-
-template <bool UNORDERED, int SEARCH = 0>
+template <bool UNORDERED>
 __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_lean(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                                     alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
                                                                                     uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
                                                                                     uint64_t packed_capacity_entry, uint64_t exc_capacity_entry, uint64_t v_first, uint64_t n_vectors_launch,
-                                                                                    const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states,
-                                                                                    uint64_t column_vectors, unsigned long long* __restrict__ search_words) {
+                                                                                    const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states) {
 	__builtin_amdgcn_s_setprio(ALPGPU_ENC_PRIO);
 #ifdef ALPGPU_LEAN_LATE_ARGS
 	(void)descs_entry, (void)packed_entry, (void)excs_entry, (void)packed_capacity_entry, (void)exc_capacity_entry;
@@ -413,9 +393,6 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	__shared__ uint64_t s_excl;
 	__shared__ uint32_t s_count;
 	__shared__ uint32_t s_ready;
-	// SEARCH: where the partial results of an item's wavefronts meet (three groups x 64 candidates)
-	__shared__ uint32_t  s_item_cnt[SEARCH != 0 ? 3 : 1][64];
-	__shared__ long long s_item_max[SEARCH != 0 ? 3 : 1][64], s_item_min[SEARCH != 0 ? 3 : 1][64];
 	const int           lane = lane_id();
 	const int           wave = wave_in_wg();
 	const uint64_t      tile = blockIdx.x;
@@ -466,13 +443,6 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		s_count = 0;
 		s_ready = 0;
 		s_excl  = ~0ull;
-	}
-	if constexpr (SEARCH != 0) {
-		if (threadIdx.x < 192) {
-			s_item_cnt[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
-			s_item_max[threadIdx.x >> 6][threadIdx.x & 63] = INT64_MIN;
-			s_item_min[threadIdx.x >> 6][threadIdx.x & 63] = INT64_MAX;
-		}
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the loads in flight
 #endif
@@ -559,48 +529,6 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	}
 	const uint64_t base_p = totals[0], base_e = totals[1];
 
-	// SEARCH: this wavefront's share of an item, if any — its samples and the two tables are asked for HERE (the pack and the record below cover the trip)
-	bool     has_item = false, item_lead = false;
-	int      item_round = 0, item_group = 0, item_s0 = 0, item_s1 = 0;
-	uint64_t item_word = 0; // index into search_words
-	double   item_smp = 0.0, item_tab_e = 0.0, item_tab_f = 0.0;
-	uint32_t item_ef = 0;
-	if constexpr (SEARCH != 0) {
-		if (wave >= 1 && wave <= 6) { // wave-uniform
-			const uint64_t gtile = (v_first >> 3) + tile; // (launches begin on multiples of 8 vectors)
-			const uint64_t blk   = gtile / 25u;
-			const int      j     = static_cast<int>(gtile - blk * 25u);
-			const bool     three = j != 0 && j % 6 == 0;    // tiles 6, 12, 18, 24 carry one of the items 50..53 as well: groups of two wavefronts there
-			const int      gsz   = three ? 2 : 3;
-			const int      group = (wave - 1) / gsz, part = (wave - 1) - group * gsz;
-			const int      item  = group == 0 ? 2 * j : (group == 1 ? 2 * j + 1 : 49 + j / 6);
-			{
-				const uint64_t rg_i  = 2 * blk + kTileSearchAhead + static_cast<uint64_t>(item / 27);
-				const int      q     = item % 27;
-				const int      sv    = q / 3;
-				const uint64_t rg_v0 = rg_i * kRowgroup;
-				if (rg_v0 < column_vectors) {
-					const uint64_t nv   = column_vectors - rg_v0 < kRowgroup ? column_vectors - rg_v0 : kRowgroup;
-					const int      n_sv = static_cast<int>((nv + 11) / 12);
-					if (sv < n_sv) {
-						has_item   = true;
-						item_lead  = part == 0;
-						item_group = group;
-						item_s0    = part * 32 / gsz, item_s1 = (part + 1) * 32 / gsz;
-						item_round = q - 3 * sv;
-						item_word  = rg_i * kTileSearchWordsPerRg + static_cast<uint64_t>(sv);
-						item_smp   = in[(rg_v0 + 12ull * sv) * kVec + 32ull * (lane & 31)];
-						item_tab_e = kExpArr[lane < 24 ? lane : 23];
-						item_tab_f = kFracArr[lane < 21 ? lane : 20];
-						const int c = lane + 64 * item_round;
-						const int ci = c < PrecF64::kNumCombos ? c : PrecF64::kNumCombos - 1;
-						item_ef    = static_cast<uint32_t>(kCombos64.e[ci]) | (static_cast<uint32_t>(kCombos64.f[ci]) << 8);
-					}
-				}
-			}
-		}
-	}
-
 	ALPGPU_LEAN_STOP(5, base_p + base_e + my_p + my_e);
 	LookbackFirst look_first {0, 0};
 	(void)look_first;
@@ -662,36 +590,6 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	}
 
 	ALPGPU_LEAN_STOP(7, buf[lane] + buf[600 + lane] + base_p);
-	// ---- SEARCH: the item, in what would be this wavefront's wait for the tile's offset ----
-	bool reload_x = false;
-	if constexpr (SEARCH != 0) {
-		if (has_item) { // wave-uniform
-			const int e = static_cast<int>(item_ef & 0xFFu), f = static_cast<int>(item_ef >> 8);
-			PrecF64::Coef k;
-			k.exp10         = __shfl(item_tab_e, e);
-			k.frac_f        = __shfl(item_tab_f, f);
-			k.frac_e        = __shfl(item_tab_f, e);
-			k.fact_d        = __shfl(item_tab_e, f); // 10^f <= 10^18: exact
-			k.sentinel_from = f == 0 ? kUpperLimit : __builtin_inf();
-			k.fact          = kFactArr[f]; // (read by the rare literal arm only)
-			PrecF64::Acc acc;
-			PrecF64::start(acc);
-#pragma unroll 1
-			for (int s0 = item_s0; s0 + 2 <= item_s1; s0 += 2) { // (two per trip, spelled out: the unroller declines this body — a rarely taken branch inside)
-				PrecF64::step(acc, readlane_f64(item_smp, s0), k);
-				PrecF64::step(acc, readlane_f64(item_smp, s0 + 1), k);
-			}
-			if ((item_s1 - item_s0) & 1) { PrecF64::step(acc, readlane_f64(item_smp, item_s1 - 1), k); }
-			PrecF64::finish(acc);
-			if (acc.non_exc != 0) { // this wavefront's samples into the group's meeting place (LDS; the tile's barrier below publishes them to the group's first wavefront)
-				__hip_atomic_fetch_add(&s_item_cnt[item_group][lane], static_cast<uint32_t>(acc.non_exc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_max(&s_item_max[item_group][lane], static_cast<long long>(acc.mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_min(&s_item_min[item_group][lane], static_cast<long long>(acc.mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-			reload_x = true;
-		}
-	}
-
 	// ---- the ordered offset ----
 	// Wavefront 0 finds the tile's offset; the others have nothing left to do but their stores, so they PARK at a workgroup barrier until it
 	// arrives there too (k_encode_fused keeps its workers spinning on an LDS word: they used to pack meanwhile; here a spinning worker would
@@ -722,22 +620,6 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	const uint64_t mine_sz = lane < wave ? s_size[lane & (kFusedWaves - 1)] : 0ull;
 	const uint64_t local   = wave_sum_u64(mine_sz);
 	const uint64_t excl    = s_excl;
-	if constexpr (SEARCH != 0) {
-		if (has_item && item_lead) { // the item's key from what its wavefronts left in LDS (all of them are past the barrier above)
-			const int       non_exc = static_cast<int>(s_item_cnt[item_group][lane]);
-			const long long mx = s_item_max[item_group][lane], mn = s_item_min[item_group][lane];
-			uint32_t        key = 0xFFFFFFFFu;
-			if (lane + 64 * item_round < PrecF64::kNumCombos && non_exc >= 2) { // encoder.hpp:182
-				const uint32_t size = 32u * static_cast<uint32_t>(PrecF64::bits(mx, mn)) + static_cast<uint32_t>(32 - non_exc) * (PrecF64::kExcBits + 16u);
-				key                 = (size << 8) | static_cast<uint32_t>(lane + 64 * item_round);
-			}
-			key = wave_min_u32(key);
-			if (lane == 0) {
-				const unsigned long long field = key == 0xFFFFFFFFu ? 0x1FFFFFull : static_cast<unsigned long long>(key) + 1ull;
-				__hip_atomic_fetch_add(search_words + item_word, field << (21 * item_round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
-	}
 	if (excl == ~0ull) { return; } // stalled: nothing of this tile is written
 	const uint64_t pre = excl + local;
 	d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
@@ -801,7 +683,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 		// The input is still in the registers of wavefronts 1..7, which only slept on an LDS word meanwhile; wavefront 0 ran the look-back, whose
 		// registers the input would not fit beside (the budget of three tiles per CU): it reads its vector again (an L2 / Infinity-Cache hit).
 		VecIn xb = x;
-		if (wave == 0 || reload_x) { xb = load_vector(in, v, lane); } // (a wavefront that ran a search item gave its input's registers to it)
+		if (wave == 0) { xb = load_vector(in, v, lane); }
 		wave_lds_sync();
 		const int words_b = bw - kLeanImageWords;
 		if (alp) {
@@ -821,305 +703,16 @@ __global__ __launch_bounds__(64 * kFusedWaves, ALPGPU_LEAN_OCC) void k_encode_le
 	if (lane == 0) { LEAN_ARG_DESCS[v] = d; }
 }
 
-// ---- the persistent, software-pipelined form (round 6; ALPGPU_OPT_ENCODE_PIPELINED) ---------------------------------------------------------------------------
-// A wavefront of k_encode_lean spends its ~14 us in three waits it cannot shorten — its input's round trip (2.5 us under load), its tile's ordered offset (2.6 us:
-// the slowest of ~60 predecessor tiles plus a trip across the fabric), the acknowledgement of its stores (2.4 us) — with ~2200 instructions in between, and a CU holds
-// three tiles.  The waits do not overlap because a workgroup lives for ONE tile.  Here a workgroup lives for many: it takes tiles from an in-order counter (one atomic
-// per tile, asked for two tiles ahead, so that its answer is never waited for), and the input of its NEXT tile is requested in front of the wait for the CURRENT
-// tile's offset: the two longest waits of a wavefront's life run side by side.  What a wavefront holds across the wait is the next tile's vector (32 VGPRs) where
-// k_encode_lean held the current one; a vector wider than the image (every ALP_RD vector) reads its input a second time for its second pass, as wavefront 0 always
-// did.  Same bytes: the same device functions in the same order per vector, the same status words and look-back (encode_lookback.hpp, told the launch's tile count).
-// Forward progress: tile t is taken by a workgroup that is resident, after tiles 0 .. t-1 were taken by workgroups that are resident (or done): the look-back never
-// waits for a tile nobody runs — which one-workgroup-per-tile launches only get from the dispatcher's habit of starting workgroups in order.  Every wait stays
-// bounded and the recovery route behind it, as before.
-// LDS words that a tile's wavefronts exchange come in three sets (iteration mod 3): the set of iteration i + 1 is cleared at the top of iteration i — last read behind
-// the barrier of iteration i - 2, which every wavefront left before it reached the barrier of iteration i - 1; first written behind the barrier of iteration i.  The tile
-// queue has three slots for the same reason.  ONE barrier per tile.
-// (the first nine parameters are read by offset — alp_device.hpp: kArgDescs .. kArgExcCap — keep their order and types)
-// OCC = wavefronts per SIMD the register budget admits: 6 (<= 80 VGPRs: three workgroups per CU) or 4 (<= 128: two per CU, nothing spilled)
-template <int OCC>
-__global__ __launch_bounds__(64 * kFusedWaves, OCC) void k_encode_pipe(const double* __restrict__ in, const alpgpu_rowgroup_state* __restrict__ rgs,
-                                                                                    alpgpu_vector_desc* __restrict__ descs_entry, uint8_t* __restrict__ packed_entry,
-                                                                                    uint8_t* __restrict__ excs_entry, uint64_t* __restrict__ status, uint64_t* __restrict__ totals,
-                                                                                    uint64_t packed_capacity_entry, uint64_t exc_capacity_entry, uint64_t v_first, uint64_t n_vectors_launch,
-                                                                                    const uint16_t* __restrict__ rd_order, uint32_t spin_limit, uint32_t async_states, uint32_t n_tiles,
-                                                                                    unsigned int* __restrict__ tile_counter) {
-	__builtin_amdgcn_s_setprio(ALPGPU_ENC_PRIO);
-	(void)descs_entry, (void)packed_entry, (void)excs_entry, (void)packed_capacity_entry, (void)exc_capacity_entry;
-	__shared__ LeanLds  lds[kFusedWaves];
-	__shared__ uint64_t s_size[3][kFusedWaves]; // iteration k uses set k % 3
-	__shared__ uint64_t s_excl[3];
-	__shared__ uint32_t s_count[3];
-	__shared__ uint32_t s_ready[3];
-	__shared__ uint32_t s_queue[3]; // tile of iteration k at s_queue[k % 3]
-	const int lane = lane_id();
-	const int wave = wave_in_wg();
-	uint64_t* buf  = lds[wave].buf;
-	// prologue: the first two tiles of this workgroup, both sets of exchange words
-	constexpr uint32_t kPending = 0xFFFFFFFEu; // a queue slot whose tile has been asked for and not yet published
-	if (threadIdx.x == 0) {
-		// ONE tile ahead, never two in a row for one workgroup: tile t + 1 must not sit queued behind tile t in the same workgroup while every other workgroup's
-		// look-back waits for its size (the first form took two tiles in its prologue and ran 3 x slower than the one-workgroup-per-tile kernel: call 4)
-		s_queue[0] = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		s_queue[1] = kPending, s_queue[2] = kPending;
-		s_count[0] = s_count[1] = s_count[2] = 0;
-		s_ready[0] = s_ready[1] = s_ready[2] = 0;
-		s_excl[0] = s_excl[1] = s_excl[2] = ~0ull;
-	}
-	__syncthreads();
-	const uint64_t base_p = totals[0], base_e = totals[1]; // bytes used by earlier launches of this column: constant while this launch runs
-	uint32_t tile = s_queue[0];
-	if (tile >= n_tiles) { return; } // workgroup-uniform: more workgroups than tiles
-	// the first tile's input and state poll
-	uint64_t vl   = static_cast<uint64_t>(tile) * kFusedWaves + wave;
-	bool     live = vl < n_vectors_launch;
-	uint64_t v    = v_first + vl;
-	const alpgpu_rowgroup_state* rgp = rgs + (live ? v : v_first) / kRowgroup;
-	uint32_t st_word = async_states ? rowgroup_state_poll_begin(rgp, lane) : reinterpret_cast<const uint32_t*>(rgp)[lane & 7];
-	VecIn    x       = load_vector_policy(in, live ? v : v_first, lane, true);
-#pragma unroll 1
-	for (uint32_t it = 0;; ++it) {
-		const int      set       = static_cast<int>(it % 3u);
-		uint32_t       acquired  = 0xFFFFFFFFu;
-		if (threadIdx.x == 0) { // the next tile: asked for now, published (LDS) behind this wavefront's analysis, looked at by every wavefront in front of its prefetch
-			acquired                = __hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			s_queue[(it + 2) % 3] = kPending; // (the slot of the iteration after next: its last readers left the previous iteration's barrier)
-			// the set of the NEXT iteration: last used two iterations ago (every wavefront has passed a barrier since its last read of it), first
-			// written behind this iteration's barrier
-			const int clear = static_cast<int>((it + 1) % 3u);
-			s_count[clear]  = 0;
-			s_ready[clear]  = 0;
-			s_excl[clear]   = ~0ull;
-		}
-		bool                        state_ok = true;
-		const alpgpu_rowgroup_state st       = async_states ? rowgroup_state_poll_finish(rgp, st_word, lane, spin_limit >> 4, state_ok) : unpack_rowgroup_state(st_word);
-		if (!state_ok) { // wave-uniform
-			if (lane == 0) { status_store(totals + 3, 1ull); }
-			return;
-		}
-		alpgpu_vector_desc d;
-		d.packed_off = d.exc_off = 0;
-		d.base                   = 0;
-		d.bw = d.e = d.f = d.lbw = 0;
-		d.exc_cnt = d.scheme = 0;
-		uint64_t ballots[8][2];
-#pragma unroll
-		for (int m = 0; m < 8; ++m) { ballots[m][0] = ballots[m][1] = 0; }
-		int      cnt = 0;
-		uint64_t acc0 = 0, acc1 = 0;
-		uint64_t fill_minus_base = 0, base_plus_magic = 0;
-		uint32_t wide_steps = 0;
-		double   exp10 = 1.0, frac_f = 1.0;
-		if (live) {
-			d.scheme = st.scheme;
-			if (st.scheme == ALPGPU_SCHEME_ALP) {
-				int e, f;
-				if (st.k > 1) {
-					second_level_select(x, &st, reinterpret_cast<double*>(buf), lane, e, f);
-				} else {
-					e = st.combos[0];
-					f = st.combos[1];
-				}
-				LeanAlp R;
-				lean_analyze_alp(x, e, f, lane, R);
-				d.base = R.base, d.bw = static_cast<uint8_t>(R.bw), d.e = static_cast<uint8_t>(e), d.f = static_cast<uint8_t>(f);
-				cnt             = R.cnt;
-				wide_steps      = R.wide_steps;
-				fill_minus_base = static_cast<uint64_t>(R.filler) - static_cast<uint64_t>(R.base);
-				base_plus_magic = 0x4338000000000000ull + static_cast<uint64_t>(R.base);
-				exp10           = opaque_uniform(kExpArr[e]);
-				frac_f          = kFracArr[f];
-#pragma unroll
-				for (int m = 0; m < 8; ++m) { ballots[m][0] = R.ballot[m][0], ballots[m][1] = R.ballot[m][1]; }
-			} else {
-				LeanRd R;
-				lean_analyze_rd(x, st, lane, R, rd_order ? rd_order + (v / kRowgroup) * ALPGPU_RD_ORDER_STRIDE : nullptr, async_states != 0);
-				d.bw = st.rd_rbw, d.lbw = st.rd_lbw;
-				cnt  = R.cnt;
-				acc0 = R.acc0, acc1 = R.acc1;
-#pragma unroll
-				for (int m = 0; m < 8; ++m) { ballots[m][0] = R.ballot[m][0], ballots[m][1] = R.ballot[m][1]; }
-			}
-			d.exc_cnt = static_cast<uint16_t>(cnt);
-		}
-		uint64_t my_p = 0, my_e = 0; // bytes
-		if (live) { record_sizes<8>(d, my_p, my_e); }
-		if (lane == 0) {
-			s_size[set][wave] = status_pack(0, my_p >> 7, my_e >> 3);
-			const uint32_t arrived = __hip_atomic_fetch_add(&s_count[set], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (arrived == kFusedWaves - 1) {
-				uint64_t aggregate = 0;
-#pragma unroll
-				for (int w = 0; w < kFusedWaves; ++w) { aggregate += s_size[set][w]; }
-				status_store(status + tile, kFlagAggregate | aggregate);
-			}
-		}
-		if (threadIdx.x == 0) { __hip_atomic_store(&s_queue[(it + 1) % 3], acquired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // (asked for at the top of this iteration: there by now)
-		// ---- pack (first window) and exception record into LDS ----
-		const bool alp = d.scheme == ALPGPU_SCHEME_ALP;
-		const int  bw  = d.bw;
-		LeanAlpPack A;
-		A.exp10 = exp10, A.frac_f = frac_f;
-		A.base_plus_magic = uniform_u64(base_plus_magic), A.fill_minus_base = uniform_u64(fill_minus_base);
-		A.wide_steps      = wide_steps;
-		const int  words_a = bw < kLeanImageWords ? bw : kLeanImageWords;
-		const bool wide_v  = bw > kLeanImageWords;
-		if (alp) {
-			if (!wide_v) {
-				lean_pack_alp<false>(buf, x, A, ballots, bw, 0, words_a, lane);
-			} else {
-				lean_pack_alp<true>(buf, x, A, ballots, bw, 0, kLeanImageWords, lane);
-			}
-		} else {
-			lean_pack_rd(buf, x, bw, 0, words_a, lane);
-		}
-		const uint32_t rec_off    = static_cast<uint32_t>(128 * words_a);
-		const bool     rec_staged = my_e <= kLeanBufBytes - rec_off;
-		const uint32_t val_bytes  = alp ? 8u * static_cast<uint32_t>(cnt) : 2u * static_cast<uint32_t>(cnt);
-		uint8_t*       img        = reinterpret_cast<uint8_t*>(buf) + rec_off;
-		if (cnt > 0 && rec_staged) {
-			if (lane == 0) { reinterpret_cast<uint64_t*>(img)[(my_e >> 3) - 1] = 0ull; }
-			wave_lds_sync();
-			for_each_exception(ballots, lane, [&](int r, int m, int j) {
-				const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? x.x[m].x : x.x[m].y));
-				if (alp) {
-					reinterpret_cast<uint64_t*>(img)[r] = bits;
-				} else {
-					reinterpret_cast<uint16_t*>(img)[r] = static_cast<uint16_t>(bits >> bw);
-				}
-				reinterpret_cast<uint16_t*>(img + val_bytes)[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
-			});
-			wave_lds_sync();
-		}
-		// ---- the next tile's input, in front of the wait for this tile's offset (wavefront 0: behind its look-back, whose status loads must not queue behind 8 KiB) ----
-		uint32_t next_tile;
-		while ((next_tile = __hip_atomic_load(&s_queue[(it + 1) % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kPending) { __builtin_amdgcn_s_sleep(1); } // (an LDS word; published long ago)
-		const bool     have_next = next_tile < n_tiles; // workgroup-uniform
-		const uint64_t vl_n      = static_cast<uint64_t>(next_tile) * kFusedWaves + wave;
-		const bool     live_n    = have_next && vl_n < n_vectors_launch;
-		const uint64_t v_n       = v_first + vl_n;
-		const alpgpu_rowgroup_state* rgp_n = rgs + (live_n ? v_n : v_first) / kRowgroup;
-		uint32_t st_word_n = 0;
-		VecIn    x_n;
-		if (wave != 0) {
-			if (have_next) {
-				st_word_n = async_states ? rowgroup_state_poll_begin(rgp_n, lane) : reinterpret_cast<const uint32_t*>(rgp_n)[lane & 7];
-				x_n       = load_vector_policy(in, live_n ? v_n : v_first, lane, true);
-			}
-		} else {
-			tile_lookback(tile, status, totals, s_size[set], &s_count[set], &s_excl[set], &s_ready[set], lane, spin_limit, nullptr, n_tiles);
-			if (have_next) {
-				st_word_n = async_states ? rowgroup_state_poll_begin(rgp_n, lane) : reinterpret_cast<const uint32_t*>(rgp_n)[lane & 7];
-				x_n       = load_vector_policy(in, live_n ? v_n : v_first, lane, true);
-			}
-		}
-		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // not __syncthreads(): its fence would wait for the next tile's loads
-		const uint64_t mine_sz = lane < wave ? s_size[set][lane & (kFusedWaves - 1)] : 0ull;
-		const uint64_t local   = wave_sum_u64(mine_sz);
-		const uint64_t excl    = s_excl[set];
-		if (excl == ~0ull) { return; } // stalled: nothing of this tile is written, the workgroup ends (the recovery route redoes the column)
-		const uint64_t pre = excl + local;
-		d.packed_off       = base_p + ((pre >> 31) & 0x7FFFFFFFull) * 128ull;
-		d.exc_off          = base_e + (pre & 0x7FFFFFFFull) * 8ull;
-		bool fits = true;
-		if (live && (d.packed_off + my_p > late_kernel_arg<uint64_t>(kArgPackedCap) || d.exc_off + my_e > late_kernel_arg<uint64_t>(kArgExcCap))) {
-			fits = false;
-			if (lane == 0) {
-				__hip_atomic_store(totals + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				late_kernel_arg<alpgpu_vector_desc*>(kArgDescs)[v] = empty_descriptor();
-			}
-		}
-		if (live && fits) {
-			uint8_t* dst = late_kernel_arg<uint8_t*>(kArgPacked) + d.packed_off;
-			uint8_t* rec = late_kernel_arg<uint8_t*>(kArgExcs) + d.exc_off;
-			if (cnt > 0) {
-				if (rec_staged) {
-					const uint64_t* img64 = reinterpret_cast<const uint64_t*>(img);
-					uint64_t*       rec64 = reinterpret_cast<uint64_t*>(rec);
-					const int       n_w   = static_cast<int>(my_e >> 3);
-					for (int w0 = 0; w0 < n_w; w0 += 256) {
-						uint64_t q[4];
-#pragma unroll
-						for (int k = 0; k < 4; ++k) {
-							const int w = w0 + 64 * k + lane;
-							q[k]        = w < n_w ? img64[w] : 0ull;
-						}
-#pragma unroll
-						for (int k = 0; k < 4; ++k) {
-							const int w = w0 + 64 * k + lane;
-							if (w < n_w) { __builtin_nontemporal_store(q[k], rec64 + w); }
-						}
-					}
-				} else { // a record larger than its staging room (rare): the vector is read again and the record written from it
-					const VecIn xr   = load_vector(in, v, lane);
-					uint16_t*   rpos = reinterpret_cast<uint16_t*>(rec + val_bytes);
-					for_each_exception(ballots, lane, [&](int r, int m, int j) {
-						const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(j == 0 ? xr.x[m].x : xr.x[m].y));
-						if (alp) {
-							reinterpret_cast<uint64_t*>(rec)[r] = bits;
-						} else {
-							reinterpret_cast<uint16_t*>(rec)[r] = static_cast<uint16_t>(bits >> bw);
-						}
-						rpos[r] = static_cast<uint16_t>(128 * m + 2 * lane + j);
-					});
-					const int n_pos = static_cast<int>((my_e - val_bytes) >> 1);
-					if (cnt + lane < n_pos) { rpos[cnt + lane] = 0; }
-				}
-			}
-			lean_store_image(buf, 8 * words_a, reinterpret_cast<ull2v*>(dst), lane);
-			if (wide_v) { // words 32.. of every column pair, through the same image: the input once more (its registers hold the next tile's vector by now)
-				const VecIn xb = load_vector(in, v, lane);
-				wave_lds_sync();
-				const int words_b = bw - kLeanImageWords;
-				if (alp) {
-					lean_pack_alp<true>(buf, xb, A, ballots, bw, kLeanImageWords, words_b, lane);
-				} else {
-					lean_pack_rd(buf, xb, bw, kLeanImageWords, words_b, lane);
-				}
-				lean_store_image(buf, 8 * words_b, reinterpret_cast<ull2v*>(dst + kLeanImageBytes), lane);
-			}
-			if (!alp && lane < 32) {
-				uint32_t* out32 = reinterpret_cast<uint32_t*>(dst + 128ull * d.bw);
-				for (int k = 0; k < d.lbw; ++k) {
-					out32[32 * k + lane] = (static_cast<uint32_t>(acc0 >> (16 * k)) & 0xFFFFu) | ((static_cast<uint32_t>(acc1 >> (16 * k)) & 0xFFFFu) << 16);
-				}
-			}
-			if (lane == 0) { late_kernel_arg<alpgpu_vector_desc*>(kArgDescs)[v] = d; }
-		}
-		if (!have_next) { return; } // workgroup-uniform
-		wave_lds_sync(); // (this wavefront's reads of its image are issued before the next tile's pack writes it: one wavefront's LDS operations run in order)
-		tile = next_tile, vl = vl_n, live = live_n, v = v_n, rgp = rgp_n, st_word = st_word_n, x = x_n;
-	}
-}
-
 // the same launch sequence as launch_encode_fused_range (encode_kernels.hip) with the kernel above
-// search_words != nullptr: the tiles run the rowgroup search's (e, f) walk as work items in their look-back wait (SEARCH = 1); column_vectors = the whole column's
-// pipelined (ordered only): k_encode_pipe — persistent workgroups, three per CU, that take tiles from the counter word behind the status words (+ 2; zeroed with them)
 void launch_k_encode_lean(hipStream_t stream, unsigned n_tiles, const double* d_in, const alpgpu_column* col, uint64_t* d_workspace, uint64_t first, uint64_t n_launch,
-                          uint32_t spin_limit, uint32_t async_states, bool unordered, uint64_t column_vectors, uint64_t* search_words, int pipelined_workgroups) {
-	if (pipelined_workgroups > 0 && !unordered && search_words == nullptr) {
-		const unsigned grid = n_tiles < static_cast<unsigned>(pipelined_workgroups) ? n_tiles : static_cast<unsigned>(pipelined_workgroups);
-		unsigned int* counter = reinterpret_cast<unsigned int*>(d_workspace + lookback_words(n_tiles) + 2);
-		static const bool roomy = std::getenv("ALPGPU_ENCODE_PIPE_ROOMY") != nullptr; // A/B: the 128-register instance whatever the workgroup count
-		if (roomy || pipelined_workgroups <= 2 * 256) { // (two per CU or fewer: the instance with 128 registers)
-			hipLaunchKernelGGL(k_encode_pipe<4>, dim3(grid), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals,
-			                   col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states, n_tiles, counter);
-		} else {
-			hipLaunchKernelGGL(k_encode_pipe<6>, dim3(grid), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, col->d_totals,
-			                   col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states, n_tiles, counter);
-		}
-		return;
-	}
-	unsigned long long* sw = reinterpret_cast<unsigned long long*>(search_words);
-#define ALPGPU_LAUNCH_LEAN(U, S)                                                                                                                                            \
-	hipLaunchKernelGGL((k_encode_lean<U, S>), dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace, \
-	                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states, column_vectors, sw)
-	if (sw != nullptr) {
-		if (unordered) { ALPGPU_LAUNCH_LEAN(true, 1); } else { ALPGPU_LAUNCH_LEAN(false, 1); }
+                          uint32_t spin_limit, uint32_t async_states, bool unordered) {
+	if (unordered) {
+		hipLaunchKernelGGL(k_encode_lean<true>, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
+		                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
 	} else {
-		if (unordered) { ALPGPU_LAUNCH_LEAN(true, 0); } else { ALPGPU_LAUNCH_LEAN(false, 0); }
+		hipLaunchKernelGGL(k_encode_lean<false>, dim3(n_tiles), dim3(64 * kFusedWaves), 0, stream, d_in, col->d_rowgroups, col->d_vectors, col->d_packed, col->d_exc, d_workspace,
+		                   col->d_totals, col->packed_capacity, col->exc_capacity, first, n_launch, col->d_rd_order, spin_limit, async_states);
 	}
-#undef ALPGPU_LAUNCH_LEAN
 }
 
 } // namespace alpgpu

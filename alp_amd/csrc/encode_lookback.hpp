@@ -96,12 +96,11 @@ __device__ __forceinline__ LookbackFirst tile_lookback_begin(uint64_t tile, cons
 template <int N_SIZES = kFusedWaves>
 __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restrict__ status, uint64_t* __restrict__ totals, const uint64_t* s_size,
                                               uint32_t* s_count, uint64_t* s_excl, uint32_t* s_ready, int lane, uint32_t spin_limit = kSpinLimit,
-                                              const LookbackFirst* begun = nullptr, uint32_t n_tiles = 0) {
-	if (n_tiles == 0) { n_tiles = gridDim.x; } // (one workgroup per tile; the persistent form — encode_lean_kernels.hip: k_encode_pipe — says how many tiles the launch has)
-	uint64_t*      bstatus = status + n_tiles;
+                                              const LookbackFirst* begun = nullptr) {
+	uint64_t*      bstatus = status + gridDim.x;
 	const uint64_t block   = tile / kBlockTiles;
 	const int      i       = static_cast<int>(tile % kBlockTiles);
-	const bool     closes  = i == kBlockTiles - 1 || tile == n_tiles - 1; // this tile completes its block
+	const bool     closes  = i == kBlockTiles - 1 || tile == gridDim.x - 1; // this tile completes its block
 	bool           stalled = false;
 	uint32_t       spins   = 0;
 	// the stall flag of another tile is a far-side read like the status words: looked at every 16th unsuccessful round only
@@ -234,7 +233,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t tile, uint64_t* __restric
 			const uint64_t excl = base + local;
 			if (closes && block != 0) { status_store(bstatus + block, kFlagPrefix | (excl + aggregate)); }
 			*s_excl = excl;
-			if (tile == n_tiles - 1) { // running totals of the column, published by the finish kernel
+			if (tile == gridDim.x - 1) { // running totals of the column, published by the finish kernel
 				const uint64_t incl = excl + aggregate;
 				totals[4]           = totals[0] + ((incl >> 31) & 0x7FFFFFFFull) * 128ull;
 				totals[5]           = totals[1] + (incl & 0x7FFFFFFFull) * 8ull;

@@ -73,8 +73,6 @@ struct alpgpu_ctx {
 	hipEvent_t  ev_fork, ev_head, ev_join;
 	int         encode_kernel;   // ALPGPU_ENCODE_KERNEL_LEAN (default) / _CLASSIC
 	int         encode_unordered; // ALPGPU_OPT_ENCODE_UNORDERED: tiles reserve their stream bytes with one atomic add (lean kernel, device columns only)
-	int         encode_tile_search; // ALPGPU_OPT_ENCODE_TILE_SEARCH: the tiles of the lean kernel run the rowgroup search's candidate walk in their look-back wait (round 6)
-	int         encode_pipelined;   // ALPGPU_OPT_ENCODE_PIPELINED: persistent workgroups per CU of the software-pipelined lean kernel (0: one workgroup per tile; round 6)
 	int         decode_pairing;  // ALPGPU_OPT_DECODE_PAIRING: 0 auto, 1..3 -> k_decode_pairs
 	int         decode_pairs_auto; // the auto rule may pick the pair kernel (ALPGPU_DECODE_PAIRS_AUTO=0 for A/B runs)
 	int         decode_pad_kib;    // ALPGPU_OPT_DECODE_RESIDENCY_PAD: KiB of unused dynamic LDS per decode workgroup (-1: chosen from the column's hints)

@@ -64,12 +64,6 @@ uint64_t encode_workspace_bytes(uint64_t n_vectors);
 // or-ed into `kernel` (lean kernel only): tiles reserve their bytes with one atomic add instead of waiting for their predecessors' sizes
 // (ALPGPU_OPT_ENCODE_UNORDERED; encode_lean_kernels.hip)
 constexpr int kEncodeUnorderedFlag = 0x100;
-// or-ed into `kernel` (lean kernel, whole columns of >= 1024 rowgroups): the tiles run the rowgroup search's candidate walk as work items in their look-back wait
-// (ALPGPU_OPT_ENCODE_TILE_SEARCH; encode_lean_kernels.hip)
-constexpr int kEncodeTileSearchFlag = 0x200;
-// or-ed into `kernel` (lean kernel, ordered): the persistent, software-pipelined form (ALPGPU_OPT_ENCODE_PIPELINED; encode_lean_kernels.hip: k_encode_pipe); bits 16.. = workgroups
-constexpr int kEncodePipelinedFlag = 0x400;
-uint64_t encode_search_words_offset();
 // single pass (force_stall: debug, every look-back that has to wait gives up — exercises the recovery route)
 // kernel: ALPGPU_ENCODE_KERNEL_LEAN (encode_lean_kernels.hip: 6 KiB of LDS and <= 72 VGPRs per wavefront, three tiles per CU) or _CLASSIC (k_encode_fused)
 int launch_encode_fused(hipStream_t stream, const double* d_in, uint64_t n_vectors, const alpgpu_column* col, uint64_t* d_workspace, bool force_stall = false,

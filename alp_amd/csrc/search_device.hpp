@@ -1,6 +1,6 @@
 // search_device.hpp — the (e, f) candidate walk of the rowgroup search (alp::encoder<PT>::find_top_k_combinations, /root/reference include/alp/encoder.hpp:139-235),
-// shared by the search kernels (init_kernels.hip) and — round 6 — by the work items the double encode's tiles run in their look-back wait
-// (encode_lean_kernels.hip: ALPGPU_OPT_ENCODE_TILE_SEARCH).  The candidate order (e = 18..0, f = e..0) and the reference's update rule make the winner "the first
+// used by the search kernels (init_kernels.hip); a header of its own since round 6, when the double encode's tiles ran the walk as work items in their look-back
+// wait (an experiment that lost: profiles/r06_encode_levers.txt, the code in profiles/r06_encode_experiments.diff).  The candidate order (e = 18..0, f = e..0) and the reference's update rule make the winner "the first
 // candidate in that order with the minimum estimated size", i.e. the minimum of (size << 8 | candidate index).
 #pragma once
 #include "alp_device_f32.hpp"

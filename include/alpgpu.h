@@ -245,14 +245,6 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  *   0  one vector per workgroup (float: two), no read-ahead, nothing learned: as before round 6.
  * No host synchronisation in any mode.  Same bytes. */
 #define ALPGPU_OPT_DECODE_UNHINTED 15
-/* ALPGPU_OPT_ENCODE_TILE_SEARCH (double columns under ALPGPU_ENCODE_KERNEL_LEAN, whole columns of >= 1024 rowgroups; round 6): 1 = the encode's tiles run the rowgroup
- * search's (e, f) candidate walk themselves, as work items between "sizes published" and "offset needed" (the wait for the ordered offset), instead of a persistent
- * search kernel that holds one of a CU's three tile slots beside them.  Same bytes.  DESIGN.md §3.2, profiles/r06_encode_levers.txt. */
-#define ALPGPU_OPT_ENCODE_TILE_SEARCH 16
-/* ALPGPU_OPT_ENCODE_PIPELINED (double columns under ALPGPU_ENCODE_KERNEL_LEAN, ordered form; round 6): n = 1..8 — the single-pass encode as PERSISTENT workgroups, n per CU
- * (3 = what a CU holds), that take tiles from an in-order counter and request the NEXT tile's input in front of the wait for the CURRENT tile's ordered offset (the two
- * longest waits of a wavefront's life side by side).  0 = one workgroup per tile.  Same bytes.  DESIGN.md §3.2, profiles/r06_encode_levers.txt. */
-#define ALPGPU_OPT_ENCODE_PIPELINED 17
 int         alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value);
 /* the launch shape alpgpu_decode_f64 (is_f32 = 0) or alpgpu_decode_f32 (1) would use for this column now: vectors per decode
  * workgroup (1, 2 or 4), from ALPGPU_OPT_DECODE_VECTORS_PER_WG and the column's size hints; negative on bad arguments */

@@ -31,33 +31,9 @@ for kind in kinds:
     ctx.encode(x, col)
     pb, eb, ov = ctx.column_totals(col)
     alg = bench.encode_alg_bytes(n, pb, eb)
-    ts = {(u, t): [] for u in (0, 1) for t in (0, 1)}  # vectors alone (states ready), with / without the tiles' search items (ALPGPU_OPT_ENCODE_TILE_SEARCH)
-    for rep in range(3):
-        for u in (0, 1):
-            for t in (0, 1):
-                ctx.set_option(capi.OPT_ENCODE_UNORDERED, u)
-                ctx.set_option(capi.OPT_ENCODE_TILE_SEARCH, t)
-                ts[(u, t)].append(bench.time_launches(lambda: ctx.encode_vectors(x, col), 5, 2)[0])
-    ctx.set_option(capi.OPT_ENCODE_TILE_SEARCH, 0)
-    ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
-    vs[0].append(min(ts[(0, 0)])), vs[1].append(min(ts[(1, 0)]))
-    # the persistent, software-pipelined form (ALPGPU_OPT_ENCODE_PIPELINED = workgroups per CU): the whole encode (search beside) and the vectors alone, ordered
-    pp = {w: ([], []) for w in (0, 2, 3, 4)}
-    for rep in range(3):
-        for w in pp:
-            ctx.set_option(capi.OPT_ENCODE_PIPELINED, w)
-            pp[w][0].append(bench.time_launches(lambda: ctx.encode(x, col), 5, 2)[0])
-            pp[w][1].append(bench.time_launches(lambda: ctx.encode_vectors(x, col), 5, 2)[0])
-    ok = {}
-    for w in pp:
-        ctx.set_option(capi.OPT_ENCODE_PIPELINED, w)
-        ctx.encode(x, col)
-        ctx.decode(col, out)
-        torch.cuda.synchronize()
-        ok[w] = bool(torch.equal(out.view(torch.int64), x.view(torch.int64)))
-    ctx.set_option(capi.OPT_ENCODE_PIPELINED, 0)
-    print(f"{kind}: pipelined (workgroups per CU: whole encode ms / vectors alone ms / round trip): " + " | ".join(f"{w}: " + " ".join(f"{v:.3f}" for v in pp[w][0]) + " / " + " ".join(f"{v:.3f}" for v in pp[w][1]) + f" / {ok[w]}" for w in pp), flush=True)
-    print(f"{kind}: vectors alone (states ready), ms: " + " | ".join(f"unordered={u} tile_search={t}: " + " ".join(f"{v:.3f}" for v in ts[(u, t)]) for u in (0, 1) for t in (0, 1)), flush=True)
+    for u in (0, 1):
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, u)
+        vs[u].append(bench.time_launches(lambda: ctx.encode_vectors(x, col), 5, 2)[0])
     ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
     ctx.encode(x, col)
     ctx.decode(col, out)
