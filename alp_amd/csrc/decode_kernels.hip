@@ -43,7 +43,10 @@ constexpr int kStepsPerWave = 8 / kDecWaves;
 #define ALPGPU_DECODE_BATCH 4 // steps whose words are requested together (decode_vector_quarters)
 #endif
 constexpr int kStageBytes   = 8704; // >= 63*128 (RD right) + 3*128 (RD left) + 128 pad, and >= 64*128 + 128 (ALP bw 64)
-constexpr int kExcStage     = 128;  // 8-byte exception values staged in LDS per vector (512 2-byte ALP_RD ones); the rest are read from HBM on use
+#ifndef ALPGPU_EXC_STAGE
+#define ALPGPU_EXC_STAGE 128 // (A/B builds: 256 — round 6, profiles/r06_decode_policy.txt)
+#endif
+constexpr int kExcStage     = ALPGPU_EXC_STAGE;  // 8-byte exception values staged in LDS per vector (four times as many 2-byte ALP_RD ones); the rest are read from HBM on use
 constexpr uint32_t kExcStageBytes = 8u * kExcStage;
 
 template <int STAGE>
@@ -626,8 +629,11 @@ __device__ __forceinline__ uint32_t issue_vector_loads(LDS& L, const alpgpu_vect
 	if (cnt > 0) { // wave-uniform
 		const uint32_t val_bytes = (is_alp ? 8u : 2u) * static_cast<uint32_t>(cnt);
 		const int      dwords    = static_cast<int>(((val_bytes < kExcStageBytes ? val_bytes : kExcStageBytes) + 3u) >> 2); // (records are 8-byte multiples)
-		static_assert(kExcStageBytes / 4 <= T, "one load per thread covers the stage");
+		static_assert(kExcStageBytes / 4 <= 2 * T, "two loads per thread cover the stage");
 		if (tid < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + tid, reinterpret_cast<uint32_t*>(L.excv) + 64 * wave, 4, 0, 0); }
+		if constexpr (kExcStageBytes / 4 > T) {
+			if (tid + T < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + T + tid, reinterpret_cast<uint32_t*>(L.excv) + T + 64 * wave, 4, 0, 0); }
+		}
 		if (tid < cnt) { pos = reinterpret_cast<const uint16_t*>(rec + val_bytes)[tid]; }
 	}
 	return pos;

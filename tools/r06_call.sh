@@ -42,6 +42,13 @@ case $step in
   run 300 encode.txt python tools/time_encode.py 1048576 mixed
   ALPGPU_ENCODE_PIPE_ROOMY=1 run 300 encode_roomy.txt python tools/time_encode.py 1048576 mixed
   ;;
+6) # a 256-entry exception stage in the double decode (A/B library), the decode of encoder output in both; then the whole suite and the bench line on the tree as it is
+  PADS=0,6 run 200 decode_encoded.txt python tools/time_decode_encoded.py
+  ALPGPU_LIB=build/variants/libalpgpu_r06_exc256.so PADS=0,6 run 200 decode_encoded_exc256.txt python tools/time_decode_encoded.py
+  ALPGPU_LIB=build/variants/libalpgpu_r06_exc256.so run 300 tests_exc256.txt python -m pytest tests/test_decode_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q
+  run 600 tests.txt python -m pytest tests -m gpu -x -q
+  run 400 bench.txt python bench.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
