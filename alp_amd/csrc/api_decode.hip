@@ -96,7 +96,14 @@ static int decode_variant_for(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 			pad_kib = bits > 8.5 ? 3 : 0;
 		}
 	}
-	return (variant & 7) | (pairing << 3) | (pad_kib << 8);
+	// exception-heavy columns (more exceptions per vector than the 128-entry stage holds, on average): the instance with the 256-entry stage (decode_kernels.hip:
+	// DecodeLdsManyExc; one vector per workgroup, non-temporal stores): 0.72 -> 0.77 on bench.py's 10 %-exceptions column (call 6)
+	int many_exc = 0;
+	if (ctx->decode_auto && pairing == 0 && (variant & 7) == 1 && col->n_vectors != 0 && static_cast<double>(col->exc_bytes_hint) >= 10.0 * 128.0 * static_cast<double>(col->n_vectors) &&
+	    !(col->alp_rd_rowgroups_hint != 0 && 2.0 * static_cast<double>(col->alp_rd_rowgroups_hint - 1) * 100.0 > static_cast<double>(col->n_vectors))) {
+		many_exc = 64;
+	}
+	return (variant & 7) | (pairing << 3) | many_exc | (pad_kib << 8);
 }
 
 // Float columns (round 6): vectors per workgroup — 2 (the bytes in flight of one double vector), FOUR for columns of narrow vectors whose sizes are known, what

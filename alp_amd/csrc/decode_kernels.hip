@@ -49,15 +49,21 @@ constexpr int kStageBytes   = 8704; // >= 63*128 (RD right) + 3*128 (RD left) + 
 constexpr int kExcStage     = ALPGPU_EXC_STAGE;  // 8-byte exception values staged in LDS per vector (four times as many 2-byte ALP_RD ones); the rest are read from HBM on use
 constexpr uint32_t kExcStageBytes = 8u * kExcStage;
 
-template <int STAGE>
+template <int STAGE, int EXC = kExcStage>
 struct __attribute__((aligned(16))) DecodeLdsT {
 	static constexpr bool kPrefixInLds = false; // exception lookup by ds_bpermute (exception_hits)
 	static constexpr int  kStage       = STAGE;
+	static constexpr uint32_t kExcBytes = 8u * EXC;
 	uint8_t  stage[STAGE];
 	uint32_t mask[32];
-	uint8_t  excv[kExcStageBytes]; // the head of the exception record as it lies in the stream (its values come first), brought in by LDS-DMA
+	uint8_t  excv[kExcBytes]; // the head of the exception record as it lies in the stream (its values come first), brought in by LDS-DMA
 };
 using DecodeLds = DecodeLdsT<kStageBytes>;
+// Round 6: columns whose vectors carry MORE exceptions than the 128-entry stage holds on average (bench.py's 10 %-exceptions column: 187 per vector) decode every
+// value beyond the stage with a load from HBM in the unpack loop (the run-time form of decode_vector_quarters).  A 256-entry stage lifts that column from 0.72 to 0.77
+// of the HBM peak — and costs every OTHER column 2-6 % (1 KiB more LDS per vector: city_temperature 0.78 -> 0.74, nyc29 0.81 -> 0.78; call 6), so it is an instance
+// of its own, launched for columns whose hints say so (api_decode.hip: decode_variant_for, variant bit 6).
+using DecodeLdsManyExc = DecodeLdsT<kStageBytes, 2 * kExcStage>;
 // Round 4: FOUR narrow vectors per workgroup.  With two, a column of <= 16-bit vectors sits on a plateau of 0.69-0.73 of the HBM peak whatever its
 // width (profiles/r04_decode_floor.txt): what bounds it is the bytes in flight per CU — 16 vectors, each two dependent round trips — and the full
 // 8.5 KiB stage per vector is what caps a CU at two vectors x eight workgroups.  A stage of 2.25 KiB (17 bits + the unit row the unpack reads
@@ -93,7 +99,7 @@ __device__ __forceinline__ ExcMask load_exception_mask(const LDS& L, int lane) {
 // ADDRESSES and issues one flat load (slower, and it waits for every counter).
 template <int VAL_BYTES, class LDS>
 __device__ __forceinline__ uint64_t fetch_exception(const LDS& L, const uint8_t* __restrict__ rec, int rank, bool all_staged) {
-	constexpr int kStaged = static_cast<int>(kExcStageBytes) / VAL_BYTES;
+	constexpr int kStaged = static_cast<int>(LDS::kExcBytes) / VAL_BYTES;
 	const int     at      = rank < kStaged ? rank : kStaged - 1;
 	uint64_t      v;
 	if constexpr (VAL_BYTES == 8) {
@@ -386,7 +392,7 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 	// exceptions, which are looked up in the wavefront's slot table instead (patch_pair_from_table)
 	const int      bw       = d.bw;
 	const int      cnt      = d.exc_cnt;
-	const bool     all_staged = cnt <= static_cast<int>(kExcStageBytes) / (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2); // wave-uniform
+	const bool     all_staged = cnt <= static_cast<int>(LDS::kExcBytes) / (d.scheme == ALPGPU_SCHEME_ALP ? 8 : 2); // wave-uniform
 	const int      a        = lane & 7;
 	const int      r0       = lane >> 3;
 	// The pair (row, columns 2a, 2a + 1) out of its two stream words (alp_device.hpp: unpack_pair_u64), in two halves: the reads of a whole
@@ -628,10 +634,10 @@ __device__ __forceinline__ uint32_t issue_vector_loads(LDS& L, const alpgpu_vect
 	const int cnt = record_elsewhere ? 0 : d.exc_cnt; // (record_elsewhere: the vector's exceptions are patched in after its stores, issue_patch_loads)
 	if (cnt > 0) { // wave-uniform
 		const uint32_t val_bytes = (is_alp ? 8u : 2u) * static_cast<uint32_t>(cnt);
-		const int      dwords    = static_cast<int>(((val_bytes < kExcStageBytes ? val_bytes : kExcStageBytes) + 3u) >> 2); // (records are 8-byte multiples)
-		static_assert(kExcStageBytes / 4 <= 2 * T, "two loads per thread cover the stage");
+		const int      dwords    = static_cast<int>(((val_bytes < LDS::kExcBytes ? val_bytes : LDS::kExcBytes) + 3u) >> 2); // (records are 8-byte multiples)
+		static_assert(LDS::kExcBytes / 4 <= 2 * T, "two loads per thread cover the stage");
 		if (tid < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + tid, reinterpret_cast<uint32_t*>(L.excv) + 64 * wave, 4, 0, 0); }
-		if constexpr (kExcStageBytes / 4 > T) {
+		if constexpr (LDS::kExcBytes / 4 > T) {
 			if (tid + T < dwords) { __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(rec) + T + tid, reinterpret_cast<uint32_t*>(L.excv) + T + 64 * wave, 4, 0, 0); }
 		}
 		if (tid < cnt) { pos = reinterpret_cast<const uint16_t*>(rec + val_bytes)[tid]; }
@@ -917,6 +923,7 @@ struct __attribute__((aligned(16))) SinkWaveLds {
 	uint8_t  stage[ALPGPU_SINK_STAGE + 128]; // + the unit row past the end that the unpack reads and masks off
 #endif
 	uint32_t mask[32];
+	static constexpr uint32_t kExcBytes = kExcStageBytes;
 	uint8_t  excv[kExcStageBytes];
 	uint32_t pref[32]; // exceptions in front of mask word i
 };
@@ -1074,6 +1081,8 @@ int launch_decode_column(hipStream_t stream, const alpgpu_column* col, double* d
 			hipLaunchKernelGGL((k_decode_column<2, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else if (V == 2) {
 			hipLaunchKernelGGL((k_decode_column<2, false>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
+		} else if ((variant & 64) && nt) { // one vector per workgroup, the 256-entry exception stage (columns of exception-heavy vectors)
+			hipLaunchKernelGGL((k_decode_column<1, true, kSinkStore, DecodeLdsManyExc>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else if (nt) {
 			hipLaunchKernelGGL((k_decode_column<1, true>), grid, block, pad_lds, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, off, 0.0, 0.0, patch_max, progress, progress_tag);
 		} else {

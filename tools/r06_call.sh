@@ -49,6 +49,10 @@ case $step in
   run 600 tests.txt python -m pytest tests -m gpu -x -q
   run 400 bench.txt python bench.py
   ;;
+7) # the 256-entry exception stage as an INSTANCE of its own, launched for exception-heavy columns only: parity, then the decode grid
+  run 300 tests.txt python -m pytest tests/test_decode_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_unhinted_gpu.py -m gpu -x -q
+  PADS=0,6 run 200 decode_encoded.txt python tools/time_decode_encoded.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
