@@ -224,8 +224,8 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
 	switch (option) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
-		if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) {
-			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2, 4 or (float columns: one wavefront per vector) 8");
+		if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && !(value >= 16 && value <= 23)) {
+			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2, 4 or (float columns) 8: one wavefront per vector, 16-18: streamed by persistent workgroups");
 		}
 		ctx->decode_auto    = value == 0;
 		ctx->decode_vpw     = static_cast<int>(value);

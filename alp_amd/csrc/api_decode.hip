@@ -360,7 +360,11 @@ static int decode_one(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 		rc = alpgpu::launch_decode_column(ctx->stream, col, static_cast<double*>(d_out), decode_variant_for(ctx, col), ctx->n_cus, static_cast<uint32_t>(ctx->decode_patch_max), ahead ? ctx->d_progress : nullptr, tag);
 	} else {
 		const int shape = decode_shape_f32(ctx, col);
-		rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), shape & 0xFF, (ctx->decode_variant & 2) != 0, (shape >> 8) == 0xFF ? -1 : (shape >> 8), ahead ? ctx->d_progress : nullptr, tag);
+		if ((shape & 0xFF) >= 16) { // the column streamed by persistent workgroups (decode_stream_f32_kernels.hip): no read-ahead beside it, nothing to report
+			rc = alpgpu::launch_decode_stream_f32(ctx->stream, col, static_cast<float*>(d_out), shape & 0xFF, ctx->n_cus, ahead ? ctx->d_progress : nullptr, tag);
+		} else {
+			rc = alpgpu::launch_decode_column_f32(ctx->stream, col, static_cast<float*>(d_out), shape & 0xFF, (ctx->decode_variant & 2) != 0, (shape >> 8) == 0xFF ? -1 : (shape >> 8), ahead ? ctx->d_progress : nullptr, tag);
+		}
 	}
 	if (ahead) {
 		const alpgpu::ReadAheadPace pace = alpgpu::policy_read_ahead_pace(static_cast<double>(col->n_vectors), static_cast<double>(col->packed_bytes_hint),

@@ -13,6 +13,7 @@
 // unit of the FastLanes u32 layout, alp_device_f32.hpp), and V consecutive vectors per workgroup keep the bytes in flight
 // per CU at the level of the double-precision kernel (V = 2 moves as many bytes per workgroup as one double vector).
 #include "alp_device_f32.hpp"
+#include "decode_f32_device.hpp"
 #include "decode_policy.hpp"
 #include "launch.hpp"
 #include <cstdlib>
@@ -133,48 +134,6 @@ __device__ __forceinline__ void land_exceptions_f32(DecodeLdsF32& L, const alpgp
 __device__ __forceinline__ RdDict load_vector_consts_f32(const alpgpu_rowgroup_state* __restrict__ rgs, uint64_t v, const alpgpu_vector_desc& d) {
 	if (d.scheme != ALPGPU_SCHEME_ALP) { return load_rd_dict(rgs, v, true); } // wave-uniform
 	return RdDict {static_cast<uint64_t>(kFactArrF[d.f]), static_cast<uint64_t>(__float_as_uint(kFracArrF[d.e]))};
-}
-
-// Where a quad's words come from: the workgroup's LDS stage (k_decode_column_f32), or HBM directly through buffer loads bounded to the
-// vector's words (k_sink_direct_f32; decode_kernels.hip: BufferWords).
-struct QuadWords {
-	u32x4    w0, w1; // units 8k + a and 8k + 8 + a: stream words k, k + 1 of the quad's four columns
-	uint64_t l0, l1; // ALP_RD: left words (16 k' + group) and + 16
-};
-struct StagedWordsF {
-	const uint8_t* stage;
-	__device__ __forceinline__ void units(int i, u32x4& w0, u32x4& w1) const {
-		w0 = reinterpret_cast<const u32x4*>(stage)[i];
-		w1 = reinterpret_cast<const u32x4*>(stage)[i + 8];
-	}
-	__device__ __forceinline__ void lefts(int rbw, int i, uint64_t& l0, uint64_t& l1) const {
-		l0 = reinterpret_cast<const uint64_t*>(stage + 128 * rbw)[i];
-		l1 = reinterpret_cast<const uint64_t*>(stage + 128 * rbw)[i + 16];
-	}
-};
-struct BufferWordsF {
-	__amdgpu_buffer_rsrc_t right, left;
-	__device__ __forceinline__ void units(int i, u32x4& w0, u32x4& w1) const {
-		const uint32_t at = static_cast<uint32_t>(i) * 16u;
-		w0 = __builtin_amdgcn_raw_buffer_load_b128(right, at, 0, 0);
-		w1 = __builtin_amdgcn_raw_buffer_load_b128(right, at, 128, 0);
-	}
-	__device__ __forceinline__ void lefts(int, int i, uint64_t& l0, uint64_t& l1) const {
-		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-		const uint32_t at = static_cast<uint32_t>(i) * 8u;
-		const u32x2    a = __builtin_amdgcn_raw_buffer_load_b64(left, at, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b64(left, at, 128, 0);
-		l0 = (static_cast<uint64_t>(a[1]) << 32) | a[0];
-		l1 = (static_cast<uint64_t>(b[1]) << 32) | b[0];
-	}
-};
-// the requests of the quad 4 tid .. 4 tid + 3 (row = tid >> 3, a = tid & 7; ALP_RD: left row tid >> 4, group tid & 15)
-template <class WORDS>
-__device__ __forceinline__ QuadWords request_quad_f32(const WORDS& words, const alpgpu_vector_desc& d, int tid) {
-	QuadWords q;
-	q.l0 = q.l1 = 0;
-	words.units(8 * (((tid >> 3) * d.bw) >> 5) + (tid & 7), q.w0, q.w1);
-	if (d.scheme != ALPGPU_SCHEME_ALP) { words.lefts(d.bw, 16 * (((tid >> 4) * d.lbw) >> 4) + (tid & 15), q.l0, q.l1); }
-	return q;
 }
 
 // one quad, after its words have arrived: thread tid (of 256: wavefront `wave`, lane) owns values 4*tid .. 4*tid+3; `em` = the vector's
@@ -346,6 +305,15 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 		if (progress != nullptr && (blockIdx.x & 127u) == 0 && tid == 0) { __hip_atomic_store(progress, progress_tag | v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	}
 
+#if defined(ALPGPU_F32_DISSECT) && ALPGPU_F32_DISSECT == 3 // measurement builds (profiles/r06_float_decode.txt): the launch as a plain fill
+	if constexpr (SINK == kSinkStoreF) {
+#pragma unroll
+		for (int i = 0; i < V; ++i) {
+			if (v0 + i < n_vectors) { store_quad<NT_STORE>(out + (v0 + i) * kVec + 4 * tid, u32x4 {1u, 2u, 3u, 4u}); }
+		}
+		return;
+	}
+#endif
 	alpgpu_vector_desc d[V];
 	uint32_t           pos[V];
 #pragma unroll
@@ -356,6 +324,16 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 	RdDict dict[V];
 #pragma unroll
 	for (int i = 0; i < V; ++i) { dict[i] = load_vector_consts_f32(rgs, v0 + i < n_vectors ? v0 + i : v0, d[i]); }
+#if defined(ALPGPU_F32_DISSECT) && ALPGPU_F32_DISSECT == 2 // ... a fill behind the descriptors' round trip
+	if constexpr (SINK == kSinkStoreF) {
+#pragma unroll
+		for (int i = 0; i < V; ++i) {
+			const uint32_t x = static_cast<uint32_t>(d[i].base) + d[i].bw + static_cast<uint32_t>(dict[i].lo ^ dict[i].hi);
+			if (v0 + i < n_vectors) { store_quad<NT_STORE>(out + (v0 + i) * kVec + 4 * tid, u32x4 {x, x + tid, 3u, 4u}); }
+		}
+		return;
+	}
+#endif
 #pragma unroll
 	for (int i = 0; i < V; ++i) { pos[i] = issue_vector_loads_f32(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
 	// only a workgroup with exceptions zeroes its masks, behind the issue of its loads (decode_kernels.hip: k_decode_column)
@@ -402,6 +380,13 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 		}
 		return;
 	}
+#if defined(ALPGPU_F32_DISSECT) && ALPGPU_F32_DISSECT == 1 // ... the staged words stored as they are (no unpack, no exceptions)
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		if (v0 + i < n_vectors) { store_quad<NT_STORE>(out + (v0 + i) * kVec + 4 * tid, reinterpret_cast<const u32x4*>(L[i].stage)[tid & 31]); }
+	}
+	return;
+#endif
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		if (v0 + i < n_vectors) {

@@ -118,6 +118,8 @@ int launch_rd_decode(hipStream_t stream, int n_cus, double* out, const uint64_t*
 // pad_kib: unused dynamic LDS per workgroup (residency cap); progress / tag / gate: as launch_decode_column
 int launch_decode_column_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int vectors_per_wg, bool plain_stores, int pad_kib = -1, uint64_t* progress = nullptr,
                              uint64_t progress_tag = 0, uint32_t gate = 0);
+// decode_stream_f32_kernels.hip: persistent workgroups, three chunks in flight each; shape 16: chunks of 8 vectors / 8 KiB of records, 17: 16 / 16 KiB, 18: 4 / 12 KiB
+int launch_decode_stream_f32(hipStream_t stream, const alpgpu_column* col, float* d_out, int shape, int n_cus, uint64_t* progress = nullptr, uint64_t progress_tag = 0);
 int launch_rowgroup_init_f32(hipStream_t stream, const float* d_in, uint64_t n_vectors, alpgpu_rowgroup_state* d_rgs, uint16_t* d_rd_order,
                              uint64_t rg_first = 0, uint64_t rg_count = 0);
 int launch_state_from_samples_f32(hipStream_t stream, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state, int force_rd, double* d_cut_estimate = nullptr);

@@ -79,7 +79,7 @@ template <int VALUE_BYTES>
 __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_vector_desc* __restrict__ descs, const uint8_t* __restrict__ packed,
                                                                 const uint8_t* __restrict__ excs, uint64_t n_vectors, uint64_t* __restrict__ ctx_words,
                                                                 uint64_t tag, uint32_t lead_min, uint32_t lead_max, uint32_t ps_per_vector, uint32_t ps_per_tick, uint32_t max_bits, uint32_t mode,
-                                                                uint32_t patience_first_ticks, uint32_t patience_ticks) {
+                                                                uint32_t patience_first_ticks, uint32_t patience_ticks, uint32_t burst_ticks) {
 	// One workgroup = kAheadWaves consecutive batches of 64 vectors per round; ONE lane of the workgroup reads the progress word, and while the round is
 	// out of reach it does so every ~7 us only: the word lives on one memory channel, and every poll of every waiting wavefront is a trip to it.
 	__shared__ uint64_t s_seen;
@@ -131,6 +131,11 @@ __global__ __launch_bounds__(64 * kAheadWaves) void k_read_ahead(const alpgpu_ve
 					if (seen == 0 && ticks > patience_first_ticks / 2) { ticks = patience_first_ticks / 2 + 1; } // (before the first word: never sleep past the patience)
 					const uint64_t until = wall_clock64() + ticks;
 					while (wall_clock64() < until) { __builtin_amdgcn_s_sleep(32); }
+				}
+				// experiment (ALPGPU_READ_AHEAD_BURST_US): every workgroup's reads go out on the same beat of the device's wall clock — the memory controllers see reads in
+				// bursts between the decode's writes instead of one here, one there (each of which turns a channel around on its own)
+				if (go && burst_ticks != 0) {
+					while (wall_clock64() % burst_ticks > burst_ticks / 8) { __builtin_amdgcn_s_sleep(8); }
 				}
 				if (go && !(mode & 16u) && seen != 0 && wg_first < seen + lead - lead / 8 * 7 && lead < 3 * lead_max) { lead += lead_max / 4; } // late: less than an eighth of the lead to spare
 				s_seen = seen, s_go = go, s_lead = lead;
@@ -196,12 +201,14 @@ int launch_read_ahead(hipStream_t stream, const alpgpu_column* col, int value_by
 	const uint64_t floor_t = 200000000ull / (ps_per_tick ? ps_per_tick : 1u);
 	const uint64_t first = est / 4 > floor_t ? est / 4 : floor_t, steady = 2 * est > floor_t ? 2 * est : floor_t;
 	const uint32_t pf = first > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(first), ps = steady > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(steady);
+	static const uint32_t burst_us = std::getenv("ALPGPU_READ_AHEAD_BURST_US") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_READ_AHEAD_BURST_US"))) : 0u;
+	const uint32_t burst = static_cast<uint32_t>(static_cast<uint64_t>(burst_us) * 1000000ull / (ps_per_tick ? ps_per_tick : 1u));
 	if (value_bytes == 8) {
 		hipLaunchKernelGGL((k_read_ahead<8>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_ctx_words, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, mode, pf, ps);
+		                   d_ctx_words, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, mode, pf, ps, burst);
 	} else {
 		hipLaunchKernelGGL((k_read_ahead<4>), dim3(static_cast<unsigned>(grid)), dim3(64 * kAheadWaves), 0, stream, col->d_vectors, col->d_packed, col->d_exc, col->n_vectors,
-		                   d_ctx_words, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, mode, pf, ps);
+		                   d_ctx_words, tag, lead_min, lead_max, ps_per_vector, ps_per_tick, max_bits, mode, pf, ps, burst);
 	}
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }

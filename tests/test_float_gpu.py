@@ -133,6 +133,43 @@ def test_decode_launch_shapes_agree(ctx, of32, vpw):
     assert np.array_equal(got.view(np.uint32), col.view(np.uint32))
 
 
+@pytest.mark.parametrize("shape", [16, 17, 18, 19, 20, 21, 22, 23])
+def test_streamed_decode_bit_exact(ctx, of32, shape):
+    """the persistent, streaming float decode (decode_stream_f32_kernels.hip; ALPGPU_OPT_DECODE_VECTORS_PER_WG 16-18: chunks of 8 / 16 / 4 vectors): every synthetic
+    column, the golden float columns and vectors of every exception count, among them records that do not fit the chunk's arena (decoded from HBM directly)"""
+    from alp_amd import capi
+    try:
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, shape)
+        for name, make in COLUMNS.items():
+            col = make()
+            got = gpu_decode(ctx, of32.encode_column(col))
+            assert np.array_equal(got.view(np.uint32), col.view(np.uint32)), name
+        for name, col, gold, _ in FLOATS:
+            assert np.array_equal(gpu_decode(ctx, gold).view(np.uint32), col.view(np.uint32)), name
+        # exception counts 0 .. 1024 in one column (positions spread over the vector), narrow and wide digits
+        rng = np.random.default_rng(77)
+        for decimals, hi in ((1, 10.0), (3, 1.0e4)):
+            vecs = []
+            for cnt in list(range(0, 70)) + [100, 127, 128, 129, 255, 256, 257, 511, 512, 700, 1023, 1024]:
+                v = np.round(rng.uniform(0, hi, 1024), decimals).astype(np.float32)
+                at = np.sort(rng.choice(1024, cnt, replace=False))
+                v[at] = rng.standard_normal(cnt).astype(np.float32) * np.float32(1.2345678e-3)
+                vecs.append(v)
+            col = np.concatenate(vecs)
+            enc = of32.encode_column(col)
+            got = gpu_decode(ctx, enc)
+            assert np.array_equal(got.view(np.uint32), col.view(np.uint32)), (decimals, np.nonzero(got.view(np.uint32) != col.view(np.uint32))[0][:8])
+        # a longer column (more chunks than workgroups' first round), ALP and ALP_RD rowgroups alternating
+        col = np.concatenate([datagen.mixed_column_f32(700, seed=31, exc_rate=0.02), datagen.rd_column_f32(300, seed=32), datagen.decimal_column_f32(1003, 1, seed=33)])
+        x = cu(col)
+        dcol = ctx.encode(x)
+        out = ctx.decode(dcol)
+        ctx.synchronize()
+        assert torch.equal(out.view(torch.int32), x.view(torch.int32))
+    finally:
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+
+
 @pytest.mark.parametrize("name", list(COLUMNS.keys()))
 def test_synthetic_float_columns_encode_bit_exact(ctx, of32, name):
     col_np = COLUMNS[name]()

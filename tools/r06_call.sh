@@ -53,6 +53,46 @@ case $step in
   run 300 tests.txt python -m pytest tests/test_decode_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_unhinted_gpu.py -m gpu -x -q
   PADS=0,6 run 200 decode_encoded.txt python tools/time_decode_encoded.py
   ;;
+8) # the float store decode on narrow columns, taken apart: as built / without the unpack / a fill behind the descriptors / a plain fill
+  run 200 narrow.txt python tools/time_f32_narrow.py
+  for k in 1 2 3; do ALPGPU_LIB=build/variants/libalpgpu_f32_dissect$k.so EXCS=0 SHAPES=2,4 run 100 narrow_dissect$k.txt python tools/time_f32_narrow.py; done
+  ;;
+9) # the streaming float decode: parity, then against the small-workgroup shapes on narrow columns
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed or shapes"
+  SHAPES=2,16,17 run 300 narrow.txt python tools/time_f32_narrow.py
+  ;;
+10) # the streaming float decode by workgroups per CU
+  for g in 1 2 3 4 5 8; do ALPGPU_STREAM_WGS_PER_CU=$g BWS=1,3,6 SHAPES=16,17 run 100 narrow_g$g.txt python tools/time_f32_narrow.py; done
+  ;;
+11) # the streaming float decode with a loading wavefront: parity, timing by residency
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed or shapes"
+  SHAPES=2,16,17,18 run 300 narrow.txt python tools/time_f32_narrow.py
+  for g in 1 2; do ALPGPU_STREAM_WGS_PER_CU=$g BWS=3 SHAPES=16,17 run 100 narrow_g$g.txt python tools/time_f32_narrow.py; done
+  for w in 6 8; do ALPGPU_LIB=build/variants/libalpgpu_stream_w$w.so BWS=3,6 SHAPES=16,17 run 100 narrow_w$w.txt python tools/time_f32_narrow.py; done
+  ;;
+12) # the streaming float decode with D loading wavefronts: parity, timing by depth (19: 1, 20: 2, 16: 3 loaders; 17: chunks of 16, 2 loaders) and residency
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed or shapes"
+  for g in 1 2 3; do ALPGPU_STREAM_WGS_PER_CU=$g BWS=1,3,6 SHAPES=19,20,16,17 run 100 narrow_g$g.txt python tools/time_f32_narrow.py; done
+  ;;
+13) # reads on the beat of the wall clock: the read-ahead (small-workgroup decode) and the streaming decode's loaders
+  for b in 0 5 10 20 40; do ALPGPU_READ_AHEAD_BURST_US=$b BWS=3,6 SHAPES=2 run 100 ahead_burst$b.txt python tools/time_f32_narrow.py; done
+  for b in 0 10 20 40 80; do ALPGPU_STREAM_BURST_US10=$b BWS=3,6 SHAPES=16,20 run 100 stream_burst$b.txt python tools/time_f32_narrow.py; done
+  ;;
+14) # the streaming decode with the read-ahead beside it
+  SIZES=1048576 LEADS=10,20,40 BWS=1,3,6 SHAPES=2,16,20 run 200 stream_ahead.txt python tools/time_f32_narrow.py
+  ;;
+16) # the streaming decode taken apart: no record loads / no stores
+  for k in 1 2; do ALPGPU_LIB=build/variants/libalpgpu_stream_dissect$k.so EXCS=0 BWS=1,3,6 SHAPES=16,20 run 100 stream_dissect$k.txt python tools/time_f32_narrow.py; done
+  for g in 1 2; do ALPGPU_STREAM_WGS_PER_CU=$g ALPGPU_LIB=build/variants/libalpgpu_stream_dissect2.so EXCS=0 BWS=3 SHAPES=16,20,19 run 100 stream_dissect2_g$g.txt python tools/time_f32_narrow.py; done
+  ;;
+17) # the streaming float decode against the rule's choice, by width
+  SIZES=1048576 BWS=1,2,3,4,5,6,7,8,9,10,11,12,14,16,18,20,24,28,32 SHAPES=16,20,18 run 400 widths.txt python tools/time_f32_narrow.py
+  ;;
+18) # more decoding wavefronts per workgroup, one workgroup per CU (21: 8 decoders, chunks of 16; 22: 8, chunks of 8; 23: 16 decoders, chunks of 16)
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed"
+  BWS=1,3,6,8 SHAPES=20,21,22,23 run 200 narrow.txt python tools/time_f32_narrow.py
+  ALPGPU_STREAM_WGS_PER_CU=2 BWS=3,6 SHAPES=21,22,23 run 200 narrow_g2.txt python tools/time_f32_narrow.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
