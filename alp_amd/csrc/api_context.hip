@@ -224,7 +224,7 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	if (!ctx) { return fail(ALPGPU_ERR_INVALID, "null context"); }
 	switch (option) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
-		if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && !(value >= 16 && value <= 23)) {
+		if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && !(value >= 16 && value <= 30)) {
 			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2, 4 or (float columns) 8: one wavefront per vector, 16-18: streamed by persistent workgroups");
 		}
 		ctx->decode_auto    = value == 0;

@@ -115,6 +115,8 @@ static int decode_shape_f32(const alpgpu_ctx* ctx, const alpgpu_column* col) {
 		const double bits = static_cast<double>(col->packed_bytes_hint) / (128.0 * static_cast<double>(col->n_vectors));
 		const double four = column_decodes_with_exceptions(ctx, col) ? alpgpu::kFourVectorsBitsExcF32 : alpgpu::kFourVectorsBitsF32; // (0: never — decode_policy.hpp)
 		if (four > 0.0 && bits <= four) { vpw = 4; }
+		// narrow vectors without exceptions: streamed by persistent workgroups (decode_policy.hpp: policy_stream_f32)
+		if (alpgpu::policy_stream_f32(col->n_vectors, static_cast<double>(col->packed_bytes_hint), column_decodes_with_exceptions(ctx, col))) { vpw = alpgpu::kStreamShapeF32; }
 	}
 	return vpw | ((ctx->decode_pad_kib >= 0 ? ctx->decode_pad_kib : 0xFF) << 8);
 }
@@ -245,6 +247,7 @@ int alpgpu_decode_vectors_per_wg(alpgpu_ctx* ctx, const alpgpu_column* col, int 
 // ... and whether it would start the read-ahead beside the decode kernel (ALPGPU_OPT_DECODE_READ_AHEAD): 1 / 0; negative on bad arguments
 int alpgpu_decode_reads_ahead(alpgpu_ctx* ctx, const alpgpu_column* col, int is_f32) {
 	if (!ctx || !col) { return fail(ALPGPU_ERR_INVALID, "null context or column"); }
+	if (is_f32 && (decode_shape_f32(ctx, col) & 0xFF) >= 16) { return 0; } // (streamed by persistent workgroups: no read-ahead beside it)
 	return read_ahead_for(ctx, col, is_f32 ? 4 : 8) ? 1 : 0;
 }
 
@@ -346,7 +349,8 @@ template <int VB>
 static int decode_one(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 	// The read-ahead (read_ahead_kernels.hip): a few persistent workgroups on the context's second stream pull the column's streams into the Infinity
 	// Cache a bounded distance ahead of the decode kernel, which tells them where it is.  Started first so that it is ahead from the first workgroup on.
-	const bool ahead = read_ahead_for(ctx, col, VB);
+	// (a float column streamed by persistent workgroups prefetches for itself; the read-ahead beside it changed nothing: call 14)
+	const bool ahead = read_ahead_for(ctx, col, VB) && !(VB == 4 && (decode_shape_f32(ctx, col) & 0xFF) >= 16);
 	uint64_t   tag   = 0;
 	if (ahead) {
 		tag = next_progress_tag(ctx);

@@ -43,6 +43,21 @@ constexpr double   kEmptyVectorsBits    = 0.75; // columns of (almost) nothing b
 #ifndef ALPGPU_F32_FOUR_VECTORS_BITS_EXC
 #define ALPGPU_F32_FOUR_VECTORS_BITS_EXC 0.0
 #endif
+// Round 6, late: float columns of 2-8-bit vectors WITHOUT exceptions are streamed by persistent workgroups (decode_stream_f32_kernels.hip; shape 27: chunks of 12 vectors,
+// 12 decoding + 2 loading wavefronts, one workgroup per CU) — 0.65-0.73 of the HBM peak against 0.60-0.65 for two vectors per workgroup + the read-ahead (calls 19-22).
+// With ~2 or more exceptions per vector it is level or behind cold (0.51-0.53 against 0.53-0.55; ahead warm), from 9 bits on it sits on a plateau of 0.69-0.70 that
+// the small workgroups pass, and a column of 1-bit vectors is faster as it was (0.76): the rule below.  ALPGPU_F32_STREAM_BITS=0: never.
+#ifndef ALPGPU_F32_STREAM_BITS
+#define ALPGPU_F32_STREAM_BITS 8.5
+#endif
+constexpr double   kStreamBitsF32      = ALPGPU_F32_STREAM_BITS;
+constexpr double   kStreamLeastBitsF32 = 1.5;
+constexpr uint64_t kStreamVectorsF32   = 32768; // shorter columns: a few chunks per workgroup only
+constexpr int      kStreamShapeF32     = 27;
+__host__ __device__ inline bool policy_stream_f32(uint64_t n_vectors, double packed_bytes, bool with_exc) {
+	const double n = static_cast<double>(n_vectors);
+	return kStreamBitsF32 > 0.0 && n_vectors >= kStreamVectorsF32 && !with_exc && packed_bytes > kStreamLeastBitsF32 * 128.0 * n && packed_bytes <= kStreamBitsF32 * 128.0 * n;
+}
 constexpr double kReadAheadBitsF32     = ALPGPU_F32_READ_AHEAD_BITS;
 constexpr double kReadAheadBitsExcF32  = ALPGPU_F32_READ_AHEAD_BITS_EXC;
 constexpr double kFourVectorsBitsF32    = ALPGPU_F32_FOUR_VECTORS_BITS;     // four float vectors per workgroup up to here (two beyond)

@@ -74,7 +74,7 @@ __device__ __forceinline__ void stream_load_descs(LDS& S, int db, const alpgpu_v
 // stage 2: the chunk's plan (one vector per lane) and the loads of its records into arena `buf`
 template <int C, int ARENA, class LDS>
 __device__ __forceinline__ void stream_issue_chunk(LDS& S, int db, int buf, const alpgpu_rowgroup_state* __restrict__ rgs, const uint8_t* __restrict__ packed,
-                                                   const uint8_t* __restrict__ excs, uint64_t v_base, int n_here, int lane) {
+                                                   const uint8_t* __restrict__ excs, uint64_t exc_limit, uint64_t v_base, int n_here, int lane) {
 	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 	const bool               valid  = lane < n_here;
 	const alpgpu_vector_desc d      = S.desc[db][lane < C ? lane : 0];
@@ -92,9 +92,11 @@ __device__ __forceinline__ void stream_issue_chunk(LDS& S, int db, int buf, cons
 	const uint64_t e0 = (static_cast<uint64_t>(lane_value(static_cast<uint32_t>(d.exc_off >> 32), 0)) << 32) | lane_value(static_cast<uint32_t>(d.exc_off), 0);
 	const int      last     = n_here - 1;
 	const uint32_t pk_total = lane_value(pk_off + pk, last), rec_total = lane_value(rec_off + rec, last);
-	const uint32_t rec_base = (pk_total + 15u) & ~15u;
+	// (the exception span is copied in 16-byte units from the 16-byte boundary below its first byte: the records then lie (e0 & 15) bytes into their part of the arena)
+	const uint32_t rec_skew = static_cast<uint32_t>(e0) & 15u;
+	const uint32_t rec_base = ((pk_total + 15u) & ~15u) + rec_skew;
 	const bool     in_order = !valid || ((pk == 0u || d.packed_off == p0 + pk_off) && (rec == 0u || d.exc_off == e0 + rec_off));
-	const bool     flat     = __builtin_amdgcn_ballot_w64(!in_order) == 0ull && rec_base + rec_total <= static_cast<uint32_t>(ARENA); // wave-uniform
+	const bool     flat     = __builtin_amdgcn_ballot_w64(!in_order) == 0ull && rec_base + rec_total + 16u <= static_cast<uint32_t>(ARENA); // wave-uniform
 	const uint32_t slot   = pk + ((rec + 15u) & ~15u);
 	const uint32_t off_v  = row_exclusive_scan16(slot);
 	const bool     direct = !flat && off_v + slot > static_cast<uint32_t>(ARENA);
@@ -142,10 +144,21 @@ __device__ __forceinline__ void stream_issue_chunk(LDS& S, int db, int buf, cons
 		for (int u0 = 0; u0 < n_units; u0 += 64) {
 			if (u0 + lane < n_units) { __builtin_amdgcn_global_load_lds(g + u0 + lane, reinterpret_cast<ull2*>(S.arena[buf]) + u0, 16, 0, 0); }
 		}
-		const uint32_t* r    = reinterpret_cast<const uint32_t*>(excs + e0);
-		const int       n_dw = static_cast<int>(rec_total >> 2);
-		for (int u0 = 0; u0 < n_dw; u0 += 64) {
-			if (u0 + lane < n_dw) { __builtin_amdgcn_global_load_lds(r + u0 + lane, reinterpret_cast<uint32_t*>(S.arena[buf] + rec_base) + u0, 4, 0, 0); }
+		if (rec_total != 0u) {
+			const uint64_t e_lo = e0 - rec_skew;
+			const int      n_eu = static_cast<int>((rec_skew + rec_total + 15u) >> 4);
+			if (e_lo + 16ull * static_cast<uint64_t>(n_eu) <= exc_limit) {
+				const ull2* r = reinterpret_cast<const ull2*>(excs + e_lo);
+				for (int u0 = 0; u0 < n_eu; u0 += 64) {
+					if (u0 + lane < n_eu) { __builtin_amdgcn_global_load_lds(r + u0 + lane, reinterpret_cast<ull2*>(S.arena[buf] + rec_base - rec_skew) + u0, 16, 0, 0); }
+				}
+			} else { // (the stream's last bytes: never past what the caller allocated)
+				const uint32_t* r    = reinterpret_cast<const uint32_t*>(excs + e0);
+				const int       n_dw = static_cast<int>(rec_total >> 2);
+				for (int u0 = 0; u0 < n_dw; u0 += 64) {
+					if (u0 + lane < n_dw) { __builtin_amdgcn_global_load_lds(r + u0 + lane, reinterpret_cast<uint32_t*>(S.arena[buf] + rec_base) + u0, 4, 0, 0); }
+				}
+			}
 		}
 		return;
 	}
@@ -300,22 +313,22 @@ __device__ __forceinline__ void stream_decode_vector(LDS& S, int buf, int tb, in
 	}
 }
 
-// the exception tables of a landed chunk (the loading wavefront that brought it in, in front of the chunk's barrier)
+// the exception table of vector i of a landed chunk, by the wavefront that is about to decode it (the loading wavefronts built a chunk's tables one vector after the
+// other in the first form: with 16 vectors per chunk that made them the workgroup's pace on every column with exceptions — call 18)
 template <class LDS>
-__device__ __forceinline__ void stream_build_tables(LDS& S, int buf, int tb, int n_here, const uint8_t* __restrict__ excs, int lane) {
-	for (int i = 0; i < n_here; ++i) {
-		const StreamPlan& P   = S.plan[buf][i];
-		const int         cnt = __builtin_amdgcn_readfirstlane(static_cast<int>(P.exc_cnt));
-		if (cnt == 0) { continue; }
-		const uint32_t flags = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(P.flags)));
-		const uint32_t vb    = (flags & kPlanAlp) ? 4u : 2u;
-		if (flags & kPlanDirect) {
-			stream_build_table(&S.table[tb][i][0], reinterpret_cast<const uint16_t*>(excs + P.exc_off + vb * cnt), cnt, lane);
-		} else {
-			const uint32_t at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(P.exc_lds)));
-			stream_build_table(&S.table[tb][i][0], reinterpret_cast<const uint16_t*>(S.arena[buf] + at + vb * cnt), cnt, lane);
-		}
+__device__ __forceinline__ void stream_build_vector_table(LDS& S, int buf, int tb, int i, const uint8_t* __restrict__ excs, int lane) {
+	const StreamPlan& P   = S.plan[buf][i];
+	const int         cnt = __builtin_amdgcn_readfirstlane(static_cast<int>(P.exc_cnt));
+	if (cnt == 0) { return; }
+	const uint32_t flags = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(P.flags)));
+	const uint32_t vb    = (flags & kPlanAlp) ? 4u : 2u;
+	if (flags & kPlanDirect) {
+		stream_build_table(&S.table[tb][i][0], reinterpret_cast<const uint16_t*>(excs + P.exc_off + vb * cnt), cnt, lane);
+	} else {
+		const uint32_t at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(P.exc_lds)));
+		stream_build_table(&S.table[tb][i][0], reinterpret_cast<const uint16_t*>(S.arena[buf] + at + vb * cnt), cnt, lane);
 	}
+	wave_lds_sync();
 }
 
 // Wavefronts 0 .. 3 unpack and store; wavefront 4 + j loads the chunks k = j (mod D) of the workgroup: D chunks' records are in flight while one is decoded.
@@ -326,8 +339,8 @@ __device__ __forceinline__ void stream_build_tables(LDS& S, int buf, int tb, int
 template <int C, int ARENA, int D, int NDEC>
 __global__ __launch_bounds__(64 * (NDEC + D)) void k_decode_stream_f32(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
                                                                                   const uint8_t* __restrict__ packed, const uint8_t* __restrict__ excs, float* __restrict__ out,
-                                                                                  uint64_t n_vectors, uint32_t burst_ticks, uint64_t* __restrict__ progress, uint64_t progress_tag) {
-	static_assert(C <= 16 && (C & (C - 1)) == 0, "a chunk's sizes are scanned inside one 16-lane row");
+                                                                                  uint64_t n_vectors, uint64_t exc_limit, uint64_t* __restrict__ progress, uint64_t progress_tag) {
+	static_assert(C <= 16, "a chunk's sizes are scanned inside one 16-lane row");
 	constexpr int NBUF = D + 1;
 	__shared__ StreamLds<C, ARENA, D> S;
 	const int      tid  = static_cast<int>(threadIdx.x);
@@ -354,30 +367,24 @@ __global__ __launch_bounds__(64 * (NDEC + D)) void k_decode_stream_f32(const alp
 		if (chunk(j) < n_chunks) {
 			stream_load_descs<C>(S, j, descs, chunk(j) * C, here(chunk(j)), lane);
 			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-			stream_issue_chunk<C, ARENA>(S, j, j % NBUF, rgs, packed, excs, chunk(j) * C, here(chunk(j)), lane);
+			stream_issue_chunk<C, ARENA>(S, j, j % NBUF, rgs, packed, excs, exc_limit, chunk(j) * C, here(chunk(j)), lane);
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the descriptors are read: their slot may be written again)
 			if (chunk(j + D) < n_chunks) { stream_load_descs<C>(S, j, descs, chunk(j + D) * C, here(chunk(j + D)), lane); }
 		}
 		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (the decoders have cleaned the tables)
-		if (j == 0) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			stream_build_tables(S, 0, 0, here(c0), excs, lane);
-		}
+		if (j == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // chunk 0 has landed
 		for (int k = 0; chunk(k) < n_chunks; ++k) {
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier k
 			// the read-ahead's pace (read_ahead_kernels.hip): workgroup 0 says where the launch is — the workgroups move through the column side by side
 			if (progress != nullptr && blockIdx.x == 0 && j == k % D && lane == 0) { __hip_atomic_store(progress, progress_tag | (chunk(k) * C), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 			if (j == k % D) { // chunk k - 1's arena is free: the records of chunk k + D into it, then the descriptors of chunk k + 2 D
 				if (chunk(k + D) < n_chunks) {
-					stream_issue_chunk<C, ARENA>(S, j, (k + D) % NBUF, rgs, packed, excs, chunk(k + D) * C, here(chunk(k + D)), lane);
+					stream_issue_chunk<C, ARENA>(S, j, (k + D) % NBUF, rgs, packed, excs, exc_limit, chunk(k + D) * C, here(chunk(k + D)), lane);
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 					if (chunk(k + 2 * D) < n_chunks) { stream_load_descs<C>(S, j, descs, chunk(k + 2 * D) * C, here(chunk(k + 2 * D)), lane); }
 				}
 			}
-			if (j == (k + 1) % D && chunk(k + 1) < n_chunks) { // the next chunk is this wavefront's: wait for it, build its tables
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				stream_build_tables(S, (k + 1) % NBUF, (k + 1) & 1, here(chunk(k + 1)), excs, lane);
-			}
+			if (j == (k + 1) % D && chunk(k + 1) < n_chunks) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // the next chunk is this wavefront's: it arrives at barrier k + 1 when the chunk has landed
 		}
 		return;
 	}
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(64 * (NDEC + D)) void k_decode_stream_f32(const alp
 		const int n_here = here(chunk(k));
 		float*    dst    = out + chunk(k) * C * kVec;
 		for (int i = wave; i < n_here; i += NDEC) {
+			stream_build_vector_table(S, buf, k & 1, i, excs, lane);
 			const uint32_t flags = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.plan[buf][i].flags)));
 			if (flags & kPlanDirect) {
 				stream_decode_vector<true>(S, buf, k & 1, i, packed, excs, dst + i * kVec, lane);
@@ -401,7 +409,6 @@ __global__ __launch_bounds__(64 * (NDEC + D)) void k_decode_stream_f32(const alp
 
 template <int C, int ARENA, int D, int NDEC>
 static int launch_stream(hipStream_t stream, const alpgpu_column* col, float* d_out, int n_cus, int wgs_per_cu, uint64_t* progress, uint64_t tag) {
-	static const uint32_t burst_ticks = std::getenv("ALPGPU_STREAM_BURST_US10") ? static_cast<uint32_t>(std::atoi(std::getenv("ALPGPU_STREAM_BURST_US10"))) * 10u : 0u; // tenths of a microsecond at 100 MHz
 	const uint64_t n        = col->n_vectors;
 	const uint64_t n_chunks = (n + C - 1) / C;
 	constexpr int  kThreads = 64 * (NDEC + D);
@@ -413,7 +420,7 @@ static int launch_stream(hipStream_t stream, const alpgpu_column* col, float* d_
 	if (wgs_per_cu > resident) { wgs_per_cu = resident; }
 	const uint64_t cap      = static_cast<uint64_t>(n_cus) * static_cast<uint64_t>(wgs_per_cu);
 	const unsigned grid     = static_cast<unsigned>(n_chunks < cap ? n_chunks : cap);
-	hipLaunchKernelGGL((k_decode_stream_f32<C, ARENA, D, NDEC>), dim3(grid), dim3(kThreads), 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, burst_ticks, progress, tag);
+	hipLaunchKernelGGL((k_decode_stream_f32<C, ARENA, D, NDEC>), dim3(grid), dim3(kThreads), 0, stream, col->d_vectors, col->d_rowgroups, col->d_packed, col->d_exc, d_out, n, col->exc_capacity, progress, tag);
 	return hipGetLastError() == hipSuccess ? ALPGPU_OK : ALPGPU_ERR_HIP;
 }
 
@@ -429,7 +436,14 @@ int launch_decode_stream_f32(hipStream_t stream, const alpgpu_column* col, float
 	if (shape == 20) { return launch_stream<8, 8192, 2, 4>(stream, col, d_out, n_cus, wgs, progress, progress_tag); }
 	if (shape == 21) { return launch_stream<16, 16384, 2, 8>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
 	if (shape == 22) { return launch_stream<8, 8192, 2, 8>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
-	if (shape == 23) { return launch_stream<16, 16384, 2, 16>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 23) { return launch_stream<16, 16384, 2, 12>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 24) { return launch_stream<12, 12288, 2, 12>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 25) { return launch_stream<14, 14336, 2, 14>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 27) { return launch_stream<12, 24576, 2, 12>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 28) { return launch_stream<12, 49152, 1, 12>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 29) { return launch_stream<12, 12288, 4, 12>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 30) { return launch_stream<12, 12288, 1, 12>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
+	if (shape == 26) { return launch_stream<16, 16384, 1, 14>(stream, col, d_out, n_cus, env_wgs > 0 ? env_wgs : 1, progress, progress_tag); }
 	return launch_stream<8, 8192, 3, 4>(stream, col, d_out, n_cus, wgs, progress, progress_tag);
 }
 

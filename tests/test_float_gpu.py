@@ -133,7 +133,7 @@ def test_decode_launch_shapes_agree(ctx, of32, vpw):
     assert np.array_equal(got.view(np.uint32), col.view(np.uint32))
 
 
-@pytest.mark.parametrize("shape", [16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("shape", [16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28])
 def test_streamed_decode_bit_exact(ctx, of32, shape):
     """the persistent, streaming float decode (decode_stream_f32_kernels.hip; ALPGPU_OPT_DECODE_VECTORS_PER_WG 16-18: chunks of 8 / 16 / 4 vectors): every synthetic
     column, the golden float columns and vectors of every exception count, among them records that do not fit the chunk's arena (decoded from HBM directly)"""
@@ -163,6 +163,15 @@ def test_streamed_decode_bit_exact(ctx, of32, shape):
         col = np.concatenate([datagen.mixed_column_f32(700, seed=31, exc_rate=0.02), datagen.rd_column_f32(300, seed=32), datagen.decimal_column_f32(1003, 1, seed=33)])
         x = cu(col)
         dcol = ctx.encode(x)
+        out = ctx.decode(dcol)
+        ctx.synchronize()
+        assert torch.equal(out.view(torch.int32), x.view(torch.int32))
+        # ... and the same column with its records NOT in vector order (ALPGPU_OPT_ENCODE_UNORDERED): a chunk's records are then no single span of the streams
+        ctx.set_option(capi.OPT_ENCODE_UNORDERED, 1)
+        try:
+            dcol = ctx.encode(x)
+        finally:
+            ctx.set_option(capi.OPT_ENCODE_UNORDERED, 0)
         out = ctx.decode(dcol)
         ctx.synchronize()
         assert torch.equal(out.view(torch.int32), x.view(torch.int32))

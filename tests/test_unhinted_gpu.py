@@ -108,7 +108,10 @@ def test_unhinted_decode_picks_the_shape_of_the_hinted_one_and_writes_the_same_b
                 if mode:
                     plan = ctx.unhinted_plan()
                     assert plan["shape"] == shape, (bw, exc, plan)
-                    assert {8: {1: 1, 2: 2, 3: 1}, 4: {1: 2}}[vb][plan["shape"]] == hinted_vpw, (bw, exc, plan, hinted_vpw)
+                    # (float columns of 2-8-bit vectors without exceptions: the hinted rule streams them — shape 27, decode_policy.hpp: policy_stream_f32 — the unhinted plan has
+                    #  no such candidate and takes two vectors per workgroup)
+                    assert {8: {1: 1, 2: 2, 3: 1}, 4: {1: 2}}[vb][plan["shape"]] == (2 if hinted_vpw == 27 else hinted_vpw), (bw, exc, plan, hinted_vpw)
+                    assert (hinted_vpw == 27) == (vb == 4 and exc == 0 and bw <= 8), (bw, exc, hinted_vpw)
                     assert plan["lead_max"] == 0  # 140 000 vectors: too short for the read-ahead on its own
         finally:
             ctx.set_option(capi.OPT_DECODE_UNHINTED, 1)
@@ -129,6 +132,11 @@ def test_long_float_columns_of_narrow_vectors_take_the_read_ahead(ctx, exc):
         ctx.set_option(capi.OPT_DECODE_READ_AHEAD, 0)
         ref = ctx.decode(col).clone()
         ctx.set_option(capi.OPT_DECODE_READ_AHEAD, -1)
+        if exc == 0:  # no exceptions: the rule streams the column by persistent workgroups that prefetch for themselves (round 6, late) — no read-ahead beside them
+            assert ctx.decode_vectors_per_wg(col) == 27 and not ctx.decode_reads_ahead(col)
+            out = ctx.decode(col)
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 2)
         assert ctx.decode_reads_ahead(col)
         before = ctx.read_ahead_batches()
         out = ctx.decode(col)

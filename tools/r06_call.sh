@@ -93,6 +93,25 @@ case $step in
   BWS=1,3,6,8 SHAPES=20,21,22,23 run 200 narrow.txt python tools/time_f32_narrow.py
   ALPGPU_STREAM_WGS_PER_CU=2 BWS=3,6 SHAPES=21,22,23 run 200 narrow_g2.txt python tools/time_f32_narrow.py
   ;;
+19) # tables built by the decoding wavefronts; 12 / 14 decoders per workgroup
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed"
+  BWS=1,3,6,8 SHAPES=20,23,24,25,26 run 200 narrow.txt python tools/time_f32_narrow.py
+  ;;
+20) # 12 decoders over larger arenas: widths 2 .. 32
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed"
+  SIZES=1048576 BWS=2,4,7,8,9,10,12,14,16,20,24,28,32 SHAPES=24,27,28 run 300 widths.txt python tools/time_f32_narrow.py
+  ;;
+21) # how far ahead: 1 / 2 / 4 loading wavefronts (30 / 24 / 29), chunks of 12, 12 decoders
+  SIZES=1048576 BWS=3,6,8 SHAPES=30,24,29 run 300 depth.txt python tools/time_f32_narrow.py
+  ;;
+22) # the exception span in 16-byte units
+  run 300 tests.txt python -m pytest tests/test_float_gpu.py -m gpu -x -q -k "streamed"
+  BWS=3,6 SHAPES=24,27 run 300 narrow.txt python tools/time_f32_narrow.py
+  ;;
+23) # the rule streams narrow float columns without exceptions: the whole GPU suite, the float sweep rows of the bench
+  run 900 tests.txt python -m pytest tests -m gpu -x -q
+  SIZES=1048576 BWS=1,2,3,4,5,6,7,8,9 SHAPES=2 run 200 rule.txt python tools/time_f32_narrow.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
