@@ -32,6 +32,7 @@ struct __attribute__((aligned(16))) DecodeLdsF32 {
 	uint8_t  stage[kStageBytesF];
 	uint32_t mask[32];
 	uint8_t  excv[4 * kExcStageF]; // the head of the exception record as it lies in the stream (values first), brought in by LDS-DMA
+	uint16_t rdict[8];             // ALP_RD: the rowgroup's dictionary, looked up by ds_read_u16 (round 6: the lookup in registers — a 3-way select through a 64-bit shift — was 13 of the ~27 vector instructions per ALP_RD value)
 };
 
 struct ExcMaskF {
@@ -156,7 +157,21 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 	uint32_t  hits = 0;
 	int       rank = 0;
 	const bool all_staged = !HBM_EXC || cnt <= (d.scheme == ALPGPU_SCHEME_ALP ? kExcStageF : 2 * kExcStageF); // wave-uniform: every exception value of the vector is in the LDS stage
-	if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
+	// Round 6: the SINKS skip an ALP vector's exception positions here (the position counts as +0.0 / as outside the range) and take the exception VALUES in one
+	// pass behind the quads (sink_exception_values_f32) — the per-value lookup (rank, four divergent blocks per quad, an LDS read and its wait each) was ~170 of
+	// the ~540 vector instructions per vector of an exception-heavy column (profiles/r05_float_sink.txt); include/alpgpu.h documents the order.  ALP_RD vectors
+	// (few exceptions, and an exception there is a LEFT part that needs its position's right part) keep the lookup in place.
+	constexpr bool kApart = SINK != kSinkStoreF;
+	if (kApart && cnt > 0 && d.scheme == ALPGPU_SCHEME_ALP) {
+		const int wi = 8 * wave + (lane >> 3);
+		uint32_t  word;
+		if constexpr (LDS::kPrefixInLds) {
+			word = L.mask[wi];
+		} else {
+			word = static_cast<uint32_t>(__shfl(static_cast<int>(em.word), wi));
+		}
+		hits = (word >> (4 * a)) & 0xFu;
+	} else if (cnt > 0) { // the quad's four mask bits and the rank of its first exception
 		const int wi = 8 * wave + (lane >> 3);
 		uint32_t  word;
 		int       pref;
@@ -213,7 +228,13 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 			return;
 		}
 #endif
-		if (hits) { // (a branch-free form — every lane reads the staged value it WOULD take, then selects — was measured in round 5: no difference, 64 VGPRs; profiles/r05_float_sink.txt)
+		if constexpr (kApart) {
+			// (the sinks: an exception position contributes +0.0f — (double)(+0.0f) added to a partial that is never -0.0 leaves it as it is — or, for COUNT, a NaN)
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				if (hits & (1u << c)) { out[c] = SINK == kSinkCountF ? 0x7FC00000u : 0u; }
+			}
+		} else if (hits) { // (a branch-free form — every lane reads the staged value it WOULD take, then selects — was measured in round 5: no difference, 64 VGPRs; profiles/r05_float_sink.txt)
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
 				if (hits & (1u << c)) {
@@ -230,13 +251,18 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 		const int      lbw  = d.lbw;
 		const uint32_t lmsk = (1u << lbw) - 1u;
 		const uint64_t dlo = dict.lo, dhi = dict.hi;
+		(void)dlo, (void)dhi;
 		const int      ls   = ((tid >> 4) * lbw) & 15;
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
 			const uint32_t f0  = static_cast<uint32_t>(w.l0 >> (16 * c)) & 0xFFFFu;
 			const uint32_t f1  = static_cast<uint32_t>(w.l1 >> (16 * c)) & 0xFFFFu;
 			const uint32_t idx = ((f0 >> ls) | (f1 << (16 - ls))) & lmsk;
+#ifdef ALPGPU_F32_RD_DICT_IN_REGISTERS // A/B (round 6): the lookup as it was until round 5
 			uint32_t       l   = static_cast<uint32_t>((idx < 4 ? dlo >> (16 * idx) : dhi >> (16 * (idx & 3))) & 0xFFFFull);
+#else
+			uint32_t       l   = L.rdict[idx & 7u];
+#endif
 			if (hits & (1u << c)) {
 				l = fetch_exception_f32<2>(L, rec, rank, all_staged);
 				++rank;
@@ -266,6 +292,26 @@ __device__ __forceinline__ void finish_quad_f32(const LDS& L, const QuadWords& w
 			asm volatile("; quad stored (exception values beyond the stage possible)" ::: "memory");
 		} else {
 			asm volatile("; quad stored (exception values all staged)" ::: "memory");
+		}
+	}
+}
+
+// the sinks' second pass over an ALP vector with exceptions: lane L takes the values j = L, L + 64, ... in ascending order (staged ones from LDS, the rest from
+// the stream) and adds them to `total` (SUM: widened; COUNT: those inside [lo, hi])
+template <int SINK, class LDS>
+__device__ __forceinline__ void sink_exception_values_f32(const LDS& L, const uint8_t* __restrict__ rec, int cnt, int lane, double& total, float range_lo, float range_hi) {
+	for (int j = lane; j < cnt; j += 64) {
+		uint32_t bits;
+		if (j < kExcStageF) {
+			bits = reinterpret_cast<const uint32_t*>(L.excv)[j];
+		} else {
+			bits = reinterpret_cast<const uint32_t*>(rec)[j];
+		}
+		const float v = __uint_as_float(bits);
+		if constexpr (SINK == kSinkCountF) {
+			total += (v >= range_lo && v <= range_hi) ? 1.0 : 0.0;
+		} else {
+			total += static_cast<double>(v);
 		}
 	}
 }
@@ -336,6 +382,11 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 #endif
 #pragma unroll
 	for (int i = 0; i < V; ++i) { pos[i] = issue_vector_loads_f32(L[i], d[i], packed, excs + d[i].exc_off, tid, wave); }
+	// ALP_RD vectors: the dictionary into the vector's LDS (lanes 0..3 of wavefront 0; visible behind the barrier below)
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		if (d[i].scheme != ALPGPU_SCHEME_ALP && tid < 4) { reinterpret_cast<uint32_t*>(L[i].rdict)[tid] = static_cast<uint32_t>((tid < 2 ? dict[i].lo : dict[i].hi) >> (32 * (tid & 1))); }
+	}
 	// only a workgroup with exceptions zeroes its masks, behind the issue of its loads (decode_kernels.hip: k_decode_column)
 	bool any_exc = false;
 #pragma unroll
@@ -369,6 +420,10 @@ __global__ __launch_bounds__(kDecThreadsF) void k_decode_column_f32(const alpgpu
 		if (wave < V && v0 + wave < n_vectors) { // wave-uniform: wavefront w finishes vector w (V <= 4)
 			const double* part  = reinterpret_cast<const double*>(L[wave].stage) + lane;
 			double        total = (part[0] + part[64]) + (part[128] + part[192]);
+#pragma unroll
+			for (int i = 0; i < V; ++i) {
+				if (wave == i && d[i].exc_cnt > 0 && d[i].scheme == ALPGPU_SCHEME_ALP) { sink_exception_values_f32<SINK>(L[i], excs + d[i].exc_off, d[i].exc_cnt, lane, total, range_lo, range_hi); }
+			}
 			total               = wave_tree_sum_f64(total);
 			if (lane == 0) {
 				if constexpr (SINK == kSinkCountF) {
@@ -451,7 +506,7 @@ static int launch_sink_f32(hipStream_t stream, const alpgpu_column* col, void* d
 #define ALPGPU_SINK_STAGE_F32 3584 // bytes of packed words (bit widths <= 28) a wavefront of k_sink_direct_f32 stages in its LDS by LDS-DMA (0: none), as k_sink_direct does
 #endif
 #ifndef ALPGPU_SINK_STAGE_F32_MAX_EXC
-#define ALPGPU_SINK_STAGE_F32_MAX_EXC 48 // ... only for vectors with at most this many exceptions
+#define ALPGPU_SINK_STAGE_F32_MAX_EXC 1024 // ... only for vectors with at most this many exceptions (round 6: any — it was 48 while the exception values were looked up per quad; with them taken behind the quads the stage pays at every count: +1.5 %, call 26)
 #endif
 struct __attribute__((aligned(16))) SinkWaveLdsF32 {
 	static constexpr bool kPrefixInLds = true;
@@ -461,6 +516,7 @@ struct __attribute__((aligned(16))) SinkWaveLdsF32 {
 	uint32_t mask[32];
 	uint8_t  excv[4 * kExcStageF];
 	uint32_t pref[32]; // exceptions in front of mask word i
+	uint16_t rdict[8]; // ALP_RD: the rowgroup's dictionary (DecodeLdsF32)
 };
 template <int SINK>
 __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
@@ -536,6 +592,10 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 	if (lane == 0) { out[v] = static_cast<double>(em.excl + static_cast<int>(em.word)); }
 	return;
 #endif
+	if (!is_alp) { // wave-uniform: the dictionary into the wavefront's LDS, behind the issue of every load (its own scalar loads are waited for here, not in front of them)
+		if (lane < 4) { reinterpret_cast<uint32_t*>(L.rdict)[lane] = static_cast<uint32_t>((lane < 2 ? dict.lo : dict.hi) >> (32 * (lane & 1))); }
+		wave_lds_sync();
+	}
 	QuadWords w[4];
 #if ALPGPU_SINK_STAGE_F32 > 0
 	if (staged) {
@@ -576,6 +636,7 @@ __global__ __launch_bounds__(kDecThreadsF, 8) void k_sink_direct_f32(const alpgp
 #pragma unroll
 	for (int q = 0; q < 4; ++q) { finish_quad_f32<false, SINK>(L, w[q], d, dict, em, rec, nullptr, 64 * q + lane, q, lane, &part[q], lo, hi); }
 	double total = (part[0] + part[1]) + (part[2] + part[3]);
+	if (is_alp && cnt > 0) { sink_exception_values_f32<SINK>(L, rec, cnt, lane, total, lo, hi); }
 	total        = wave_tree_sum_f64(total);
 	if (lane == 0) {
 		if constexpr (SINK == kSinkCountF) {

@@ -245,11 +245,6 @@ __device__ __forceinline__ void stream_decode_vector(LDS& S, int buf, int tb, in
 		}
 	}
 	const uint32_t msk = bw_mask32(bw);
-	uint64_t       dlo = 0, dhi = 0;
-	if (!is_alp) {
-		dlo = (static_cast<uint64_t>(S.dict[buf][i][1]) << 32) | S.dict[buf][i][0];
-		dhi = (static_cast<uint64_t>(S.dict[buf][i][3]) << 32) | S.dict[buf][i][2];
-	}
 #pragma unroll
 	for (int qd = 0; qd < 4; ++qd) {
 		const int      tid  = 64 * qd + lane;
@@ -293,7 +288,7 @@ __device__ __forceinline__ void stream_decode_vector(LDS& S, int buf, int tb, in
 				const uint32_t f0  = static_cast<uint32_t>(w[qd].l0 >> (16 * c)) & 0xFFFFu;
 				const uint32_t f1  = static_cast<uint32_t>(w[qd].l1 >> (16 * c)) & 0xFFFFu;
 				const uint32_t idx = ((f0 >> ls) | (f1 << (16 - ls))) & lmsk;
-				uint32_t       l   = static_cast<uint32_t>((idx < 4 ? dlo >> (16 * idx) : dhi >> (16 * (idx & 3))) & 0xFFFFull);
+				uint32_t       l   = reinterpret_cast<const uint16_t*>(&S.dict[buf][i][0])[idx & 7u]; // (the dictionary looked up in LDS: decode_f32_kernels.hip)
 				if (hits & (1u << c)) {
 					if constexpr (DIRECT) {
 						l = reinterpret_cast<const uint16_t*>(rec_hbm)[rank];

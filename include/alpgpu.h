@@ -524,7 +524,10 @@ int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
  * (every float widens exactly): thread t = 64 w + L of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0, giving
  * p[w][L]; then s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); then the balanced tree over adjacent lanes over the 64 s[L] (as for
  * double; earlier in round 3 each wavefront ran the tree first).  ALPGPU_OPT_CONSUMER_PIPELINED: 0 / 2 = one wavefront per vector (the
- * default for float columns whatever they hold), 1 / 3 = the staged four-wavefront kernel; same bits. */
+ * default for float columns whatever they hold), 1 / 3 = the staged four-wavefront kernel; same bits.
+ * Round 6: in an ALP vector the exception POSITIONS are skipped in the quads (they contribute nothing to p[w][L]) and the exception VALUES
+ * join behind them, in the order of the record: s[L] += (double)exc[j] for j = L, L + 64, L + 128, ... before the tree.  ALP_RD vectors: as
+ * before, every value in its place.  (tests/test_decode_sum_gpu.py: host_sums_f32 is the replica.) */
 int alpgpu_decode_sum_f32(alpgpu_ctx* ctx, const alpgpu_column* col, double* d_sums);
 int alpgpu_decode_count_range_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float lo, float hi, uint32_t* d_counts);
 int alpgpu_pad_tail_f32(alpgpu_ctx* ctx, float* d_in, uint64_t n_values);

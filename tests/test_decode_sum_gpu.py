@@ -253,16 +253,37 @@ def test_decode_count_range_matches_numpy(ctx, oracle, name, shape):
 
 # ---- float columns (alpgpu_decode_sum_f32 / alpgpu_decode_count_range_f32) -------------------------------------------------
 
-def host_sums_f32(values):
+def host_sums_f32(values, enc=None):
     """values [n, 1024] float32 -> the order documented in include/alpgpu.h: thread t = 64 w + L adds values 4t..4t+3 (in double) -> p[w][L];
-    s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); adjacent-lane tree over the 64 s[L]"""
+    s[L] = (p[0][L] + p[1][L]) + (p[2][L] + p[3][L]); adjacent-lane tree over the 64 s[L].  Round 6: in an ALP vector the exception positions are SKIPPED
+    in the quads and the exception values join behind them: s[L] += exc[j] for j = L, L + 64, ... (ascending) before the tree.  enc: the column's encoding
+    (oracle layout: scheme, exc_cnt, pos, exc); None = no vector carries exceptions (or all of them are ALP_RD)"""
     n = values.shape[0]
-    v = values.astype(np.float64).reshape(n, 4, 64, 4)  # vector, wavefront, lane, quad element
-    p = np.zeros((n, 4, 64))
+    v = values.astype(np.float64).reshape(n, 1024).copy()
+    extra = np.zeros((n, 64))
     with np.errstate(invalid="ignore", over="ignore"):
+        if enc is not None:
+            for i in np.nonzero((enc["scheme"] == 2) & (enc["exc_cnt"] > 0))[0]:
+                c = int(enc["exc_cnt"][i])
+                v[i, enc["pos"][i, :c]] = 0.0
+                e = enc["exc"][i].view(np.float32)[:c].astype(np.float64)
+                for j in range(c):  # lane j % 64, ascending j
+                    extra[i, j % 64] = e[j] if j < 64 else extra[i, j % 64] + e[j]
+        v = v.reshape(n, 4, 64, 4)  # vector, wavefront, lane, quad element
+        p = np.zeros((n, 4, 64))
         for c in range(4):
             p = p + v[:, :, :, c]
-        return pairwise_tree((p[:, 0] + p[:, 1]) + (p[:, 2] + p[:, 3]))
+        s = (p[:, 0] + p[:, 1]) + (p[:, 2] + p[:, 3])
+        if enc is not None:
+            has = (enc["scheme"] == 2) & (enc["exc_cnt"] > 0)
+            for i in np.nonzero(has)[0]:
+                c = int(enc["exc_cnt"][i])
+                e = enc["exc"][i].view(np.float32)[:c].astype(np.float64)
+                t = s[i].copy()
+                for j in range(c):
+                    t[j % 64] = t[j % 64] + e[j]
+                s[i] = t
+        return pairwise_tree(s)
 
 
 COLUMNS_F32 = {
@@ -299,7 +320,7 @@ def test_decode_sum_f32_matches_documented_order(ctx, of32, name, kernel_f32):
     ctx.synchronize()
     dec = dec.cpu().numpy()
     assert np.array_equal(dec.view(np.uint32), col.view(np.uint32))
-    want = host_sums_f32(dec.reshape(-1, 1024))
+    want = host_sums_f32(dec.reshape(-1, 1024), enc)
     got = got.cpu().numpy()
     same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), f"{name}: {np.nonzero(~same)[0][:5]} {got[~same][:3]} {want[~same][:3]}"
@@ -312,7 +333,7 @@ def test_exception_carrying_float_vectors_across_a_full_chip(ctx, of32, kernel_f
     enc = of32.encode_column(col)
     assert enc["exc_cnt"].max() > 60
     dcol = capi.DeviceColumn.from_host(*layout.compact(enc, 4), dtype="f32")
-    want = host_sums_f32(col.reshape(-1, 1024))
+    want = host_sums_f32(col.reshape(-1, 1024), enc)
     for _ in range(3):
         got = ctx.decode_sum(dcol).cpu().numpy()
         same = got.view(np.uint64) == want.view(np.uint64)

@@ -112,6 +112,23 @@ case $step in
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   SIZES=1048576 BWS=1,2,3,4,5,6,7,8,9 SHAPES=2 run 200 rule.txt python tools/time_f32_narrow.py
   ;;
+24) # the ALP_RD dictionary looked up in LDS (float kernels): parity, then SUM / decode of the bench's float columns against the lookup in registers
+  run 600 tests.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q
+  run 200 sum.txt python tools/time_f32_sum.py
+  ALPGPU_LIB=build/variants/libalpgpu_rd_dict_regs.so run 200 sum_regs.txt python tools/time_f32_sum.py
+  ;;
+25) # the float sinks take an ALP vector's exception values behind the quads
+  run 600 tests.txt python -m pytest tests/test_float_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q
+  run 200 sum.txt python tools/time_f32_sum.py
+  ;;
+26) # the float sink's LDS stage for vectors of any exception count (it was: at most 48)
+  run 200 sum.txt python tools/time_f32_sum.py
+  ALPGPU_LIB=build/variants/libalpgpu_sinkf_stage_128.so run 200 sum_128.txt python tools/time_f32_sum.py
+  ALPGPU_LIB=build/variants/libalpgpu_sinkf_stage_all.so run 200 sum_all.txt python tools/time_f32_sum.py
+  ;;
+27) # dynamic instruction counts of the float sinks on the bench's float columns
+  bash tools/pmc_busy.sh r06_sumf python tools/time_f32_sum.py 262144 > $out/pmc.txt 2>&1
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
