@@ -57,6 +57,7 @@ struct __attribute__((aligned(16))) DecodeLdsT {
 	uint8_t  stage[STAGE];
 	uint32_t mask[32];
 	uint8_t  excv[kExcBytes]; // the head of the exception record as it lies in the stream (its values come first), brought in by LDS-DMA
+	uint16_t rdict[8];        // ALP_RD: the rowgroup's dictionary, looked up by ds_read_u16 (round 6; decode_f32_kernels.hip: DecodeLdsF32)
 };
 using DecodeLds = DecodeLdsT<kStageBytes>;
 // Round 6: columns whose vectors carry MORE exceptions than the 128-entry stage holds on average (bench.py's 10 %-exceptions column: 187 per vector) decode every
@@ -537,6 +538,7 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 		const uint64_t mask = bw_mask(rbw);
 		const uint32_t lmsk = (1u << lbw) - 1u;
 		const uint64_t dlo = dict.lo, dhi = dict.hi;
+		(void)dlo, (void)dhi;
 		auto rd_steps = [&](auto exc_mode) {
 			constexpr int EXC = decltype(exc_mode)::value; // as in the ALP arm
 #pragma unroll
@@ -559,8 +561,13 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 					const uint32_t w0 = lw[i].x, w1 = lw[i].y;
 					const uint32_t i0  = (((w0 & 0xFFFFu) >> s) | ((w1 & 0xFFFFu) << (16 - s))) & lmsk;
 					const uint32_t i1  = (((w0 >> 16) >> s) | ((w1 >> 16) << (16 - s))) & lmsk;
+#ifdef ALPGPU_RD_DICT_IN_REGISTERS // A/B (round 6): the lookup as it was until round 5 — a 3-way select through a 64-bit shift per value
 					uint64_t       l0  = ((i0 < 4 ? dlo >> (16 * i0) : dhi >> (16 * (i0 & 3))) & 0xFFFFull);
 					uint64_t       l1  = ((i1 < 4 ? dlo >> (16 * i1) : dhi >> (16 * (i1 & 3))) & 0xFFFFull);
+#else
+					uint64_t       l0  = L.rdict[i0 & 7u];
+					uint64_t       l1  = L.rdict[i1 & 7u];
+#endif
 					if (EXC == 1 || (EXC == 2 && cnt > 0)) {
 						const bool     staged = EXC == 1 ? true : all_staged;
 						int            rank;
@@ -709,6 +716,11 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 			if constexpr (ALPGPU_DECODE_PATCH_MODE == 2) { patch_table_zero(L[i], wave, lane); }
 		}
 	}
+	// ALP_RD vectors: the dictionary into the vector's LDS (four lanes; visible behind the barrier below)
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		if (d[i].scheme != ALPGPU_SCHEME_ALP && tid < 4) { reinterpret_cast<uint32_t*>(L[i].rdict)[tid] = static_cast<uint32_t>((tid < 2 ? dict[i].lo : dict[i].hi) >> (32 * (tid & 1))); }
+	}
 	// Only a workgroup that has exceptions zeroes its masks, and it does so behind the issue of all its loads: the barrier that fences the
 	// zeroes from the atomics waits for LDS only, so it falls into the shadow of the HBM round trip.  (Until round 3 every workgroup,
 	// exceptions or not, began with the zeroing write and a barrier in front of its first load.)
@@ -853,6 +865,10 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_pairs(const alpgpu_ve
 	const VectorConsts       c0 = load_vector_consts(rgs, v0, d0), c1 = load_vector_consts(rgs, v1, d1);
 	double2*                 o0 = reinterpret_cast<double2*>(out + v0 * kVec);
 	double2*                 o1 = reinterpret_cast<double2*>(out + v1 * kVec);
+	if (tid < 4) { // ALP_RD vectors: the dictionary into the vector's LDS (visible behind the barrier in front of the vector's unpack)
+		if (d0.scheme != ALPGPU_SCHEME_ALP) { reinterpret_cast<uint32_t*>(L[0].rdict)[tid] = static_cast<uint32_t>((tid < 2 ? c0.lo : c0.hi) >> (32 * (tid & 1))); }
+		if (d1.scheme != ALPGPU_SCHEME_ALP) { reinterpret_cast<uint32_t*>(L[1].rdict)[tid] = static_cast<uint32_t>((tid < 2 ? c1.lo : c1.hi) >> (32 * (tid & 1))); }
+	}
 	const bool together = n_here == 2 && (PAIRING == 3 || (vector_is_narrow(d0) && vector_is_narrow(d1))); // workgroup-uniform
 	// vectors whose exceptions are patched in after their stores (apply_patches): decoded as if they had none
 	// (ALPGPU_DECODE_PATCH_MODE 2 keeps its slot tables in k_decode_column only: here such vectors go through the mask)
@@ -926,6 +942,7 @@ struct __attribute__((aligned(16))) SinkWaveLds {
 	static constexpr uint32_t kExcBytes = kExcStageBytes;
 	uint8_t  excv[kExcStageBytes];
 	uint32_t pref[32]; // exceptions in front of mask word i
+	uint16_t rdict[8]; // ALP_RD: the rowgroup's dictionary (DecodeLdsT)
 };
 template <int SINK>
 __global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink_direct(const alpgpu_vector_desc* __restrict__ descs, const alpgpu_rowgroup_state* __restrict__ rgs,
@@ -988,6 +1005,10 @@ __global__ __launch_bounds__(64 * kDecWaves, ALPGPU_SINK_DIRECT_OCC) void k_sink
 	constexpr int     kRsrcFlags = 0x00020000; // gfx9 raw buffer, 32-bit data format
 	const BufferWords words {__builtin_amdgcn_make_buffer_rsrc(first, 0, 128 * d.bw, kRsrcFlags),
 	                         __builtin_amdgcn_make_buffer_rsrc(first + 128u * d.bw, 0, is_alp ? 0 : 128 * d.lbw, kRsrcFlags)};
+	if (!is_alp) { // wave-uniform: the dictionary into the wavefront's LDS
+		if (lane < 4) { reinterpret_cast<uint32_t*>(L.rdict)[lane] = static_cast<uint32_t>((lane < 2 ? dict.lo : dict.hi) >> (32 * (lane & 1))); }
+		wave_lds_sync();
+	}
 	double part[kDecWaves] = {0.0, 0.0, 0.0, 0.0};
 #if ALPGPU_SINK_STAGE > 0
 	if (staged) {

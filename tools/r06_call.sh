@@ -129,6 +129,11 @@ case $step in
 27) # dynamic instruction counts of the float sinks on the bench's float columns
   bash tools/pmc_busy.sh r06_sumf python tools/time_f32_sum.py 262144 > $out/pmc.txt 2>&1
   ;;
+28) # the ALP_RD dictionary looked up in LDS, double kernels: parity, then decode / SUM of an ALP_RD column against the lookup in registers
+  run 600 tests.txt python -m pytest tests/test_decode_gpu.py tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_reference_gpu.py -m gpu -x -q
+  run 200 rd.txt python tools/time_rd_f64.py
+  ALPGPU_LIB=build/variants/libalpgpu_rd64_regs.so run 200 rd_regs.txt python tools/time_rd_f64.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
