@@ -134,6 +134,10 @@ case $step in
   run 200 rd.txt python tools/time_rd_f64.py
   ALPGPU_LIB=build/variants/libalpgpu_rd64_regs.so run 200 rd_regs.txt python tools/time_rd_f64.py
   ;;
+29) # the whole GPU suite and the bench line on the tree as it is
+  run 900 tests.txt python -m pytest tests -m gpu -x -q
+  run 600 bench.txt python bench.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
