@@ -138,6 +138,10 @@ case $step in
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 600 bench.txt python bench.py
   ;;
+32) # narrow double columns under the read-ahead: two vectors per workgroup, five workgroups per CU — the suite, the rule against the old shape
+  run 900 tests.txt python -m pytest tests -m gpu -x -q
+  EXCS=0 BWS=1,2,3,4,5,6,7,8,9 PADS=0,11 run 400 pad.txt python tools/sweep_pad_narrow.py
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
