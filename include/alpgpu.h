@@ -151,7 +151,10 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
  * workgroup, or 0 (default) = choose from the column's size hints: 2 keeps twice the bytes in flight and is faster for
  * narrow columns (average packed width <= 17 bits; <= 22 bits when there are about two or more exceptions per vector: crossovers
  * re-measured at one-bit resolution in rounds 4 and 5), 1 for wider ones — every ALP_RD column.  A column without size hints: ALPGPU_OPT_DECODE_UNHINTED.
- * Float columns: 1, 2 or 4; 0 = 2, and 4 for columns of narrow vectors whose sizes are known (round 6).
+ * Float columns: 1, 2 or 4; 8 = one wavefront per vector; 16..30 = the column STREAMED by persistent workgroups (decode_stream_f32_kernels.hip: loading
+ * wavefronts several chunks ahead, decoding wavefronts that own whole vectors; the values name chunk size / arena / wavefront counts, 27 = chunks of 12 vectors,
+ * 24 KiB of records per chunk, 12 decoding + 2 loading wavefronts, one workgroup per CU).  0 = 2, and 27 for hinted columns of >= 32 768 vectors with more
+ * than 1.5 and at most 8.5 packed bits per value and fewer than ~2 exceptions per vector (round 6: 0.65-0.72 of the HBM peak against 0.60-0.62).
  * 4 (double columns; round 4) = four vectors per workgroup over a 2.25 KiB stage, vectors wider than 17 bits read straight from HBM:
  * built to lift the narrow widths' floor, measured SLOWER than 2 at every width (profiles/r04_decode_floor.txt), never chosen by 0.
  * ALPGPU_OPT_DECODE_PLAIN_STORES: 1 = ordinary instead of non-temporal stores. */
@@ -518,7 +521,7 @@ int alpgpu_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint3
 int alpgpu_rd_state_from_samples_f32(alpgpu_ctx* ctx, const float* d_samples, uint32_t n_samples, alpgpu_rowgroup_state* d_state);
 int alpgpu_encode_vectors_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
 int alpgpu_encode_f32(alpgpu_ctx* ctx, const float* d_in, uint64_t n_vectors, alpgpu_column* col);
-/* ALPGPU_OPT_DECODE_VECTORS_PER_WG applies with values 0 (auto), 1, 2 and 4 (float: four vectors over the full stage) */
+/* ALPGPU_OPT_DECODE_VECTORS_PER_WG applies with values 0 (auto), 1, 2, 4 (float: four vectors over the full stage), 8 and 16..30 (see the option) */
 int alpgpu_decode_f32(alpgpu_ctx* ctx, const alpgpu_column* col, float* d_out);
 /* The fused consumers of alpgpu_decode_sum_f64 / alpgpu_decode_count_range_f64 for float columns.  Sums accumulate in double
  * (every float widens exactly): thread t = 64 w + L of 256 adds values 4t, 4t+1, 4t+2, 4t+3 in that order starting from 0, giving

@@ -10,6 +10,7 @@
 #   sinkf: python tools/prof_sink_direct_f32.py 1048576                  (k_sink_direct_f32 and the staged float SUM sink)
 #   shapes: python tools/prof_decode_shapes.py 1048576                   (the auto rule's other decode launches: k_decode_pairs, two vectors x six workgroups per CU, one x six)
 #   ahead: python tools/prof_read_ahead.py 1048576                       (k_read_ahead beside k_decode_column<1> / <2> on 3- and 4-bit columns; kernel stats only mean something without --pmc)
+#   streamf: BWS=4 EXCS=0 SHAPES=2 SIZES=1048576 python tools/time_f32_narrow.py   (a 4-bit float column: k_decode_column_f32<2> and, by the rule, k_decode_stream_f32<12, 24576, 2, 12>)
 # (enc / encrd also decode what they encoded: the ALP_RD column's k_decode_column row; encf runs the float search in front of the float encode)
 # raw outputs under gpurun_out/<tag>_prof/, condensed by tools/summarize_round.py into profiles/<tag>_* (run the summary LOCALLY on the
 # merged directory, and remove a stale local gpurun_out/<tag>_prof first: rocprofv3 names its files after process ids, a second run
@@ -39,6 +40,7 @@ run narrow python $ROOT/tools/time_one.py 8:1048576:2
 run sinkf python $ROOT/tools/prof_sink_direct_f32.py 1048576
 run shapes python $ROOT/tools/prof_decode_shapes.py 1048576
 run ahead python $ROOT/tools/prof_read_ahead.py 1048576
+BWS=4 EXCS=0 SHAPES=2 SIZES=1048576 run streamf python $ROOT/tools/time_f32_narrow.py
 cd $ROOT
 if [ -f $OUT/dec_stats.log ]; then grep -h '"metric"' $OUT/dec_stats.log | tail -1 > $OUT/bench_under_rocprof.json; fi
 python tools/summarize_round.py $TAG $OUT

@@ -23,7 +23,7 @@ def short(name):
 
 
 cmds = {"dec": "python bench.py --steps 20 --warmup 10 --no-extras", "enc": "python tools/prof_encode.py mixed 1048576", "encf": "python tools/prof_float.py 1048576",
-        "encrd": "python tools/prof_encode.py rd 1048576", "cons": "python tools/prof_consumers.py 0 1048576", "narrow": "python tools/time_one.py 8:1048576:2", "sinkf": "python tools/prof_sink_direct_f32.py 1048576", "shapes": "python tools/prof_decode_shapes.py 1048576", "ahead": "python tools/prof_read_ahead.py 1048576"}
+        "encrd": "python tools/prof_encode.py rd 1048576", "cons": "python tools/prof_consumers.py 0 1048576", "narrow": "python tools/time_one.py 8:1048576:2", "sinkf": "python tools/prof_sink_direct_f32.py 1048576", "shapes": "python tools/prof_decode_shapes.py 1048576", "ahead": "python tools/prof_read_ahead.py 1048576", "streamf": "BWS=4 EXCS=0 SHAPES=2 SIZES=1048576 python tools/time_f32_narrow.py"}
 with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w") as w:
     w.write(f"# rocprofv3 --kernel-trace --stats --output-format csv; library sha256[:16] = {sha}; tree = {head}\n")
     w.write("Command,Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
