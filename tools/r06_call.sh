@@ -142,6 +142,12 @@ case $step in
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   EXCS=0 BWS=1,2,3,4,5,6,7,8,9 PADS=0,11 run 400 pad.txt python tools/sweep_pad_narrow.py
   ;;
+final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
+  run 900 tests.txt python -m pytest tests -m gpu -x -q
+  run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
+  timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
+  timeout 900 python bench.py --gpus 1 --column-gb 100 --steps 10 --warmup 3 > $out/bench_configs4_n1.json 2> $out/bench_configs4.err; echo "configs4 rc=$?"
+  ;;
 *) echo "unknown step $step";;
 esac
 tail -n 40 $out/*.txt | cut -c1-400
