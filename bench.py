@@ -616,7 +616,7 @@ def headline(value, world, args, elapsed, kern_ms, alg_bytes, decoded_bytes_rank
     }
 
 
-TAIL_BUDGET = 7900  # characters of stdout the driver keeps (8 KB), with a margin
+TAIL_BUDGET = 7700  # characters of stdout the driver keeps (8 KB), with a margin
 
 
 def fit_the_tail(result: dict) -> str:
