@@ -225,7 +225,7 @@ int alpgpu_set_option(alpgpu_ctx* ctx, int option, int64_t value) {
 	switch (option) {
 	case ALPGPU_OPT_DECODE_VECTORS_PER_WG:
 		if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && !(value >= 16 && value <= 30)) {
-			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2, 4 or (float columns) 8: one wavefront per vector, 16-18: streamed by persistent workgroups");
+			return fail(ALPGPU_ERR_INVALID, "decode vectors per workgroup must be 0 (auto), 1, 2, 4 or (float columns) 8: one wavefront per vector, 16-30: streamed by persistent workgroups");
 		}
 		ctx->decode_auto    = value == 0;
 		ctx->decode_vpw     = static_cast<int>(value);

@@ -3,23 +3,22 @@
 // Replaces, per vector, what decode_f32_kernels.hip replaces (falp<float> + patch_exceptions, include/alp/falp.hpp:28-44, include/alp/decoder.hpp:141-149;
 // ALP_RD: include/alp/rd.hpp:152-178) — same bytes, another schedule.
 //
-// Why (profiles/r06_float_decode.txt, call 8): with one small workgroup per two vectors, a 3-bit float column decodes at 0.49 of the HBM peak cold and 0.74 with
-// its records already in the Infinity Cache; the same launch WITHOUT its packed-word loads runs at 0.84.  The 384 bytes a vector reads cost as much as 3 KiB of
-// what it writes: every workgroup's life is descriptor round trip -> record round trip -> stores, one after the other, under a memory system saturated with
-// writes, and every wavefront works out the same per-vector scalars again (200 scalar + 142 vector instructions per wavefront for two vectors).  Here
-//   * a workgroup owns chunks c, c + G, c + 2 G ... of C consecutive vectors and is THREE chunks deep in flight: the descriptors of chunk k + 2 and the
-//     records of chunk k + 1 (packed words + exception records, LDS-DMA into a double-buffered arena whose slots are dealt by a prefix sum over the chunk's
-//     sizes) are on their way while chunk k is unpacked and stored: no load of the steady state is ever waited for right behind its issue;
-//   * what a vector's decode needs besides its words — widths, base, 10^f, 10^-e, the conversion shortcut's verdict, slot offsets — is worked out ONCE per
-//     chunk, one vector per LANE (not once per wavefront and vector in scalar code), and left in LDS as a 48-byte plan the unpack reads back;
-//   * exceptions are found through a table per vector — quad t of the vector -> (index of its first exception, 4 hit bits) — written by the lanes that hold
-//     the positions (they are sorted: a lane sees its neighbours) and cleaned by the threads that read it: no mask, no scan, no ds_bpermute, no zeroing pass.
-//   * the workgroup's FIFTH wavefront issues every load and is the only one that waits for memory; the four that unpack and store never wait for anything but
-//     the chunk barrier: on gfx9 loads and stores share one counter, and a wavefront that both prefetches and stores drains its stores (a round trip through a
-//     memory system saturated with writes) once per chunk — the first form of this kernel did, and ran a chunk of 8 vectors in 4 us per workgroup;
-//   * a decoding wavefront owns WHOLE vectors (lane L: the quads L, 64 + L, 128 + L, 192 + L): one plan read per vector and wavefront, four independent chains
-//     per lane, the vector's exception table written and read by the same wavefront (no barrier between the two).
+// Why (profiles/r06_float_decode.txt): with one small workgroup per two vectors, a 3-bit float column decodes at 0.49 of the HBM peak cold and 0.74 with its records
+// already in the Infinity Cache; the same launch WITHOUT its packed-word loads runs at 0.84.  The 384 bytes a vector reads cost as much as 3 KiB of what it writes:
+// every workgroup's life is descriptor round trip -> record round trip -> stores, one after the other, under a memory system saturated with writes, and every
+// wavefront works out the same per-vector scalars again (200 scalar + 142 vector instructions per wavefront for two vectors).  Here
+//   * ONE workgroup per CU owns chunks c, c + G, c + 2 G ... of C consecutive vectors.  Its D LOADING wavefronts issue every load — a chunk's descriptors a turn
+//     ahead, then its packed words and exception records as two flat LDS-DMA copies into the chunk's arena (a column written in vector order: the chunk's records are
+//     one span of each stream; otherwise vector by vector) — D chunks ahead of the decode, and are the only wavefronts that wait for memory;
+//   * its NDEC DECODING wavefronts own whole vectors (lane L: the quads L, 64 + L, 128 + L, 192 + L) and wait for nothing but the chunk barrier: on gfx9 loads and
+//     stores share one counter, and a wavefront that both prefetches and stores drains its stores — a round trip through a memory system saturated with writes —
+//     once per chunk (the first form of this kernel did: 4 us per chunk of 8 vectors and workgroup);
+//   * what a vector's decode needs besides its words — widths, base, 10^f, 10^-e, the conversion shortcut's verdict, slot offsets — is worked out ONCE per chunk,
+//     one vector per LANE (not once per wavefront and vector in scalar code), and left in LDS as a 48-byte plan the unpack reads back;
+//   * exceptions are found through a table per vector — quad t -> (index of its first exception, 4 hit bits) — written by the decoding wavefront from the (sorted)
+//     positions and cleaned by the lanes that read it: no mask, no scan, no ds_bpermute, no zeroing pass.
 // A vector whose record does not fit what is left of the arena is decoded from HBM directly (bounded buffer loads; positions and values from the stream).
+// Shapes (template parameters; ALPGPU_OPT_DECODE_VECTORS_PER_WG 16-30): the rule uses <12, 24576, 2, 12> (decode_policy.hpp: policy_stream_f32).
 #include "alp_device_f32.hpp"
 #include "decode_f32_device.hpp"
 #include "launch.hpp"
@@ -189,15 +188,16 @@ __device__ __forceinline__ void stream_issue_chunk(LDS& S, int db, int buf, cons
 // stage 3: the exception table of one vector from its (sorted) positions
 template <class POS>
 __device__ __forceinline__ void stream_build_table(uint16_t* __restrict__ table, POS pos, int cnt, int lane) {
+	// (positions are taken modulo 1024: a malformed record cannot reach beyond the vector's table — the kernels follow a column's records as they find them)
 	for (int j = lane; j < cnt; j += 64) {
-		const uint32_t p     = pos[j];
+		const uint32_t p     = pos[j] & 1023u;
 		const uint32_t q     = p >> 2;
-		const uint32_t prev  = j > 0 ? pos[j - 1] : 0xFFFFu;
+		const uint32_t prev  = j > 0 ? (pos[j - 1] & 1023u) : 0xFFFFu;
 		if ((prev >> 2) != q) { // the first exception of its quad: it speaks for the (at most three) that follow
 			uint32_t hits = 1u << (p & 3u);
 #pragma unroll
 			for (int t = 1; t < 4; ++t) {
-				const uint32_t pn = pos[j + t < cnt ? j + t : cnt - 1];
+				const uint32_t pn = pos[j + t < cnt ? j + t : cnt - 1] & 1023u;
 				if ((pn >> 2) == q) { hits |= 1u << (pn & 3u); }
 			}
 			table[q] = static_cast<uint16_t>((static_cast<uint32_t>(j) << 4) | hits);
