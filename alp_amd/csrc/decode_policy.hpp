@@ -71,7 +71,8 @@ __host__ __device__ inline bool policy_read_ahead_auto(uint64_t n_vectors, doubl
 	const double limit = value_bytes == 8 ? (with_exc ? kReadAheadBitsExc : kReadAheadBits) : (with_exc ? kReadAheadBitsExcF32 : kReadAheadBitsF32);
 	// (float columns of 1-bit vectors: 0.75 cold, 0.72 with the second stream of reads; double columns of almost nothing but 0-bit vectors — the gov26 shape, a pure stream of
 	//  stores: 0.82 with six workgroups per CU and no second stream, 0.71-0.72 with it: kEmptyVectorsBits)
-	const double least = value_bytes == 8 ? kEmptyVectorsBits : 1.5;
+	// (float columns of 1-bit vectors WITH exceptions: 0.44 -> 0.52 with the read-ahead, call 3 — the 1.5-bit floor is for exception-free ones)
+	const double least = value_bytes == 8 ? kEmptyVectorsBits : (with_exc ? 0.5 : 1.5);
 	return n_vectors >= kReadAheadVectors && packed_bytes <= limit * 128.0 * static_cast<double>(n_vectors) && packed_bytes >= least * 128.0 * static_cast<double>(n_vectors);
 }
 
