@@ -142,6 +142,10 @@ case $step in
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   EXCS=0 BWS=1,2,3,4,5,6,7,8,9 PADS=0,11 run 400 pad.txt python tools/sweep_pad_narrow.py
   ;;
+34) # the double sinks take an ALP vector's exception values behind the pairs: parity, then the SUM with 0 / 20 / 100 exceptions per vector
+  run 900 tests.txt python -m pytest tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_last_register_gpu.py tests/test_encode_gpu.py -m gpu -x -q
+  run 300 sum_exc.txt python tools/time_sum_exc.py
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
