@@ -350,7 +350,11 @@ static int decode_one(alpgpu_ctx* ctx, const alpgpu_column* col, void* d_out) {
 	// The read-ahead (read_ahead_kernels.hip): a few persistent workgroups on the context's second stream pull the column's streams into the Infinity
 	// Cache a bounded distance ahead of the decode kernel, which tells them where it is.  Started first so that it is ahead from the first workgroup on.
 	// (a float column streamed by persistent workgroups prefetches for itself; the read-ahead beside it changed nothing: call 14)
+#ifdef ALPGPU_STREAM_WITH_READ_AHEAD // measurement build: the read-ahead beside the streamed float decode too
+	const bool ahead = read_ahead_for(ctx, col, VB);
+#else
 	const bool ahead = read_ahead_for(ctx, col, VB) && !(VB == 4 && (decode_shape_f32(ctx, col) & 0xFF) >= 16);
+#endif
 	uint64_t   tag   = 0;
 	if (ahead) {
 		tag = next_progress_tag(ctx);
