@@ -524,6 +524,13 @@ __device__ __forceinline__ void decode_vector_quarters(const LDS& L, const WORDS
 					alp_steps(ExcMode<1> {}, ArithShortcut<1> {});
 				}
 			} else {
+#ifndef ALPGPU_SINK_NO_NARROW_ARITH // round 6, call 36: the SINKS' vectors of <= 32 bits through the 32-bit unpack too (7 vector instructions per value instead of 13; until
+				// then the store decode's only): SUM of 2-24-bit columns 0.54-0.76 -> 0.45-0.69 ms per 1 Mi vectors (-9 to -15 %), with 20 exceptions per vector -8 to -13 %,
+				// the benchmark column -3 %; same bits.  -DALPGPU_SINK_NO_NARROW_ARITH: the A/B.
+				if (!kPerVectorLoops && bw <= 32) {
+					alp_steps(ExcMode<2> {}, ArithShortcut<2> {});
+				} else
+#endif
 				alp_steps(ExcMode<2> {}, ArithShortcut<1> {});
 			}
 		} else {
