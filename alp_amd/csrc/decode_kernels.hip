@@ -687,7 +687,20 @@ __global__ __launch_bounds__(64 * kDecWaves) void k_decode_column(const alpgpu_v
 	const int      tid  = static_cast<int>(threadIdx.x);
 	const int      lane = tid & 63;
 	const int      wave = wave_in_wg();
+#ifdef ALPGPU_DEC_XCD_GROUP // experiment (round 6, call 40): consecutive workgroups go to consecutive XCDs; here each XCD takes ALPGPU_DEC_XCD_GROUP CONSECUTIVE workgroups' vectors of a span of 8 groups
+	uint64_t b_idx = blockIdx.x;
+	{
+		constexpr uint64_t kG = ALPGPU_DEC_XCD_GROUP, kSpan = 8 * kG;
+		const uint64_t     full = (static_cast<uint64_t>(gridDim.x) / kSpan) * kSpan;
+		if (b_idx < full) {
+			const uint64_t r = b_idx % kSpan;
+			b_idx            = b_idx - r + (r & 7u) * kG + (r >> 3);
+		}
+	}
+	const uint64_t v0 = (wg_offset + b_idx) * V;
+#else
 	const uint64_t v0   = (wg_offset + blockIdx.x) * V;
+#endif
 	if (v0 >= n_vectors) { return; }
 	// An unhinted decode (api_decode.hip) launches every candidate shape; the plan kernel in front of them has written which one runs (bits 8.. of patch_max
 	// = this launch's number, 0 = not a candidate: the usual launch).  One scalar load, taken by candidates only; a closed candidate costs its dispatch.

@@ -146,6 +146,14 @@ case $step in
   run 900 tests.txt python -m pytest tests/test_decode_sum_gpu.py tests/test_fuzz_gpu.py tests/test_last_register_gpu.py tests/test_encode_gpu.py -m gpu -x -q
   run 300 sum_exc.txt python tools/time_sum_exc.py
   ;;
+40) # the store decode with each XCD taking G consecutive workgroups' vectors (G = 4 / 32 / 512) against the dispatcher's round-robin, arms alternating twice
+  for rep in 1 2; do
+    run 200 xcd.txt python tools/time_decode_lib.py
+    for g in 4 32 512; do ALPGPU_LIB=build/variants/libalpgpu_xcd$g.so run 200 xcd.txt python tools/time_decode_lib.py; done
+  done
+  EXC=20 run 200 xcd_exc.txt python tools/time_decode_lib.py
+  EXC=20 ALPGPU_LIB=build/variants/libalpgpu_xcd32.so run 200 xcd_exc.txt python tools/time_decode_lib.py
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
