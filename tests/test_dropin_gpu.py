@@ -71,6 +71,19 @@ def test_one_host_column_over_several_contexts(tmp_path):
     assert p.returncode == 0 and "multi_test: 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
 
 
+def test_per_vector_api_from_several_host_threads(tmp_path):
+    """The reference's vector functions are re-entrant (its scratch is thread_local since issue #41, encoder.hpp:314-319; its end-to-end benchmark decodes from
+    worker threads, run_query.cpp:233-305).  Six host threads run the reference-shaped loop over columns of their own (double and float; decimal, ALP_RD,
+    exceptions, specials) through include/alp.hpp at the same time — one process-wide context and stream, device scratch per thread (gpu_bridge.hpp): every byte
+    they produce equals what the same loop produced alone, and every vector round-trips."""
+    exe = tmp_path / "threads_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", f"-I{ROOT}/include", "-o", str(exe), f"{ROOT}/tests/cpp/threads_test.cpp",
+                           f"-L{ROOT}/alp_amd", "-lalpgpu", f"-Wl,-rpath,{ROOT}/alp_amd"])
+    p = subprocess.run([str(exe), "6", "130", "2"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    assert p.returncode == 0 and ", 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
 def test_header_tables_are_the_devices_and_encode_value(tmp_path, ctx, oracle):
     """alp::Constants<PT>::{FRAC_ARR, EXP_ARR, FACT_ARR} (host copies in include/alp/constants.hpp) against what the DEVICE computes with ITS tables,
     and alp::encoder<PT>::encode_value<SAFE> (through alpgpu_encode_value_*) against the oracle."""
