@@ -219,7 +219,8 @@ int         alpgpu_synchronize(alpgpu_ctx* ctx);
 #define ALPGPU_OPT_ENCODE_UNORDERED 10
 /* ALPGPU_OPT_DECODE_RESIDENCY_PAD (tuning aid): KiB of unused dynamic LDS every double store-decode workgroup asks for, which caps the workgroups
  * resident per CU (160 KiB / (its own 9.6 or 19.3 KiB + this)); -1 (default) = chosen from the column's size hints (what a CU wants
- * is an amount of bytes in flight).  Never changes results. */
+ * is an amount of bytes in flight).  Never changes results (tests/test_decode_gpu.py: 0 .. 120 KiB at one and two vectors per workgroup); a pad that does not fit
+ * beside the workgroup's own LDS any more (150 KiB with two vectors per workgroup) makes the launch fail: alpgpu_decode_f64 returns ALPGPU_ERR_HIP, nothing is written. */
 #define ALPGPU_OPT_DECODE_RESIDENCY_PAD 11
 /* ALPGPU_OPT_DECODE_READ_AHEAD (store decode, double since round 5, float since round 6): alpgpu_decode_f64 / _f32 start a READ-AHEAD beside the decode kernel — a few persistent workgroups
  * on the context's second stream that pull descriptors, packed words and exception records into the Infinity Cache ALPGPU_OPT_DECODE_READ_AHEAD_US

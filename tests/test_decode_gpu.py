@@ -106,6 +106,24 @@ def test_tuning_options_do_not_change_results(ctx, oracle, vectors_per_wg, plain
         ctx.set_option(capi.OPT_DECODE_PLAIN_STORES, 0)
 
 
+@pytest.mark.parametrize("pad_kib", [0, 3, 6, 11, 14, 40, 120])
+def test_residency_pad_does_not_change_results(ctx, oracle, pad_kib):
+    """ALPGPU_OPT_DECODE_RESIDENCY_PAD (unused dynamic LDS per store-decode workgroup = fewer workgroups resident per CU; the rule's own choices are 0 / 3 / 6 /
+    11 / 14 KiB): never changes a byte, at one and at two vectors per workgroup, up to a pad that leaves ONE workgroup per CU."""
+    from alp_amd import capi
+    try:
+        ctx.set_option(capi.OPT_DECODE_RESIDENCY_PAD, pad_kib)
+        for vpw in (1, 2):
+            ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, vpw)
+            for name in ("mixed_1pct", "mixed_30pct", "rd_latlon", "adversarial"):
+                col = COLUMNS[name]()
+                got = gpu_decode(ctx, oracle.encode_column(col))
+                assert np.array_equal(got.view(np.uint64), col.view(np.uint64)), (name, pad_kib, vpw)
+    finally:
+        ctx.set_option(capi.OPT_DECODE_RESIDENCY_PAD, -1)
+        ctx.set_option(capi.OPT_DECODE_VECTORS_PER_WG, 0)
+
+
 @pytest.mark.parametrize("pairing", [1, 2, 3])
 def test_pairing_workgroups_write_the_same_bytes(ctx, oracle, pairing):
     """ALPGPU_OPT_DECODE_PAIRING (k_decode_pairs: workgroups that own two vectors and decide from their descriptors how to run them): every

@@ -178,6 +178,27 @@ def test_two_pass_encode_gives_the_same_column(ctx, oracle, name):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
+@pytest.mark.parametrize("name", ["mixed_1pct", "mixed_10pct", "drifting_k", "adversarial", "rd_unit", "every_width", "long_mixed"])
+def test_classic_single_pass_kernel_gives_the_same_column(ctx, name):
+    """ALPGPU_OPT_ENCODE_KERNEL = ALPGPU_ENCODE_KERNEL_CLASSIC (round 3's k_encode_fused: integers and packed units in registers, two tiles per CU) is a
+    shipped option: the same bytes as the default lean kernel on ALP, ALP_RD, every packed width, heavy exception loads and a column of > 1000 look-back
+    tiles, and the decode of its column is the input."""
+    from alp_amd import capi
+    col_np = {"rd_unit": lambda: datagen.rd_column(210, seed=12), "every_width": lambda: datagen.every_bit_width_column(),
+              "long_mixed": lambda: datagen.mixed_column(9000, seed=78, exc_rate=0.03)}.get(name, COLUMNS.get(name))()
+    d1, x = gpu_encode(ctx, col_np)
+    try:
+        ctx.set_option(capi.OPT_ENCODE_KERNEL, 1)
+        d2, _ = gpu_encode(ctx, col_np)
+        out = ctx.decode(d2)
+        ctx.synchronize()
+    finally:
+        ctx.set_option(capi.OPT_ENCODE_KERNEL, 0)
+    for a, b in zip(d1.to_host(), d2.to_host()):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert torch.equal(out.view(torch.int64), x.view(torch.int64))
+
+
 def test_long_column_spans_several_fused_launches_worth_of_tiles(ctx, oracle):
     """many tiles: the look-back chain across > 1000 workgroups must give the oracle's offsets"""
     col_np = datagen.mixed_column(6000, seed=77, exc_rate=0.02)
