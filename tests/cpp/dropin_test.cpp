@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -153,6 +154,33 @@ static int test_u8_lanes() {
 	return failures;
 }
 
+// the small public helpers of alp::encoder / alp::decoder (encoder.hpp:75-106, decoder.hpp:128-131): known answers from their definitions
+template <class PT>
+static int test_helpers(const char* name) {
+	using E  = alp::encoder<PT>;
+	using ST = typename alp::inner_t<PT>::st;
+	int failures = 0;
+	auto expect = [&](bool ok, const char* what) {
+		if (!ok) { std::printf("FAIL helpers<%s>: %s\n", name, what), ++failures; }
+	};
+	expect(E::template count_bits<uint64_t>(0) == 0 && E::template count_bits<uint64_t>(1) == 1 && E::template count_bits<uint64_t>(255) == 8 && E::template count_bits<uint64_t>(256) == 9, "count_bits(x)");
+	expect(E::template count_bits<uint64_t>(1ull << 63) == 64 && E::template count_bits<uint32_t>(0x80000000u) == 32, "count_bits of the top bit");
+	expect(E::template count_bits<ST>(ST(5), ST(-3)) == 4 && E::template count_bits<ST>(ST(7), ST(7)) == 0 && E::template count_bits<ST>(ST(1023), ST(0)) == 10, "count_bits(max, min)");
+	expect(E::template count_bits<ST>(std::numeric_limits<ST>::max(), std::numeric_limits<ST>::min()) == sizeof(ST) * 8, "count_bits over the whole range wraps like the unsigned type");
+	expect(E::is_impossible_to_encode(std::numeric_limits<PT>::quiet_NaN()) && E::is_impossible_to_encode(std::numeric_limits<PT>::infinity()) &&
+	           E::is_impossible_to_encode(-std::numeric_limits<PT>::infinity()) && E::is_impossible_to_encode(PT(-0.0)) && E::is_impossible_to_encode(PT(1e19)) &&
+	           E::is_impossible_to_encode(PT(-1e19)),
+	       "is_impossible_to_encode of NaN, infinities, -0.0 and values beyond the int64 limits");
+	expect(!E::is_impossible_to_encode(PT(0.0)) && !E::is_impossible_to_encode(PT(1.5)) && !E::is_impossible_to_encode(PT(-123456.0)) && !E::is_impossible_to_encode(PT(9.0e18)), "is_impossible_to_encode of ordinary values");
+	// decode_value = (PT)(integer) * FACT[f] * FRAC[e], one value through the vector kernel
+	const PT dv = alp::decoder<PT>::decode_value(ST(12345), 2, 3);
+	const PT want = static_cast<PT>(static_cast<ST>(12345) * static_cast<ST>(100)) * alp::Constants<PT>::FRAC_ARR[3];
+	expect(std::memcmp(&dv, &want, sizeof(PT)) == 0, "decode_value(12345, f = 2, e = 3)");
+	expect(E::template encode_value<true>(PT(12.5), 0, 1) == ST(125) && E::template encode_value<false>(PT(-7.25), 0, 2) == ST(-725), "encode_value of exact decimals");
+	if (!failures) { std::printf("ok   helpers<%s>\n", name); }
+	return failures;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 2) { return 2; }
 	const std::string dir = argv[1];
@@ -165,6 +193,7 @@ int main(int argc, char** argv) {
 		++n;
 	}
 	failures += test_u8_lanes();
+	failures += test_helpers<double>("double") + test_helpers<float>("float");
 	std::printf("%d columns, %d failures\n", n, failures);
 	return failures ? 1 : 0;
 }
