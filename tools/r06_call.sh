@@ -154,6 +154,30 @@ case $step in
   EXC=20 run 200 xcd_exc.txt python tools/time_decode_lib.py
   EXC=20 ALPGPU_LIB=build/variants/libalpgpu_xcd32.so run 200 xcd_exc.txt python tools/time_decode_lib.py
   ;;
+41) # soak: the whole GPU suite three times, smoke, the default bench line
+  for i in 1 2 3; do run 600 tests_$i.txt python -m pytest tests -m gpu -x -q -p no:cacheprovider; done
+  run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
+  timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
+  ;;
+42) # the whole-column entry points captured into a hipGraph and replayed
+  run 800 graph.txt python -m pytest tests/test_graph_gpu.py -m gpu -q -s -p no:cacheprovider
+  ;;
+43) # host threads: the per-vector drop-in API from six threads, the column ABI from five threads with a context each
+  run 800 threads.txt python -m pytest tests/test_threads_gpu.py tests/test_dropin_gpu.py -m gpu -q -s -p no:cacheprovider -k thread
+  ;;
+44) # the N = 8 bench path end to end with eight ranks on ONE GPU (gloo; bookkeeping, not a measurement) -> profiles/r06_bench_8ranks_one_gpu.json
+  ALPGPU_BENCH_TEST_SHARED_GPU=1 timeout 800 python bench.py --gpus 8 --column-gb 4 --steps 3 --warmup 1 > $out/bench8.json 2> $out/bench8.err
+  ;;
+45) # parity of two shipped options that had no test: the classic single-pass encode kernel, the decode's residency pad
+  run 800 opts.txt python -m pytest tests/test_encode_gpu.py tests/test_decode_gpu.py -m gpu -q -p no:cacheprovider -k "classic or residency"
+  ;;
+47) # the final tree: the whole GPU suite twice, smoke
+  for i in 1 2; do run 700 tests_$i.txt python -m pytest tests -m gpu -x -q -p no:cacheprovider; done
+  run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
+  ;;
+49) # fuzz campaign with fresh seeds: 20 000 double + 20 000 float columns against the oracle, 10 000 against the real reference (call 48: 2 000)
+  ALPGPU_FUZZ_ROUNDS=20000 ALPGPU_FUZZ_SEED_BASE=2000000 run 2800 fuzz.txt python -m pytest tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider -n 8
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
