@@ -178,6 +178,9 @@ case $step in
 49) # fuzz campaign with fresh seeds: 20 000 double + 20 000 float columns against the oracle, 10 000 against the real reference (call 48: 2 000)
   ALPGPU_FUZZ_ROUNDS=20000 ALPGPU_FUZZ_SEED_BASE=2000000 run 2800 fuzz.txt python -m pytest tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider -n 8
   ;;
+50) # random combinations of the options over random columns, 500 s
+  FUZZ_SECONDS=500 run 1200 fuzz_options.txt python tools/fuzz_options.py 100000 1
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
