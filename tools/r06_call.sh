@@ -181,6 +181,9 @@ case $step in
 50) # random combinations of the options over random columns, 500 s
   FUZZ_SECONDS=500 run 1200 fuzz_options.txt python tools/fuzz_options.py 100000 1
   ;;
+51) # the host-column entry points over random lengths and context counts, 400 s
+  FUZZ_SECONDS=400 run 1000 fuzz_host.txt python tools/fuzz_host.py 100000 1
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
