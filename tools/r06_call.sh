@@ -184,6 +184,9 @@ case $step in
 51) # the host-column entry points over random lengths and context counts, 400 s
   FUZZ_SECONDS=400 run 1000 fuzz_host.txt python tools/fuzz_host.py 100000 1
   ;;
+52) # corrupted blobs: refused or decoded inside their buffers, 300 s
+  FUZZ_SECONDS=300 run 600 fuzz_blob.txt python tools/fuzz_blob.py 1000000 1
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
