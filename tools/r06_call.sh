@@ -187,6 +187,11 @@ case $step in
 52) # corrupted blobs: refused or decoded inside their buffers, 300 s
   FUZZ_SECONDS=300 run 600 fuzz_blob.txt python tools/fuzz_blob.py 1000000 1
   ;;
+53) # more of the three fuzzers with new seeds (200 000 columns, 6 888 option sets, 4 545 host columns: no difference)
+  ALPGPU_FUZZ_ROUNDS=80000 ALPGPU_FUZZ_SEED_BASE=9000000 run 1500 fuzz.txt python -m pytest tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider -n 8
+  FUZZ_SECONDS=900 run 1200 fuzz_options.txt python tools/fuzz_options.py 1000000 2
+  FUZZ_SECONDS=500 run 800 fuzz_host.txt python tools/fuzz_host.py 1000000 2
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
