@@ -192,6 +192,10 @@ case $step in
   FUZZ_SECONDS=900 run 1200 fuzz_options.txt python tools/fuzz_options.py 1000000 2
   FUZZ_SECONDS=500 run 800 fuzz_host.txt python tools/fuzz_host.py 1000000 2
   ;;
+56) # third round of the fuzzers (9 889 option sets, 250 000 columns: no difference)
+  FUZZ_SECONDS=1200 run 1500 fuzz_options.txt python tools/fuzz_options.py 1000000 3
+  ALPGPU_FUZZ_ROUNDS=100000 ALPGPU_FUZZ_SEED_BASE=50000000 run 1200 fuzz.txt python -m pytest tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider -n 8
+  ;;
 final) # the closing run: whole GPU suite, smoke, the bench line, configs[4] at N = 1 (tools/profile_round.sh r06 is a call of its own)
   run 900 tests.txt python -m pytest tests -m gpu -x -q
   run 300 smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
